@@ -1,0 +1,160 @@
+/* walt_amd.h -- C ABI of the MI355X-native WALT seed-and-extend hot path.
+ *
+ * This is the drop-in boundary for the body of WALT's two `#pragma omp parallel
+ * for` loops (reference src/walt/mapping.cpp:494-499 and paired.cpp:664-669)
+ * plus the serial pair-merge loop (paired.cpp:684-699).  Plain pointers and
+ * sizes only; no C++/torch types.  Every function returns 0 on success or a
+ * negative WALT_E* code; walt_last_error() gives the message.  The library
+ * never calls exit().  All four strand indexes stay resident in HBM, so ONE
+ * call covers both strand passes that the reference makes per batch
+ * (mapping.cpp:491-500).
+ *
+ * Citations are file:line in smithlabcode/walt v1.0.
+ */
+#ifndef WALT_AMD_H_
+#define WALT_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WALT_OK 0
+#define WALT_EINVAL (-1)   /* bad argument */
+#define WALT_EIO (-2)      /* file missing / short read (reference: FREAD_CHECK exit, util.hpp:62-69) */
+#define WALT_EHIP (-3)     /* HIP runtime error / no device */
+#define WALT_EBASE (-4)    /* non-ACGT base in a read (reference: getBits exit, util.hpp:117-119) */
+#define WALT_ENOMEM (-5)
+#define WALT_EFORMAT (-6)  /* malformed .dbindex */
+
+/* strand_mask bits for walt_index_open: which strand files to make resident */
+#define WALT_STRAND_CT00 1u
+#define WALT_STRAND_CT01 2u
+#define WALT_STRAND_GA10 4u
+#define WALT_STRAND_GA11 8u
+#define WALT_STRANDS_CT 3u   /* single-end default (mapping.cpp:443-445) */
+#define WALT_STRANDS_GA 12u  /* single-end -A (mapping.cpp:446-449) */
+#define WALT_STRANDS_ALL 15u /* paired-end (paired.cpp:589-593) */
+
+/* BestMatch, mapping.hpp:39-52: 16 bytes, strand char at offset 8. */
+typedef struct {
+  uint32_t genome_pos;
+  uint32_t times;
+  char strand;
+  char pad_[3]; /* written as 0 */
+  uint32_t mismatch;
+} walt_best_match;
+
+/* CandidatePosition, paired.hpp:35-46: 12 bytes. */
+typedef struct {
+  uint32_t genome_pos;
+  char strand;
+  char pad_[3];
+  uint32_t mismatch;
+} walt_candidate;
+
+/* What MergePairedEndResults (paired.cpp:474-545) derives for one pair. */
+typedef struct {
+  walt_best_match m1, m2; /* per-mate records the writers print (paired.cpp:515-569) */
+  uint32_t best_times;    /* 0: no pair, 1: unique proper pair, >=2: ambiguous */
+  int32_t frag_len;       /* `len` of OutputBestPairedResults when best_times==1, else 0 */
+  int32_t best_i, best_j; /* indices into the ranked lists when best_times==1, else -1 */
+  uint32_t pair_mm;       /* r1.mismatch + r2.mismatch of the reported pair */
+  uint32_t pad_[3];
+} walt_pair_result;
+
+/* Work/statistics block returned by the batch calls (all counters are sums
+ * over the batch; too_short counts one per strand pass like
+ * stat.num_of_short_reads++ at mapping.cpp:230-233 / paired.cpp:112-115). */
+typedef struct {
+  uint64_t too_short;
+  uint64_t probes;     /* seed probes into non-empty buckets (diagnostic) */
+  uint64_t candidates; /* candidates verified (diagnostic) */
+  uint64_t big_regions;/* regions handled wave-cooperatively (diagnostic) */
+} walt_batch_stats;
+
+typedef struct walt_index walt_index;
+
+const char* walt_last_error(void);
+int walt_device_count(void);
+
+/* ---- index ------------------------------------------------------------- */
+
+/* Replaces ReadIndexHeadInfo + per-batch ReadIndex (reference.cpp:381-417,
+ * 324-351; call sites mapping.cpp:437,492 and paired.cpp:583,661): reads
+ * <path> and the selected <path>_CT00/_CT01/_GA10/_GA11 files once, uploads
+ * them to `device` and builds the derived HBM structures (2-bit genome, entry
+ * keys, directory).  dir_digits < 0 picks the directory depth from the index
+ * size. */
+int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_digits,
+                    walt_index** out);
+
+/* Same from host arrays laid out exactly like the .dbindex strand files
+ * (reference.cpp:302-322): per strand s in {CT00,CT01,GA10,GA11} (NULL = not
+ * present) genome bytes [genome_len], counter [4^12+1], index [index_size]. */
+int walt_index_from_host(uint32_t n_chrom, const uint32_t* chrom_len, const char* const* chrom_names,
+                         const uint8_t* const genome[4], const uint32_t* const counter[4],
+                         const uint32_t* const index[4], const uint32_t index_size[4], int device,
+                         int dir_digits, walt_index** out);
+
+void walt_index_close(walt_index* idx);
+
+/* Genome::num_of_chroms / length / name / start_index (reference.hpp:44-70). */
+uint32_t walt_index_n_chrom(const walt_index* idx);
+uint32_t walt_index_chrom_len(const walt_index* idx, uint32_t i);
+const char* walt_index_chrom_name(const walt_index* idx, uint32_t i);
+uint64_t walt_index_genome_len(const walt_index* idx);
+uint64_t walt_index_device_bytes(const walt_index* idx);
+int walt_index_dir_digits(const walt_index* idx);
+/* number of 4^12 buckets that take the literal search (diagnostic), per strand */
+uint64_t walt_index_bad_buckets(const walt_index* idx, int strand);
+
+/* ---- single-end: replaces the strand loop + omp loop over SingleEndMapping,
+ *      mapping.cpp:486-500 / 224-316 ------------------------------------- */
+
+/* Host buffers.  bases: concatenated sanitised reads (only ACGT, as
+ * LoadReadsFromFastqFile leaves them, mapping.cpp:101-103); offsets[n+1].
+ * out[n] is initialised by the callee to (0,0,'+',max_mm) (mapping.cpp:486-489)
+ * and holds the state after the '+' and '-' passes. */
+int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offsets, uint32_t n,
+                      int ag_wildcard, uint32_t max_mismatches, uint32_t b, walt_best_match* out,
+                      walt_batch_stats* stats);
+
+/* Device-resident form (pointers are HBM addresses on idx's device; stream is a
+ * hipStream_t or NULL).  Asynchronous: returns after enqueueing; d_stats
+ * (walt_batch_stats, device memory) is accumulated into, not cleared.
+ * d_workspace must hold walt_se_workspace_bytes(n, max_read_len) bytes. */
+size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len);
+int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
+                             uint32_t max_read_len, int ag_wildcard, uint32_t max_mismatches,
+                             uint32_t b, void* d_out, void* d_stats, void* d_workspace, void* stream);
+
+/* ---- paired-end: replaces PairEndMapping over both mates and strands
+ *      (paired.cpp:642-672 / 106-201), the heap drain (685-692) and the pair
+ *      search of MergePairedEndResults (474-545) ----------------------------- */
+
+/* ranked1/ranked2 (optional, may be NULL): n*top_k candidates per mate in the
+ * pop order of the reference's priority_queue, ranked_n1/2[n] their counts. */
+int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offsets1,
+                      const char* bases2, const uint64_t* offsets2, uint32_t n,
+                      uint32_t max_mismatches, uint32_t b, uint32_t top_k, int frag_range,
+                      walt_pair_result* out, walt_candidate* ranked1, uint32_t* ranked_n1,
+                      walt_candidate* ranked2, uint32_t* ranked_n2, walt_batch_stats* stats /*[2]*/);
+
+size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k);
+int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* d_offsets1,
+                             const void* d_bases2, const void* d_offsets2, uint32_t n,
+                             uint32_t max_read_len, uint32_t max_mismatches, uint32_t b,
+                             uint32_t top_k, int frag_range, void* d_out, void* d_stats /*[2]*/,
+                             void* d_workspace, void* stream);
+
+/* ---- makedb-compatible index builder (host; reference.cpp:79-322,
+ *      makedb.cpp:46-159).  Byte-identical files for N-free FASTA. ---------- */
+int walt_makedb(const char* fasta_path, const char* out_dbindex_path, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WALT_AMD_H_ */

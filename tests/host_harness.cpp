@@ -1,0 +1,231 @@
+// host_harness.cpp -- CPU unit-test harness for the per-lane building blocks of
+// the HIP kernels (walt_amd/csrc/core.h, index_core.h).
+//
+// TEST CODE ONLY.  It compiles the SAME inline functions the kernels use with
+// g++ and drives them one read at a time, so search / packing / verification /
+// fold / heap logic can be checked against the oracle without a GPU.  The
+// wave-cooperative parts of the kernels are exercised only by the -m gpu tests.
+// This is not a product path: nothing in walt_amd/ links or loads it.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../walt_amd/csrc/host_common.h"
+#include "../walt_amd/csrc/index_core.h"
+
+using namespace walt;
+
+struct HStrand {
+  std::vector<uint32_t> g2, cnt, bad, dir;
+  std::vector<Ent> ent;
+  StrandView view;
+};
+struct HIndex {
+  HStrand s[4];
+  bool present[4];
+  std::vector<uint32_t> start;
+  IndexView view;
+};
+
+template <int NW>
+static void verify_region(const IndexView& iv, const StrandView& sv, const Region& reg, uint32_t seed_i,
+                          uint32_t len, const uint32_t* rd, const uint32_t* mk, RegionSummary& sum) {
+  for (uint32_t j = reg.l; j <= reg.u; ++j) {
+    uint32_t pos = sv.ent[j].pos;
+    uint32_t chr = chrom_id(iv.start_index, iv.n_chrom, pos);
+    if (pos - iv.start_index[chr] < seed_i) continue;
+    uint32_t gp = pos - seed_i;
+    if (gp + len >= iv.start_index[chr + 1]) continue;
+    uint32_t mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
+    sum = summary_merge(sum, summary_one(mm, gp));
+  }
+}
+
+extern "C" {
+
+void* hh_index_new(uint32_t n_chrom, const uint32_t* chrom_len, int dir_digits) {
+  HIndex* h = new HIndex();
+  h->start.assign(n_chrom + 1, 0);
+  for (uint32_t i = 0; i < n_chrom; ++i) h->start[i + 1] = h->start[i] + chrom_len[i];
+  memset(&h->view, 0, sizeof(h->view));
+  h->view.n_chrom = n_chrom;
+  h->view.dir_digits = (uint32_t)dir_digits;
+  h->view.dir_slots = pow3(kKeyWeight + dir_digits);
+  for (int i = 0; i < 4; ++i) h->present[i] = false;
+  return h;
+}
+
+// returns number of BAD buckets, or -1 on an invalid index
+long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t genome_len,
+                         const uint32_t* counter, const uint32_t* index, uint32_t index_size) {
+  HIndex* h = reinterpret_cast<HIndex*>(hp);
+  HStrand& s = h->s[strand];
+  const uint32_t ga = strand >= 2;
+  const uint32_t nwords = (genome_len + 15) / 16;
+  s.g2.assign((size_t)nwords + 96, 0);
+  for (uint32_t i = 0; i < genome_len; ++i) {
+    uint32_t c = base_code(genome[i]);
+    if (c > 3 || c == (ga ? 2u : 1u)) return -1;
+    s.g2[i >> 4] |= c << (2 * (i & 15));
+  }
+  s.cnt.assign(counter, counter + kNumBuckets + 1);
+  s.bad.assign(kNumBuckets / 32, 0);
+  s.ent.resize((size_t)index_size + 1);
+  for (uint32_t j = 0; j < index_size; ++j) {
+    bool t;
+    if ((uint64_t)index[j] + kMinSeedLen > genome_len) return -1;
+    s.ent[j] = make_ent(s.g2.data(), genome_len, index[j], t);
+    uint32_t hsh = hash_at(s.g2.data(), index[j]);
+    if (!(s.cnt[hsh] <= j && j < s.cnt[hsh + 1])) return -1;
+    if (t) s.bad[hsh >> 5] |= 1u << (hsh & 31);
+  }
+  for (uint32_t j = 1; j < index_size; ++j) {
+    if (ent_key(s.ent[j - 1]) > ent_key(s.ent[j])) {
+      uint32_t ha = hash_at(s.g2.data(), s.ent[j - 1].pos), hb = hash_at(s.g2.data(), s.ent[j].pos);
+      if (ha == hb) s.bad[ha >> 5] |= 1u << (ha & 31);
+    }
+  }
+  const uint32_t D = h->view.dir_digits, slots = h->view.dir_slots;
+  s.dir.resize((size_t)slots + 1);
+  for (uint32_t K = 0; K < slots; ++K) s.dir[K] = dir_entry(s.cnt.data(), s.ent.data(), D, ga, K);
+  s.dir[slots] = index_size;
+  s.view.g2 = s.g2.data(); s.view.cnt = s.cnt.data(); s.view.bad = s.bad.data(); s.view.dir = s.dir.data();
+  s.view.ent = s.ent.data(); s.view.index_size = index_size; s.view.genome_len = genome_len; s.view.ga = ga;
+  s.view.pad_ = 0;
+  h->view.s[strand] = s.view;
+  h->view.start_index = h->start.data();
+  h->present[strand] = true;
+  long nbad = 0;
+  for (uint32_t w : s.bad) nbad += __builtin_popcount(w);
+  return nbad;
+}
+
+// test hook: force every bucket onto the literal path (or clear the flags)
+void hh_index_force_bad(void* hp, int strand, int on) {
+  HIndex* h = reinterpret_cast<HIndex*>(hp);
+  for (uint32_t& w : h->s[strand].bad) w = on ? 0xFFFFFFFFu : 0u;
+}
+
+void hh_index_free(void* hp) { delete reinterpret_cast<HIndex*>(hp); }
+
+// lane-serial emulation of k_map_se for NW = 64 words (any length <= 1024)
+int hh_map_se(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, int ag, uint32_t max_mm,
+              uint32_t b, BestMatch* out, uint64_t* too_short) {
+  HIndex* h = reinterpret_cast<HIndex*>(hp);
+  const IndexView& iv = h->view;
+  const std::vector<uint32_t>& mt = compare_mask_table();
+  constexpr int NW = 64;
+  std::vector<uint32_t> rec(packed_fields(NW));
+  *too_short = 0;
+  for (uint32_t r = 0; r < n; ++r) {
+    uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
+    if (len > 1024) return -1;
+    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_digits, NW,
+                   rec.data(), 1))
+      return -2;
+    BestMatch best; best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
+    const uint32_t* rd = &rec[1];
+    if (len < kMinReadLen) {
+      *too_short += 2;
+    } else {
+      uint32_t repeats = seed_repeats(len);
+      for (uint32_t fi = 0; fi < 2; ++fi) {
+        const StrandView& sv = iv.s[(ag ? 2 : 0) + fi];
+        for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+          if (best.mismatch == 0 && seed_i) break;
+          if (best.mismatch == 1 && seed_i >= 2) break;
+          const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
+          Region reg = seed_lookup(iv, sv, care, care[kCareWords], repeats);
+          uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
+          if (size == 0 || size > b) continue;
+          uint32_t mk[NW];
+          for (int w = 0; w < NW; ++w) mk[w] = compare_mask_word(mt.data(), seed_i, repeats, len, (uint32_t)w);
+          RegionSummary sum = summary_empty();
+          verify_region<NW>(iv, sv, reg, seed_i, len, rd, mk, sum);
+          fold_region(best, sum, fi == 0 ? '+' : '-');
+        }
+      }
+    }
+    out[r] = best;
+  }
+  return 0;
+}
+
+// lane-serial emulation of the paired-end top-k kernel for one mate:
+// ranked[n*top_k] in pop order, ranked_n[n].
+int hh_pe_topk(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, int ag, uint32_t max_mm,
+               uint32_t b, uint32_t top_k, Candidate* ranked, uint32_t* ranked_n, uint64_t* too_short) {
+  HIndex* h = reinterpret_cast<HIndex*>(hp);
+  const IndexView& iv = h->view;
+  const std::vector<uint32_t>& mt = compare_mask_table();
+  constexpr int NW = 64;
+  std::vector<uint32_t> rec(packed_fields(NW));
+  std::vector<HeapEnt> heap(top_k + 1);
+  *too_short = 0;
+  for (uint32_t r = 0; r < n; ++r) {
+    uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
+    if (len > 1024) return -1;
+    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_digits, NW,
+                   rec.data(), 1))
+      return -2;
+    const uint32_t* rd = &rec[1];
+    uint32_t hsize = 0;
+    if (len < kMinReadLen) {
+      *too_short += 2;
+    } else {
+      uint32_t repeats = seed_repeats(len);
+      for (uint32_t fi = 0; fi < 2; ++fi) {
+        const StrandView& sv = iv.s[(ag ? 2 : 0) + fi];
+        for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+          bool full = hsize >= top_k;
+          if (full && heap_mm(heap[0]) == 0 && seed_i) break;        // paired.cpp:133-135
+          if (full && heap_mm(heap[0]) == 1 && seed_i >= 2) break;   // paired.cpp:139-141
+          const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
+          Region reg = seed_lookup(iv, sv, care, care[kCareWords], repeats);
+          uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
+          if (size == 0 || size > b) continue;
+          uint32_t mk[NW];
+          for (int w = 0; w < NW; ++w) mk[w] = compare_mask_word(mt.data(), seed_i, repeats, len, (uint32_t)w);
+          for (uint32_t j = reg.l; j <= reg.u; ++j) {
+            uint32_t pos = sv.ent[j].pos;
+            uint32_t chr = chrom_id(iv.start_index, iv.n_chrom, pos);
+            if (pos - iv.start_index[chr] < seed_i) continue;
+            uint32_t gp = pos - seed_i;
+            if (gp + len >= iv.start_index[chr + 1]) continue;
+            uint32_t mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
+            if (mm > max_mm) continue;
+            HeapEnt e; e.pos = gp; e.mms = mm | (fi << 31);
+            topk_push(heap.data(), hsize, top_k, e);
+          }
+        }
+      }
+    }
+    uint32_t k = 0;
+    while (hsize) {
+      HeapEnt e = heap_pop(heap.data(), hsize);
+      Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
+      ranked[(uint64_t)r * top_k + k++] = c;
+    }
+    ranked_n[r] = k;
+  }
+  return 0;
+}
+
+void hh_pe_merge(void* hp, const Candidate* r1, const uint32_t* n1, const Candidate* r2, const uint32_t* n2,
+                 uint32_t top_k, const uint64_t* off1, const uint64_t* off2, uint32_t n, int frag_range,
+                 uint32_t max_mm, PairResult* out) {
+  HIndex* h = reinterpret_cast<HIndex*>(hp);
+  for (uint32_t j = 0; j < n; ++j)
+    pair_merge(r1 + (uint64_t)j * top_k, (int)n1[j], r2 + (uint64_t)j * top_k, (int)n2[j],
+               (uint32_t)(off1[j + 1] - off1[j]), (uint32_t)(off2[j + 1] - off2[j]), h->view.start_index,
+               h->view.n_chrom, frag_range, max_mm, out[j]);
+}
+
+// expose the literal tables for tests/test_seedtab.py
+void hh_get_nocare(uint32_t* out3x150) {
+  for (int s = 0; s < 3; ++s) memcpy(out3x150 + 150 * s, nocare_row(s), 150 * sizeof(uint32_t));
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+"""walt_amd -- MI355X-native seed-and-extend hot path of WALT behind a C ABI.
+
+This package is only the thin Python binding of ``lib/libwalt_amd.so`` (built
+from ``csrc/`` by ``python -m walt_amd.build`` / ``__graft_entry__.build()``);
+the product is the HIP library declared in ``include/walt_amd.h``.  There is
+no CPU fallback: if the library is missing the import fails loudly, and the
+mapping calls return WALT_EHIP when no GPU is present.
+
+Function names and argument meaning follow the reference call sites they
+replace (smithlabcode/walt v1.0): ``map_se_batch`` is the strand loop + OpenMP
+loop over ``SingleEndMapping`` (mapping.cpp:486-500), ``map_pe_batch`` the
+loops over ``PairEndMapping`` plus ``MergePairedEndResults``
+(paired.cpp:642-699), ``Index`` is ``ReadIndexHeadInfo``/``ReadIndex``
+(reference.cpp:324-417), ``makedb`` is makedb.cpp:128-159.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwalt_amd.so")
+
+WALT_OK = 0
+STRAND_CT00, STRAND_CT01, STRAND_GA10, STRAND_GA11 = 1, 2, 4, 8
+STRANDS_CT, STRANDS_GA, STRANDS_ALL = 3, 12, 15
+
+# numpy views of the C structs (include/walt_amd.h)
+best_match_dtype = np.dtype(
+    [("genome_pos", "<u4"), ("times", "<u4"), ("strand", "S1"), ("pad", "V3"), ("mismatch", "<u4")])
+candidate_dtype = np.dtype([("genome_pos", "<u4"), ("strand", "S1"), ("pad", "V3"), ("mismatch", "<u4")])
+pair_result_dtype = np.dtype(
+    [("m1", best_match_dtype), ("m2", best_match_dtype), ("best_times", "<u4"), ("frag_len", "<i4"),
+     ("best_i", "<i4"), ("best_j", "<i4"), ("pair_mm", "<u4"), ("pad", "V12")])
+batch_stats_dtype = np.dtype(
+    [("too_short", "<u8"), ("probes", "<u8"), ("candidates", "<u8"), ("big_regions", "<u8")])
+assert best_match_dtype.itemsize == 16 and candidate_dtype.itemsize == 12
+assert pair_result_dtype.itemsize == 64 and batch_stats_dtype.itemsize == 32
+
+
+class WaltError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("walt_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libwalt_amd.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "walt_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, u32, u64, ci = c.c_void_p, c.c_uint32, c.c_uint64, c.c_int
+    L.walt_last_error.restype = c.c_char_p
+    L.walt_device_count.restype = ci
+    L.walt_index_open.argtypes = [c.c_char_p, ci, c.c_uint, ci, c.POINTER(vp)]
+    L.walt_index_from_host.argtypes = [u32, vp, vp, vp, vp, vp, vp, ci, ci, c.POINTER(vp)]
+    L.walt_index_close.argtypes = [vp]
+    L.walt_index_close.restype = None
+    L.walt_index_n_chrom.argtypes = [vp]
+    L.walt_index_n_chrom.restype = u32
+    L.walt_index_chrom_len.argtypes = [vp, u32]
+    L.walt_index_chrom_len.restype = u32
+    L.walt_index_chrom_name.argtypes = [vp, u32]
+    L.walt_index_chrom_name.restype = c.c_char_p
+    L.walt_index_genome_len.argtypes = [vp]
+    L.walt_index_genome_len.restype = u64
+    L.walt_index_device_bytes.argtypes = [vp]
+    L.walt_index_device_bytes.restype = u64
+    L.walt_index_dir_digits.argtypes = [vp]
+    L.walt_index_dir_digits.restype = ci
+    L.walt_index_bad_buckets.argtypes = [vp, ci]
+    L.walt_index_bad_buckets.restype = u64
+    L.walt_map_se_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, vp, vp]
+    L.walt_se_workspace_bytes.argtypes = [u32, u32]
+    L.walt_se_workspace_bytes.restype = c.c_size_t
+    L.walt_map_se_batch_device.argtypes = [vp, vp, vp, u32, u32, ci, u32, u32, vp, vp, vp, vp]
+    L.walt_map_pe_batch.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, ci, vp, vp, vp, vp, vp, vp]
+    L.walt_pe_workspace_bytes.argtypes = [u32, u32, u32]
+    L.walt_pe_workspace_bytes.restype = c.c_size_t
+    L.walt_map_pe_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, ci, vp, vp, vp, vp]
+    L.walt_makedb.argtypes = [c.c_char_p, c.c_char_p, ci]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != WALT_OK:
+        raise WaltError(rc, lib().walt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().walt_device_count()
+
+
+def makedb(fasta_path, out_dbindex_path, threads=1):
+    """makedb -c <fasta_path> -o <out_dbindex_path> (makedb.cpp:128-159)."""
+    _check(lib().walt_makedb(os.fsencode(fasta_path), os.fsencode(out_dbindex_path), int(threads)))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def pack_reads(seqs):
+    """list of str/bytes -> (bases uint8[total], offsets uint64[n+1])."""
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    return bases, offsets
+
+
+class Index:
+    """Device-resident index (all selected strands stay in HBM)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def open(cls, dbindex_path, device=0, strands=STRANDS_ALL, dir_digits=-1):
+        h = ctypes.c_void_p()
+        _check(lib().walt_index_open(os.fsencode(dbindex_path), int(device), int(strands), int(dir_digits),
+                                     ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_host(cls, chrom_len, genome, counter, index, chrom_names=None, device=0, dir_digits=-1):
+        """genome/counter/index: 4-lists (CT00, CT01, GA10, GA11) of numpy arrays or None."""
+        n = len(chrom_len)
+        cl = np.ascontiguousarray(chrom_len, dtype=np.uint32)
+        names = None
+        keep = []
+        if chrom_names is not None:
+            arr = (ctypes.c_char_p * n)(*[os.fsencode(x) for x in chrom_names])
+            names = ctypes.cast(arr, ctypes.c_void_p)
+            keep.append(arr)
+        g = (ctypes.c_void_p * 4)()
+        cn = (ctypes.c_void_p * 4)()
+        ix = (ctypes.c_void_p * 4)()
+        sz = (ctypes.c_uint32 * 4)()
+        for s in range(4):
+            if genome[s] is None:
+                continue
+            ga = np.ascontiguousarray(genome[s], dtype=np.uint8)
+            ca = np.ascontiguousarray(counter[s], dtype=np.uint32)
+            ia = np.ascontiguousarray(index[s], dtype=np.uint32)
+            keep += [ga, ca, ia]
+            g[s], cn[s], ix[s], sz[s] = ga.ctypes.data, ca.ctypes.data, ia.ctypes.data, ia.size
+        h = ctypes.c_void_p()
+        _check(lib().walt_index_from_host(n, cl.ctypes.data, names, ctypes.cast(g, ctypes.c_void_p),
+                                          ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(ix, ctypes.c_void_p),
+                                          ctypes.cast(sz, ctypes.c_void_p), int(device), int(dir_digits),
+                                          ctypes.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            lib().walt_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def n_chrom(self):
+        return lib().walt_index_n_chrom(self._h)
+
+    @property
+    def chrom_lengths(self):
+        return [lib().walt_index_chrom_len(self._h, i) for i in range(self.n_chrom)]
+
+    @property
+    def chrom_names(self):
+        return [lib().walt_index_chrom_name(self._h, i).decode() for i in range(self.n_chrom)]
+
+    @property
+    def genome_len(self):
+        return lib().walt_index_genome_len(self._h)
+
+    @property
+    def device_bytes(self):
+        return lib().walt_index_device_bytes(self._h)
+
+    @property
+    def dir_digits(self):
+        return lib().walt_index_dir_digits(self._h)
+
+    def bad_buckets(self, strand):
+        return lib().walt_index_bad_buckets(self._h, strand)
+
+    # -- single-end -----------------------------------------------------------
+    def map_se_batch(self, bases, offsets, ag_wildcard=False, max_mismatches=6, b=5000):
+        """Host-buffer form.  Returns (best_match[n], stats)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out = np.zeros(n, dtype=best_match_dtype)
+        stats = np.zeros(1, dtype=batch_stats_dtype)
+        _check(lib().walt_map_se_batch(self._h, _ptr(bases), _ptr(offsets), n, int(bool(ag_wildcard)),
+                                       int(max_mismatches), int(b), _ptr(out), _ptr(stats)))
+        return out, stats[0]
+
+    def map_se_batch_device(self, d_bases, d_offsets, n, max_read_len, d_out, d_stats, d_workspace, stream=0,
+                            ag_wildcard=False, max_mismatches=6, b=5000):
+        """Device-pointer form (ints are HBM addresses, stream a hipStream_t value)."""
+        _check(lib().walt_map_se_batch_device(self._h, d_bases, d_offsets, int(n), int(max_read_len),
+                                              int(bool(ag_wildcard)), int(max_mismatches), int(b), d_out, d_stats,
+                                              d_workspace, stream))
+
+    # -- paired-end -----------------------------------------------------------
+    def map_pe_batch(self, bases1, offsets1, bases2, offsets2, max_mismatches=6, b=5000, top_k=50,
+                     frag_range=1000, want_ranked=False):
+        bases1 = np.ascontiguousarray(bases1, dtype=np.uint8)
+        bases2 = np.ascontiguousarray(bases2, dtype=np.uint8)
+        offsets1 = np.ascontiguousarray(offsets1, dtype=np.uint64)
+        offsets2 = np.ascontiguousarray(offsets2, dtype=np.uint64)
+        n = offsets1.size - 1
+        if offsets2.size - 1 != n:
+            raise ValueError("The number of reads in paired-end files should be the same.")  # paired.cpp:673-677
+        out = np.zeros(n, dtype=pair_result_dtype)
+        stats = np.zeros(2, dtype=batch_stats_dtype)
+        r1 = r2 = n1 = n2 = None
+        if want_ranked:
+            r1 = np.zeros((n, top_k), dtype=candidate_dtype)
+            r2 = np.zeros((n, top_k), dtype=candidate_dtype)
+            n1 = np.zeros(n, dtype=np.uint32)
+            n2 = np.zeros(n, dtype=np.uint32)
+        _check(lib().walt_map_pe_batch(self._h, _ptr(bases1), _ptr(offsets1), _ptr(bases2), _ptr(offsets2), n,
+                                       int(max_mismatches), int(b), int(top_k), int(frag_range), _ptr(out),
+                                       _ptr(r1), _ptr(n1), _ptr(r2), _ptr(n2), _ptr(stats)))
+        if want_ranked:
+            return out, stats, (r1, n1, r2, n2)
+        return out, stats

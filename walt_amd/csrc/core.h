@@ -1,0 +1,508 @@
+// core.h -- per-lane building blocks of the MI355X seed-and-extend path.
+//
+// Everything here is a pure inline function over plain pointers, compiled
+// into the HIP kernels (map_se.hip / map_pe.hip / index_dev.hip) and -- for CPU
+// unit tests only (tests/host_harness.cpp) -- by g++.  No wave intrinsics live
+// here; those are in the kernels.
+//
+// Data layout in HBM (one StrandView per strand file _CT00/_CT01/_GA10/_GA11):
+//   g2   : genome, 2 bits/base (A0 C1 G2 T3 -- order preserving, as the
+//          reference's char compares at mapping.cpp:172-173,188-189 need),
+//          16 bases per u32, base i at bits [2(i%16), 2(i%16)+1].
+//   cnt  : the .dbindex counter array, 4^12+1 bucket starts (reference.hpp:79-92).
+//   ent  : one 12-byte entry per .dbindex index slot: {key_hi, key_lo, pos}.
+//          pos is the original index[] value; key is a DERIVED 64-bit string of
+//          the 32 genome chars at care positions 12..43 behind pos
+//          (F2CAREDPOSITION[12..43], seedpattern.hpp:424-430), char 12 in the
+//          top 2 bits.  It is what LowerBound/UpperBound (mapping.cpp:166-196)
+//          would read through genome.sequence[index[mid] + cmp_pos].
+//   bad  : bitmap over the 4^12 buckets; bit set = keys of this bucket are not
+//          non-decreasing (entries whose care positions run over a chromosome
+//          end are sorted by the "beyond the end is smallest" rule of
+//          reference.cpp:258-288 but are READ as real bytes) or touch the end of
+//          the genome.  Such buckets take the literal search; all others take
+//          the key search, which returns the same [l,u].
+//   dir  : DERIVED directory over the first 12+D care chars in base 3 (a
+//          converted strand has a 3-letter alphabet): dir[K] = first slot whose
+//          (12+D)-char prefix is >= K.  Replaces the first D rounds of the
+//          per-character LowerBound/UpperBound narrowing by one lookup.
+#ifndef WALT_AMD_CORE_H_
+#define WALT_AMD_CORE_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define WALT_HD __host__ __device__ __forceinline__
+#else
+#define WALT_HD inline
+#endif
+
+namespace walt {
+
+// seedpattern.hpp:355-361, 424
+constexpr uint32_t kKeyWeight = 12;     // F2SEEDKEYWEIGHT
+constexpr uint32_t kNumCare = 60;       // F2CAREDPOSITION_SIZE
+constexpr uint32_t kMinReadLen = 38;    // MINIMALREADLEN
+constexpr uint32_t kMinSeedLen = 36;    // MINIMALSEEDLEN
+constexpr uint32_t kMaxRepeats = 50;    // cap at mapping.cpp:238
+constexpr uint32_t kMinRepeats = 12;    // (38 - 2) / 3
+constexpr uint32_t kKeyChars = 32;      // care chars 12..43 held in Ent::key
+constexpr uint32_t kMaskWords = 10;     // 160 bases of table-driven compare mask
+constexpr uint32_t kNumBuckets = 1u << 24;
+constexpr uint32_t kMaxDirDigits = 8;   // 3^(12+8) < 2^32
+constexpr uint32_t kEraseBucket = 500000;  // reference.cpp:211
+
+WALT_HD uint32_t care_pos(uint32_t i) { return 1 + 3 * i; }  // F2CAREDPOSITION[i]
+
+struct Ent {
+  uint32_t key_hi, key_lo, pos;
+};
+
+struct StrandView {
+  const uint32_t* g2;
+  const uint32_t* cnt;
+  const uint32_t* bad;
+  const uint32_t* dir;
+  const Ent* ent;
+  uint32_t index_size;
+  uint32_t genome_len;
+  uint32_t ga;  // 0: C->T strand (letters A,G,T)  1: G->A strand (letters A,C,T)
+  uint32_t pad_;
+};
+
+struct IndexView {
+  StrandView s[4];               // CT00, CT01, GA10, GA11
+  const uint32_t* start_index;   // n_chrom + 1 (Genome::start_index, reference.hpp:55)
+  uint32_t n_chrom;
+  uint32_t dir_digits;           // D
+  uint32_t dir_slots;            // 3^(12+D)
+  uint32_t pad_;
+};
+
+// BestMatch, mapping.hpp:39-52.  Same 16-byte layout.
+struct BestMatch {
+  uint32_t genome_pos;
+  uint32_t times;
+  uint32_t strand;  // low byte '+' / '-', upper bytes 0
+  uint32_t mismatch;
+};
+
+// Packed read record produced by pack_reads (one per read and conversion).
+//   words[NW]      converted read, 2 bits/base, 16 bases per word
+//   care[s][4]     for seed shift s: the chars at read offsets s+1+3i, i<50,
+//                  MSB first (char 0 in bits 31..30 of care[s][0])
+//   slot[s]        first directory slot of the (12+d)-char prefix, d=min(D,n)
+// kept in SoA form in HBM: field f of read r at base[f * stride + r].
+constexpr uint32_t kCareWords = 4;
+constexpr uint32_t kPerSeedWords = kCareWords + 1;
+WALT_HD uint32_t packed_fields(uint32_t nw) { return 1 + nw + 3 * kPerSeedWords; }
+// field 0: length; 1..nw: words; then per seed: care[4], slot
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+WALT_HD uint32_t pow3(uint32_t e) {
+  uint32_t r = 1;
+  for (uint32_t i = 0; i < e; ++i) r *= 3;
+  return r;
+}
+
+// seed geometry, mapping.cpp:235-239
+WALT_HD uint32_t seed_repeats(uint32_t read_len) {
+  uint32_t r = (read_len - 2) / 3;
+  return r < kMaxRepeats ? r : kMaxRepeats;
+}
+
+// 2-bit code of a sanitised base; 4 = not ACGT (getBits would exit, util.hpp:117-119)
+WALT_HD uint32_t base_code(uint8_t c) {
+  return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+// read conversion, mapping.cpp:142-164 (C->T: code 1 -> 3; G->A: code 2 -> 0)
+WALT_HD uint32_t convert_code(uint32_t code, uint32_t ga) {
+  return ga ? (code == 2 ? 0u : code) : (code == 1 ? 3u : code);
+}
+// base-3 digit of a converted code on a strand (C->T: A,G,T -> 0,1,2; G->A: A,C,T -> 0,1,2)
+WALT_HD uint32_t digit3(uint32_t code, uint32_t ga) { return ga ? code - (code >> 1) : (code + 1) >> 1; }
+WALT_HD uint32_t code_of_digit3(uint32_t d, uint32_t ga) { return ga ? (d == 2 ? 3u : d) : (d == 0 ? 0u : d + 1); }
+
+WALT_HD uint32_t g2_code(const uint32_t* g2, uint64_t pos) {
+  return (g2[pos >> 4] >> (2 * (uint32_t)(pos & 15))) & 3u;
+}
+// genome char as the reference reads it: beyond the end compares below every base
+WALT_HD int gchar(const StrandView& sv, uint64_t pos) {
+  return pos < sv.genome_len ? (int)g2_code(sv.g2, pos) : -1;
+}
+
+// getChromID, reference.cpp:43-60
+WALT_HD uint32_t chrom_id(const uint32_t* start_index, uint32_t n_chrom, uint32_t pos) {
+  uint32_t l = 0, h = n_chrom;
+  while (l < h) {
+    uint32_t m = (l + h + 1) >> 1;
+    if (pos >= start_index[m]) l = m; else h = m - 1;
+  }
+  return l;
+}
+
+WALT_HD uint64_t ent_key(const Ent& e) { return ((uint64_t)e.key_hi << 32) | e.key_lo; }
+
+// char p (0..49) of an MSB-first care string held in 4 words
+WALT_HD uint32_t care_char(const uint32_t* care, uint32_t p) {
+  uint32_t w = p >> 4;
+  uint32_t v = w == 0 ? care[0] : w == 1 ? care[1] : w == 2 ? care[2] : care[3];
+  return (v >> (30 - 2 * (p & 15))) & 3u;
+}
+
+// ---------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------
+struct Region {  // inclusive [l,u]; empty when l > u (the reference's (1,0) marker)
+  uint32_t l, u;
+};
+WALT_HD Region empty_region() { Region r; r.l = 1; r.u = 0; return r; }
+
+// LowerBound / UpperBound, mapping.cpp:166-196, literal, reading the genome
+// through ent[mid].pos (used for BAD buckets and for care chars >= 44).
+WALT_HD uint32_t lit_lower(const StrandView& sv, uint32_t low, uint32_t high, int ch, uint32_t cp) {
+  while (low < high) {
+    uint32_t mid = low + (high - low) / 2;
+    int c = gchar(sv, (uint64_t)sv.ent[mid].pos + cp);
+    if (c >= ch) high = mid; else low = mid + 1;
+  }
+  return low;
+}
+WALT_HD uint32_t lit_upper(const StrandView& sv, uint32_t low, uint32_t high, int ch, uint32_t cp) {
+  while (low < high) {
+    uint32_t mid = low + (high - low + 1) / 2;
+    int c = gchar(sv, (uint64_t)sv.ent[mid].pos + cp);
+    if (c <= ch) low = mid; else high = mid - 1;
+  }
+  return low;
+}
+// IndexRegion, mapping.cpp:198-222, for care chars [p0, seed_len) on inclusive [l,u].
+WALT_HD Region lit_region(const StrandView& sv, const uint32_t* care, uint32_t p0, uint32_t seed_len,
+                          uint32_t l, uint32_t u) {
+  for (uint32_t p = p0; p < seed_len; ++p) {
+    uint32_t cp = care_pos(p);
+    int ch = (int)care_char(care, p);
+    l = lit_lower(sv, l, u, ch, cp);
+    u = lit_upper(sv, l, u, ch, cp);
+    if (l == u && ch != gchar(sv, (uint64_t)sv.ent[l].pos + cp)) return empty_region();
+  }
+  if (l > u) return empty_region();
+  Region r; r.l = l; r.u = u; return r;
+}
+
+// Target key (care chars 12..43 of the read's care string) and the mask of its
+// first nk chars.
+WALT_HD uint64_t target_key(const uint32_t* care) {
+  return ((uint64_t)(care[0] & 0xFFu) << 56) | ((uint64_t)care[1] << 24) | (care[2] >> 8);
+}
+WALT_HD uint64_t key_mask(uint32_t nk) { return nk >= 32 ? ~0ull : ~(~0ull >> (2 * nk)); }
+
+// Full seed lookup for one (read, strand, seed shift): the region
+// SingleEndMapping gets from counter[] + IndexRegion (mapping.cpp:265-274).
+// care/slot come from the packed read.  Returns empty_region() when the bucket
+// is empty or nothing matches.
+WALT_HD Region seed_lookup(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
+                           uint32_t seed_len) {
+  uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
+  uint32_t n = seed_len - kKeyWeight;
+  if ((sv.bad[h >> 5] >> (h & 31)) & 1u) {
+    uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
+    if (first == second) return empty_region();          // mapping.cpp:271-272
+    return lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);
+  }
+  uint32_t D = iv.dir_digits;
+  uint32_t d = D < n ? D : n;
+  uint32_t lo = sv.dir[slot];
+  uint32_t hi = sv.dir[slot + pow3(D - d)];
+  if (lo == hi) return empty_region();
+  Region r;
+  if (n == d) {
+    r.l = lo; r.u = hi - 1;
+    return r;
+  }
+  uint32_t nk = n < kKeyChars ? n : kKeyChars;
+  uint64_t M = key_mask(nk);
+  uint64_t T = target_key(care) & M;
+  // lower bound of T among masked keys in [lo, hi)
+  uint32_t a = lo, b = hi;
+  while (a < b) {
+    uint32_t mid = a + ((b - a) >> 1);
+    if ((ent_key(sv.ent[mid]) & M) < T) a = mid + 1; else b = mid;
+  }
+  if (a == hi || (ent_key(sv.ent[a]) & M) != T) return empty_region();
+  // upper end: short linear probe, then binary search
+  uint32_t u = a;
+  uint32_t probe = 0;
+  while (u + 1 < hi && probe < 4) {
+    if ((ent_key(sv.ent[u + 1]) & M) != T) break;
+    ++u; ++probe;
+  }
+  if (probe == 4 && u + 1 < hi) {
+    uint32_t x = u + 1, y = hi;  // first index in [x,y) with masked key > T
+    while (x < y) {
+      uint32_t mid = x + ((y - x) >> 1);
+      if ((ent_key(sv.ent[mid]) & M) <= T) x = mid + 1; else y = mid;
+    }
+    u = x - 1;
+  }
+  if (n > kKeyChars) return lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+  r.l = a; r.u = u;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// verification: masked mismatch count, mapping.cpp:288-304.
+//   rd/mask: NW words.  mask has bit 2k of word w set for every compared read
+//   offset 16w+k (table part from the literal F2NOCAREDPOSITION rows + tail).
+// ---------------------------------------------------------------------------
+WALT_HD uint32_t popc32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popc(x);
+#else
+  return (uint32_t)__builtin_popcount(x);
+#endif
+}
+WALT_HD uint32_t funnel_r(uint32_t lo, uint32_t hi, uint32_t s) {  // (hi:lo >> s) low 32 bits, s in [0,31]
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __funnelshift_r(lo, hi, s);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> s);
+#endif
+}
+
+template <int NW>
+WALT_HD uint32_t count_mismatch(const uint32_t* g2, uint32_t gpos, const uint32_t* rd, const uint32_t* mask) {
+  const uint32_t* g = g2 + (gpos >> 4);
+  uint32_t sh = 2 * (gpos & 15);
+  uint32_t mm = 0;
+  uint32_t cur = g[0];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    uint32_t nxt = g[w + 1];
+    uint32_t x = funnel_r(cur, nxt, sh) ^ rd[w];
+    mm += popc32((x | (x >> 1)) & mask[w]);
+    cur = nxt;
+  }
+  return mm;
+}
+
+// compare mask word w for (seed shift, repeats, read_len): table part + tail
+// [3*repeats + seed_i, read_len)  (mapping.cpp:299)
+WALT_HD uint32_t tail_mask_word(uint32_t w, uint32_t lo, uint32_t hi) {
+  uint32_t b0 = 16 * w, b1 = b0 + 16;
+  uint32_t a = lo > b0 ? lo : b0;
+  uint32_t b = hi < b1 ? hi : b1;
+  if (a >= b) return 0;
+  uint32_t na = a - b0, nb = b - b0;  // bases [na, nb) of this word
+  uint32_t m = nb == 16 ? 0x55555555u : ((1u << (2 * nb)) - 1u) & 0x55555555u;
+  uint32_t below = ((1u << (2 * na)) - 1u);
+  return m & ~below;
+}
+// mask_table layout: [3][kMaxRepeats - kMinRepeats + 1][kMaskWords]
+WALT_HD uint32_t mask_table_index(uint32_t seed_i, uint32_t repeats, uint32_t w) {
+  return (seed_i * (kMaxRepeats - kMinRepeats + 1) + (repeats - kMinRepeats)) * kMaskWords + w;
+}
+WALT_HD uint32_t compare_mask_word(const uint32_t* mask_table, uint32_t seed_i, uint32_t repeats,
+                                   uint32_t read_len, uint32_t w) {
+  uint32_t t = w < kMaskWords ? mask_table[mask_table_index(seed_i, repeats, w)] : 0u;
+  return t | tail_mask_word(w, 3 * repeats + seed_i, read_len);
+}
+
+// ---------------------------------------------------------------------------
+// fold of one region's candidates into the running BestMatch,
+// mapping.cpp:306-313.  Index slots are distinct positions, so inside ONE
+// region consecutive equal-best candidates always differ; only the first of
+// them can coincide with the carried-in position.
+// RegionSummary is an associative, order-aware reduction over the candidates.
+// ---------------------------------------------------------------------------
+struct RegionSummary {
+  uint32_t min_mm;  // 0xFFFFFFFF when no candidate passed the edge filters
+  uint32_t count;   // candidates with mm == min_mm
+  uint32_t first;   // position of the first such candidate
+  uint32_t last;    // position of the last
+};
+WALT_HD RegionSummary summary_empty() { RegionSummary s; s.min_mm = 0xFFFFFFFFu; s.count = 0; s.first = 0; s.last = 0; return s; }
+WALT_HD RegionSummary summary_one(uint32_t mm, uint32_t pos) { RegionSummary s; s.min_mm = mm; s.count = 1; s.first = pos; s.last = pos; return s; }
+// a precedes b in candidate order
+WALT_HD RegionSummary summary_merge(const RegionSummary& a, const RegionSummary& b) {
+  if (b.count == 0 || a.min_mm < b.min_mm) return a.count ? a : b;
+  if (a.count == 0 || b.min_mm < a.min_mm) return b;
+  RegionSummary s; s.min_mm = a.min_mm; s.count = a.count + b.count; s.first = a.first; s.last = b.last;
+  return s;
+}
+WALT_HD void fold_region(BestMatch& best, const RegionSummary& s, uint32_t strand_char) {
+  if (s.count == 0) return;
+  if (s.min_mm < best.mismatch) {
+    best.genome_pos = s.last; best.times = s.count; best.strand = strand_char; best.mismatch = s.min_mm;
+  } else if (s.min_mm == best.mismatch) {
+    uint32_t same = (s.first == best.genome_pos) ? 1u : 0u;
+    if (s.count > same) {
+      best.times += s.count - same;
+      best.genome_pos = s.last;
+      best.strand = strand_char;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Paired-end top-k: std::priority_queue<CandidatePosition> as libstdc++ 11
+// implements it (bits/stl_heap.h: __push_heap:134, __adjust_heap:223,
+// __pop_heap:253), comparator = mismatch only (paired.hpp:39-41).  Entries are
+// (pos, packed = mismatch | strand_bit << 31) pairs; strand_bit 1 = '-'.
+// ---------------------------------------------------------------------------
+struct HeapEnt {
+  uint32_t pos, mms;
+};
+WALT_HD uint32_t heap_mm(const HeapEnt& e) { return e.mms & 0x7FFFFFFFu; }
+
+WALT_HD void heap_sift_up(HeapEnt* h, uint32_t hole, uint32_t top, HeapEnt v) {  // __push_heap
+  while (hole > top) {
+    uint32_t parent = (hole - 1) / 2;
+    if (!(heap_mm(h[parent]) < heap_mm(v))) break;
+    h[hole] = h[parent];
+    hole = parent;
+  }
+  h[hole] = v;
+}
+WALT_HD void heap_push(HeapEnt* h, uint32_t& size, HeapEnt v) {  // push_back + push_heap
+  heap_sift_up(h, size, 0, v);
+  ++size;
+}
+WALT_HD void heap_adjust(HeapEnt* h, uint32_t hole, uint32_t len, HeapEnt v) {  // __adjust_heap
+  const uint32_t top = hole;
+  uint32_t child = hole;
+  while ((int32_t)child < ((int32_t)len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (heap_mm(h[child]) < heap_mm(h[child - 1])) --child;
+    h[hole] = h[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && (int32_t)child == ((int32_t)len - 2) / 2) {
+    child = 2 * (child + 1);
+    h[hole] = h[child - 1];
+    hole = child - 1;
+  }
+  heap_sift_up(h, hole, top, v);
+}
+// pop_heap + pop_back; returns the removed top
+WALT_HD HeapEnt heap_pop(HeapEnt* h, uint32_t& size) {
+  HeapEnt topv = h[0];
+  if (size > 1) {
+    HeapEnt v = h[size - 1];
+    h[size - 1] = topv;
+    heap_adjust(h, 0, size - 1, v);
+  }
+  --size;
+  return topv;
+}
+// TopCandidates::Push, paired.hpp:63-70
+WALT_HD void topk_push(HeapEnt* h, uint32_t& size, uint32_t k, HeapEnt v) {
+  if (size < k) {
+    heap_push(h, size, v);
+  } else if (heap_mm(v) < heap_mm(h[0])) {
+    heap_pop(h, size);
+    heap_push(h, size, v);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Paired-end merge, paired.cpp:98-104, 296-331, 474-545.
+// ---------------------------------------------------------------------------
+struct Candidate {  // CandidatePosition, paired.hpp:35-46 (12 bytes)
+  uint32_t genome_pos;
+  uint32_t strand;  // low byte '+' / '-'
+  uint32_t mismatch;
+};
+struct PairResult {
+  BestMatch m1, m2;
+  uint32_t best_times;
+  int32_t frag_len;
+  int32_t best_i, best_j;
+  uint32_t pair_mm;
+  uint32_t pad_[3];
+};
+
+WALT_HD void forward_pos(uint32_t gp, uint32_t strand_char, uint32_t chr, uint32_t read_len,
+                         const uint32_t* start_index, uint32_t& s, uint32_t& e) {
+  uint32_t len = start_index[chr + 1] - start_index[chr];
+  uint32_t v = gp - start_index[chr];
+  s = strand_char == '+' ? v : len - v - read_len;
+  e = s + read_len;
+}
+WALT_HD void best4single(const Candidate* r, int n, BestMatch& best) {  // paired.cpp:296-318
+  for (int i = n - 1; i >= 0; --i) {
+    if (r[i].mismatch < best.mismatch) {
+      best.genome_pos = r[i].genome_pos; best.times = 1; best.strand = r[i].strand; best.mismatch = r[i].mismatch;
+    } else if (r[i].mismatch == best.mismatch) {
+      if (best.genome_pos == r[i].genome_pos) continue;
+      best.genome_pos = r[i].genome_pos; best.strand = r[i].strand; best.times++;
+    } else {
+      break;
+    }
+  }
+}
+WALT_HD int pair_len(const Candidate& r1, const Candidate& r2, uint32_t len1, uint32_t len2,
+                     const uint32_t* start_index, uint32_t n_chrom) {  // paired.cpp:210-243
+  uint32_t c1 = chrom_id(start_index, n_chrom, r1.genome_pos);
+  uint32_t c2 = chrom_id(start_index, n_chrom, r2.genome_pos);
+  uint32_t s1, e1, s2, e2;
+  forward_pos(r1.genome_pos, r1.strand, c1, len1, start_index, s1, e1);
+  forward_pos(r2.genome_pos, r2.strand, c2, len2, start_index, s2, e2);
+  uint32_t ov_s = s1 > s2 ? s1 : s2;
+  uint32_t ov_e = e1 < e2 ? e1 : e2;
+  bool plus = r1.strand == '+';
+  uint32_t one_l = plus ? s1 : (ov_e > s1 ? ov_e : s1);
+  uint32_t one_r = plus ? (ov_s < e1 ? ov_s : e1) : e1;
+  uint32_t two_l = plus ? (ov_e > s2 ? ov_e : s2) : s2;
+  uint32_t two_r = plus ? e2 : (ov_s < e2 ? ov_s : e2);
+  return plus ? (int)(two_r - one_l) : (int)(one_r - two_l);
+}
+WALT_HD void pair_merge(const Candidate* r1, int n1, const Candidate* r2, int n2, uint32_t len1, uint32_t len2,
+                        const uint32_t* start_index, uint32_t n_chrom, int frag_range, uint32_t max_mm,
+                        PairResult& out) {
+  int bi = -1, bj = -1;
+  uint32_t min_mm = max_mm;
+  uint64_t best_pos = 0;
+  uint32_t best_times = 0;
+  for (int i = n1 - 1; i >= 0; --i) {
+    uint32_t c1 = 0xFFFFFFFFu;
+    for (int j = n2 - 1; j >= 0; --j) {
+      if (r1[i].strand == r2[j].strand) continue;
+      uint32_t mm = r1[i].mismatch + r2[j].mismatch;
+      if (mm > min_mm) break;
+      if (c1 == 0xFFFFFFFFu) c1 = chrom_id(start_index, n_chrom, r1[i].genome_pos);
+      uint32_t c2 = chrom_id(start_index, n_chrom, r2[j].genome_pos);
+      if (c1 != c2) continue;
+      uint32_t s1, e1, s2, e2;
+      forward_pos(r1[i].genome_pos, r1[i].strand, c1, len1, start_index, s1, e1);
+      forward_pos(r2[j].genome_pos, r2[j].strand, c2, len2, start_index, s2, e2);
+      int frag = r1[i].strand == '+' ? (int)(e2 - s1) : (int)(e1 - s2);
+      if (frag <= 0 || frag > frag_range) continue;
+      uint64_t cur = ((uint64_t)r1[i].genome_pos << 32) + r2[j].genome_pos;
+      if (mm < min_mm) {
+        bi = i; bj = j; best_times = 1; min_mm = mm; best_pos = cur;
+      } else if (mm == min_mm && cur != best_pos) {
+        bi = i; bj = j; best_times++;
+      }
+    }
+  }
+  BestMatch init; init.genome_pos = 0; init.times = 0; init.strand = '+'; init.mismatch = max_mm;
+  out.m1 = init; out.m2 = init;
+  out.best_times = best_times; out.frag_len = 0; out.best_i = -1; out.best_j = -1; out.pair_mm = 0;
+  out.pad_[0] = out.pad_[1] = out.pad_[2] = 0;
+  if (best_times == 1) {
+    out.best_i = bi; out.best_j = bj;
+    out.frag_len = pair_len(r1[bi], r2[bj], len1, len2, start_index, n_chrom);
+    out.pair_mm = r1[bi].mismatch + r2[bj].mismatch;
+    out.m1.genome_pos = r1[bi].genome_pos; out.m1.times = 1; out.m1.strand = r1[bi].strand; out.m1.mismatch = r1[bi].mismatch;
+    out.m2.genome_pos = r2[bj].genome_pos; out.m2.times = 1; out.m2.strand = r2[bj].strand; out.m2.mismatch = r2[bj].mismatch;
+  } else {
+    best4single(r1, n1, out.m1);
+    best4single(r2, n2, out.m2);
+  }
+}
+
+}  // namespace walt
+#endif  // WALT_AMD_CORE_H_

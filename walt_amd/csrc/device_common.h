@@ -1,0 +1,59 @@
+// device_common.h -- the walt_index handle and HIP helpers shared by the .hip
+// translation units.
+#ifndef WALT_AMD_DEVICE_COMMON_H_
+#define WALT_AMD_DEVICE_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/walt_amd.h"
+#include "host_common.h"
+#include "index_core.h"
+
+#define WALT_HIP(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return walt::fail(WALT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+struct walt_index {
+  int device = 0;
+  walt::IndexHead head;
+  std::vector<uint32_t> start_index;  // n_chrom + 1
+  walt::IndexView view;               // device pointers
+  std::vector<void*> allocs;          // everything to hipFree
+  uint32_t* d_mask_table = nullptr;   // compare_mask_table() on the device
+  uint64_t device_bytes = 0;
+  uint64_t bad_buckets[4] = {0, 0, 0, 0};
+  unsigned strand_mask = 0;
+};
+
+namespace walt {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kG2PadWords = 96;  // slack behind the packed genome for window loads
+
+inline unsigned grid_for(uint64_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
+
+// words per packed read for a maximum read length (template instances 8/16/32/64)
+inline int nw_for_len(uint32_t max_len) {
+  if (max_len <= 128) return 8;
+  if (max_len <= 256) return 16;
+  if (max_len <= 512) return 32;
+  if (max_len <= 1024) return 64;
+  return 0;
+}
+
+// Upload + derived-structure build for one strand from DEVICE-resident raw
+// arrays (genome bytes, counter, index).  Takes ownership of nothing; the raw
+// index/bytes may be freed by the caller afterwards; counter is copied.
+int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, const uint32_t* d_counter,
+                        const uint32_t* d_index, uint32_t index_size, hipStream_t stream);
+int finish_index_device(walt_index* idx);  // start_index, mask table
+int choose_dir_digits(uint64_t max_index_size, int requested);
+
+}  // namespace walt
+#endif

@@ -1,0 +1,370 @@
+// device_index.hip -- makes a WALT .dbindex resident in HBM and builds the
+// derived structures the mapping kernels use (layout: core.h header comment).
+//
+// Replaces ReadIndexHeadInfo + the per-batch, per-strand ReadIndex of the
+// reference (reference.cpp:324-351,381-417; call sites mapping.cpp:437,492,
+// paired.cpp:583,661): all selected strands are loaded ONCE and stay resident.
+#include <stdio.h>
+#include <string.h>
+
+#include "device_common.h"
+
+namespace walt {
+
+// ---------------------------------------------------------------------------
+// kernels (one element per thread; all streaming/coalesced on the outputs)
+// ---------------------------------------------------------------------------
+
+// genome bytes -> 2 bits/base.  err[0] counts bytes outside the strand alphabet.
+__global__ void k_pack_genome(const uint8_t* __restrict__ bytes, uint32_t len, uint32_t ga,
+                              uint32_t* __restrict__ g2, uint32_t nwords, uint32_t* __restrict__ err) {
+  uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint64_t b0 = (uint64_t)w * 16;
+  uint32_t v = 0, bad = 0;
+  if (b0 + 16 <= len) {
+    const uint4 q = *reinterpret_cast<const uint4*>(bytes + b0);  // hipMalloc base is 256-B aligned
+    uint32_t qs[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint8_t c = (uint8_t)(qs[i] >> (8 * k));
+        uint32_t code = base_code(c);
+        bad += (code > 3) || (code == (ga ? 2u : 1u));
+        v |= (code & 3u) << (2 * (4 * i + k));
+      }
+    }
+  } else {
+    for (uint32_t k = 0; k < 16; ++k) {
+      if (b0 + k < len) {
+        uint32_t code = base_code(bytes[b0 + k]);
+        bad += (code > 3) || (code == (ga ? 2u : 1u));
+        v |= (code & 3u) << (2 * k);
+      }
+    }
+  }
+  g2[w] = v;
+  if (bad) atomicAdd(err, bad);
+}
+
+// index[] -> Ent {key, pos}; marks buckets whose entries touch the genome end.
+__global__ void k_make_ent(const uint32_t* __restrict__ g2, uint32_t genome_len,
+                           const uint32_t* __restrict__ index, uint32_t n, Ent* __restrict__ ent,
+                           uint32_t* __restrict__ bad, uint32_t* __restrict__ err) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t pos = index[j];
+  if ((uint64_t)pos + kMinSeedLen > genome_len) {  // not a position makedb can emit (reference.cpp:202-203)
+    atomicAdd(err + 1, 1u);
+    Ent z; z.key_hi = 0; z.key_lo = 0; z.pos = 0;
+    ent[j] = z;
+    return;
+  }
+  bool touches;
+  Ent e = make_ent(g2, genome_len, pos, touches);
+  ent[j] = e;
+  if (touches) {
+    uint32_t h = hash_at(g2, pos);
+    atomicOr(&bad[h >> 5], 1u << (h & 31));
+  }
+}
+
+// bucket b is BAD when its keys are not non-decreasing.
+__global__ void k_mark_unsorted(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t n,
+                                uint32_t* __restrict__ bad) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (j >= n) return;
+  Ent a = ent[j - 1], b = ent[j];
+  if (ent_key(a) > ent_key(b)) {
+    uint32_t ha = hash_at(g2, a.pos), hb = hash_at(g2, b.pos);
+    if (ha == hb) atomicOr(&bad[ha >> 5], 1u << (ha & 31));
+  }
+}
+
+// the reference's counter[] must be the bucket of every entry: cnt[h] <= j < cnt[h+1]
+__global__ void k_check_buckets(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t n,
+                                const uint32_t* __restrict__ cnt, uint32_t* __restrict__ err) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t h = hash_at(g2, ent[j].pos);
+  if (!(cnt[h] <= j && j < cnt[h + 1])) atomicAdd(err + 2, 1u);
+}
+
+__global__ void k_build_dir(const uint32_t* __restrict__ cnt, const Ent* __restrict__ ent, uint32_t D,
+                            uint32_t ga, uint32_t slots, uint32_t index_size, uint32_t* __restrict__ dir) {
+  uint32_t K = blockIdx.x * blockDim.x + threadIdx.x;
+  if (K > slots) return;
+  dir[K] = K == slots ? index_size : dir_entry(cnt, ent, D, ga, K);
+}
+
+__global__ void k_popcount(const uint32_t* __restrict__ words, uint32_t n, unsigned long long* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = i < n ? __popc(words[i]) : 0;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+// ---------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(walt_index* idx, T** p, uint64_t count) {
+  void* q = nullptr;
+  uint64_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) return fail(WALT_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  idx->allocs.push_back(q);
+  idx->device_bytes += bytes;
+  *p = reinterpret_cast<T*>(q);
+  return WALT_OK;
+}
+
+int choose_dir_digits(uint64_t max_index_size, int requested) {
+  if (requested >= 0) return requested > (int)kMaxDirDigits ? (int)kMaxDirDigits : requested;
+  // smallest D with index_size / 3^(12+D) <= 8 entries per directory slot
+  int D = 0;
+  uint64_t slots = 531441;  // 3^12
+  while (D < (int)kMaxDirDigits && max_index_size > 8 * slots) {
+    slots *= 3;
+    ++D;
+  }
+  return D;
+}
+
+int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, const uint32_t* d_counter,
+                        const uint32_t* d_index, uint32_t index_size, hipStream_t stream) {
+  const uint32_t genome_len = idx->head.genome_len;
+  const uint32_t ga = strand >= 2 ? 1u : 0u;
+  const uint32_t D = idx->view.dir_digits;
+  const uint32_t slots = idx->view.dir_slots;
+  StrandView& sv = idx->view.s[strand];
+  uint32_t *g2 = nullptr, *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr;
+  Ent* ent = nullptr;
+  const uint32_t nwords = (genome_len + 15) / 16;
+  int rc;
+  if ((rc = dev_alloc(idx, &g2, (uint64_t)nwords + kG2PadWords))) return rc;
+  if ((rc = dev_alloc(idx, &cnt, (uint64_t)kNumBuckets + 1))) return rc;
+  if ((rc = dev_alloc(idx, &bad, kNumBuckets / 32))) return rc;
+  if ((rc = dev_alloc(idx, &dir, (uint64_t)slots + 1))) return rc;
+  if ((rc = dev_alloc(idx, &ent, (uint64_t)index_size + 1))) return rc;
+  WALT_HIP(hipMalloc(reinterpret_cast<void**>(&err), 4 * sizeof(uint32_t)));
+  WALT_HIP(hipMemsetAsync(err, 0, 4 * sizeof(uint32_t), stream));
+  WALT_HIP(hipMemsetAsync(g2 + nwords, 0, kG2PadWords * sizeof(uint32_t), stream));
+  WALT_HIP(hipMemsetAsync(bad, 0, kNumBuckets / 8, stream));
+  WALT_HIP(hipMemcpyAsync(cnt, d_counter, ((uint64_t)kNumBuckets + 1) * 4, hipMemcpyDeviceToDevice, stream));
+  if (nwords)
+    hipLaunchKernelGGL(k_pack_genome, dim3(grid_for(nwords)), dim3(kBlock), 0, stream, d_bytes, genome_len, ga, g2,
+                       nwords, err);
+  if (index_size) {
+    hipLaunchKernelGGL(k_make_ent, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, genome_len, d_index,
+                       index_size, ent, bad, err);
+  }
+  uint32_t herr[4] = {0, 0, 0, 0};
+  WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
+  WALT_HIP(hipStreamSynchronize(stream));
+  if (herr[0] || herr[1]) {
+    hipFree(err);
+    return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[0]) +
+                                  " genome bytes outside the converted alphabet, " + std::to_string(herr[1]) +
+                                  " index positions beyond the genome");
+  }
+  if (index_size) {
+    hipLaunchKernelGGL(k_check_buckets, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, ent, index_size,
+                       cnt, err);
+    if (index_size > 1)
+      hipLaunchKernelGGL(k_mark_unsorted, dim3(grid_for(index_size - 1)), dim3(kBlock), 0, stream, g2, ent,
+                         index_size, bad);
+  }
+  hipLaunchKernelGGL(k_build_dir, dim3(grid_for((uint64_t)slots + 1)), dim3(kBlock), 0, stream, cnt, ent, D, ga,
+                     slots, index_size, dir);
+  unsigned long long* d_cnt64 = nullptr;
+  WALT_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt64), sizeof(unsigned long long)));
+  WALT_HIP(hipMemsetAsync(d_cnt64, 0, sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k_popcount, dim3(grid_for(kNumBuckets / 32)), dim3(kBlock), 0, stream, bad, kNumBuckets / 32,
+                     d_cnt64);
+  unsigned long long nbad = 0;
+  WALT_HIP(hipMemcpyAsync(&nbad, d_cnt64, sizeof(nbad), hipMemcpyDeviceToHost, stream));
+  WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
+  WALT_HIP(hipStreamSynchronize(stream));
+  WALT_HIP(hipGetLastError());
+  hipFree(d_cnt64);
+  hipFree(err);
+  if (herr[2])
+    return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[2]) +
+                                  " index entries are not in the bucket of their hash");
+  idx->bad_buckets[strand] = nbad;
+  sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
+  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.pad_ = 0;
+  idx->strand_mask |= 1u << strand;
+  return WALT_OK;
+}
+
+int finish_index_device(walt_index* idx) {
+  const uint32_t n = (uint32_t)idx->head.lengths.size();
+  idx->start_index.assign(n + 1, 0);
+  for (uint32_t i = 0; i < n; ++i) idx->start_index[i + 1] = idx->start_index[i] + idx->head.lengths[i];
+  uint32_t* d_start = nullptr;
+  int rc;
+  if ((rc = dev_alloc(idx, &d_start, n + 1))) return rc;
+  WALT_HIP(hipMemcpy(d_start, idx->start_index.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+  idx->view.start_index = d_start;
+  idx->view.n_chrom = n;
+  const std::vector<uint32_t>& mt = compare_mask_table();
+  if ((rc = dev_alloc(idx, &idx->d_mask_table, mt.size()))) return rc;
+  WALT_HIP(hipMemcpy(idx->d_mask_table, mt.data(), mt.size() * 4, hipMemcpyHostToDevice));
+  return WALT_OK;
+}
+
+static int new_index(int device, const IndexHead& head, int dir_digits, walt_index** out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(WALT_EHIP, "no HIP device available (the walt_amd hot path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(WALT_EINVAL, "device ordinal out of range");
+  WALT_HIP(hipSetDevice(device));
+  walt_index* idx = new walt_index();
+  idx->device = device;
+  idx->head = head;
+  memset(&idx->view, 0, sizeof(idx->view));
+  idx->view.dir_digits = (uint32_t)choose_dir_digits(head.max_index_size, dir_digits);
+  idx->view.dir_slots = pow3(kKeyWeight + idx->view.dir_digits);
+  *out = idx;
+  return WALT_OK;
+}
+
+// validate a host counter[] before it is trusted on the device
+static int check_counter(const uint32_t* counter, uint32_t index_size) {
+  if (counter[0] != 0 || counter[kNumBuckets] != index_size) return fail(WALT_EFORMAT, "counter[] ends do not match index_size");
+  for (uint32_t i = 0; i < kNumBuckets; ++i)
+    if (counter[i] > counter[i + 1]) return fail(WALT_EFORMAT, "counter[] is not non-decreasing");
+  return WALT_OK;
+}
+
+static int upload_strand(walt_index* idx, int strand, const uint8_t* genome, const uint32_t* counter,
+                         const uint32_t* index, uint32_t index_size) {
+  int rc = check_counter(counter, index_size);
+  if (rc) return rc;
+  const uint32_t genome_len = idx->head.genome_len;
+  uint8_t* d_bytes = nullptr;
+  uint32_t *d_counter = nullptr, *d_index = nullptr;
+  auto cleanup = [&]() {
+    if (d_bytes) hipFree(d_bytes);
+    if (d_counter) hipFree(d_counter);
+    if (d_index) hipFree(d_index);
+  };
+  hipError_t e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&d_bytes), (uint64_t)genome_len + 16)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&d_counter), ((uint64_t)kNumBuckets + 1) * 4)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&d_index), ((uint64_t)index_size + 1) * 4)) != hipSuccess) {
+    cleanup();
+    return fail(WALT_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  }
+  if ((e = hipMemcpy(d_bytes, genome, genome_len, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_counter, counter, ((uint64_t)kNumBuckets + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_index, index, (uint64_t)index_size * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+    cleanup();
+    return fail(WALT_EHIP, std::string("hipMemcpy failed: ") + hipGetErrorString(e));
+  }
+  rc = build_strand_device(idx, strand, d_bytes, d_counter, d_index, index_size, nullptr);
+  cleanup();
+  return rc;
+}
+
+}  // namespace walt
+
+using namespace walt;
+
+extern "C" {
+
+int walt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_digits, walt_index** out) {
+  if (!dbindex_path || !out || !(strand_mask & 15u)) return fail(WALT_EINVAL, "walt_index_open: bad argument");
+  *out = nullptr;
+  IndexHead head;
+  int rc = read_index_head(dbindex_path, head);
+  if (rc) return rc;
+  walt_index* idx = nullptr;
+  if ((rc = new_index(device, head, dir_digits, &idx))) return rc;
+  static const char* sfx[4] = {"_CT00", "_CT01", "_GA10", "_GA11"};
+  for (int s = 0; s < 4 && !rc; ++s) {
+    if (!(strand_mask & (1u << s))) continue;
+    StrandFile sf;
+    rc = read_strand_file(std::string(dbindex_path) + sfx[s], head.genome_len, sf);
+    if (!rc && sf.strand != ((s & 1) ? '-' : '+')) rc = fail(WALT_EFORMAT, std::string("strand byte mismatch in ") + sfx[s]);
+    if (!rc) rc = upload_strand(idx, s, sf.genome.data(), sf.counter.data(), sf.index.data(), (uint32_t)sf.index.size());
+  }
+  if (!rc) rc = finish_index_device(idx);
+  if (rc) {
+    std::string keep = walt_last_error();
+    walt_index_close(idx);
+    set_error(keep);
+    return rc;
+  }
+  *out = idx;
+  return WALT_OK;
+}
+
+int walt_index_from_host(uint32_t n_chrom, const uint32_t* chrom_len, const char* const* chrom_names,
+                         const uint8_t* const genome[4], const uint32_t* const counter[4],
+                         const uint32_t* const index[4], const uint32_t index_size[4], int device, int dir_digits,
+                         walt_index** out) {
+  if (!out || !chrom_len || !n_chrom) return fail(WALT_EINVAL, "walt_index_from_host: bad argument");
+  *out = nullptr;
+  IndexHead head;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n_chrom; ++i) {
+    head.lengths.push_back(chrom_len[i]);
+    head.names.push_back(chrom_names && chrom_names[i] ? chrom_names[i] : ("chr" + std::to_string(i)));
+    total += chrom_len[i];
+  }
+  if (total >= (1ull << 32)) return fail(WALT_EINVAL, "genome longer than 2^32 bases");
+  head.genome_len = (uint32_t)total;
+  for (int s = 0; s < 4; ++s)
+    if (genome[s] && index_size[s] > head.max_index_size) head.max_index_size = index_size[s];
+  walt_index* idx = nullptr;
+  int rc = new_index(device, head, dir_digits, &idx);
+  if (rc) return rc;
+  for (int s = 0; s < 4 && !rc; ++s) {
+    if (!genome[s]) continue;
+    if (!counter[s] || (!index[s] && index_size[s])) rc = fail(WALT_EINVAL, "strand arrays missing");
+    if (!rc) rc = upload_strand(idx, s, genome[s], counter[s], index[s], index_size[s]);
+  }
+  if (!rc) rc = finish_index_device(idx);
+  if (rc) {
+    std::string keep = walt_last_error();
+    walt_index_close(idx);
+    set_error(keep);
+    return rc;
+  }
+  *out = idx;
+  return WALT_OK;
+}
+
+void walt_index_close(walt_index* idx) {
+  if (!idx) return;
+  hipSetDevice(idx->device);
+  for (void* p : idx->allocs) hipFree(p);
+  delete idx;
+}
+
+uint32_t walt_index_n_chrom(const walt_index* idx) { return idx ? (uint32_t)idx->head.lengths.size() : 0; }
+uint32_t walt_index_chrom_len(const walt_index* idx, uint32_t i) {
+  return idx && i < idx->head.lengths.size() ? idx->head.lengths[i] : 0;
+}
+const char* walt_index_chrom_name(const walt_index* idx, uint32_t i) {
+  return idx && i < idx->head.names.size() ? idx->head.names[i].c_str() : "";
+}
+uint64_t walt_index_genome_len(const walt_index* idx) { return idx ? idx->head.genome_len : 0; }
+uint64_t walt_index_device_bytes(const walt_index* idx) { return idx ? idx->device_bytes : 0; }
+int walt_index_dir_digits(const walt_index* idx) { return idx ? (int)idx->view.dir_digits : -1; }
+uint64_t walt_index_bad_buckets(const walt_index* idx, int strand) {
+  return idx && strand >= 0 && strand < 4 ? idx->bad_buckets[strand] : 0;
+}
+
+}  // extern "C"

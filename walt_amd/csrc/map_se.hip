@@ -1,0 +1,287 @@
+// map_se.hip -- single-end seed-and-extend on MI355X.
+//
+// Replaces, for a whole batch and BOTH strand passes, the loop
+//     for fi in {0,1}: ReadIndex(...); #pragma omp parallel for: SingleEndMapping(...)
+// of ProcessSingledEndReads (reference mapping.cpp:486-500) and the body of
+// SingleEndMapping (mapping.cpp:224-316).
+//
+// Work decomposition: one read per LANE for the seed
+// lookup (the lookup is a chain of dependent gathers, so 64 independent chains
+// per wave keep 64 HBM requests in flight), candidates of small regions verified
+// by the owning lane, regions larger than kSmallRegion verified by the whole
+// wavefront (lane k takes slot l+k, l+64+k, ...) with a ballot/min reduction
+// that reproduces the sequential BestMatch fold (mapping.cpp:306-313).
+#include <string.h>
+
+#include "map_common.h"
+
+namespace walt {
+
+__global__ void k_pack_reads(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n,
+                             uint32_t ga, uint32_t D, uint32_t nw, uint32_t* __restrict__ packed,
+                             uint64_t stride, uint32_t* __restrict__ err) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint64_t o = offsets[r];
+  uint64_t len64 = offsets[r + 1] - o;
+  if (len64 > 16ull * nw) {
+    atomicAdd(err + 1, 1u);
+    len64 = 0;
+  }
+  if (!pack_read(bases + o, (uint32_t)len64, ga, D, nw, packed + r, stride)) atomicAdd(err, 1u);
+}
+
+// ---------------------------------------------------------------------------
+// Wave-cooperative verification of one large region owned by lane `owner`.
+// All 64 lanes call this with the same (uniform) arguments broadcast from the
+// owner.  Returns the RegionSummary of the region in candidate order.
+// ---------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
+                                                     uint32_t l, uint32_t size, uint32_t seed_i, uint32_t len,
+                                                     const uint32_t* rd, const uint32_t* mk, uint32_t lane,
+                                                     uint32_t& n_verified) {
+  RegionSummary acc = summary_empty();
+  for (uint32_t base = 0; base < size; base += 64) {
+    uint32_t k = base + lane;
+    uint32_t mm = 0xFFFFFFFFu, gp = 0;
+    if (k < size) {
+      uint32_t pos = sv.ent[l + k].pos;
+      uint32_t m;
+      if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, len, rd, mk, gp, m)) {
+        mm = m;
+        ++n_verified;
+      }
+    }
+    uint32_t mn = wave_min_u32(mm);
+    if (mn != 0xFFFFFFFFu) {
+      unsigned long long eq = __ballot(mm == mn);
+      RegionSummary c;
+      c.min_mm = mn;
+      c.count = (uint32_t)__popcll(eq);
+      c.first = bcast(gp, (int)__ffsll((long long)eq) - 1);
+      c.last = bcast(gp, 63 - (int)__clzll((long long)eq));
+      acc = summary_merge(acc, c);
+    }
+  }
+  return acc;
+}
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
+                                                    uint64_t stride, uint32_t n, uint32_t strand_base,
+                                                    uint32_t max_mm, uint32_t b,
+                                                    const uint32_t* __restrict__ mask_table,
+                                                    BestMatch* __restrict__ out,
+                                                    unsigned long long* __restrict__ stats) {
+  __shared__ BlockShared sh;
+  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t n_chrom = iv.n_chrom;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = r < n;
+
+  LaneRead<NW> lr;
+  load_lane_read<NW>(lr, packed, stride, r, valid);
+  const bool mappable = valid && lr.len >= kMinReadLen;
+
+  BestMatch best;  // mapping.cpp:486
+  best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
+  uint32_t n_probe = 0, n_verified = 0, n_big = 0;
+
+  for (uint32_t fi = 0; fi < 2; ++fi) {
+    const StrandView& sv = iv.s[strand_base + fi];
+    const uint32_t strand_char = fi == 0 ? '+' : '-';
+#pragma unroll 1
+    for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+      // mapping.cpp:250-257 (a `break` there leaves every later seed skipped too,
+      // which these per-seed predicates reproduce because best only improves)
+      bool act = mappable && !(best.mismatch == 0 && seed_i) && !(best.mismatch == 1 && seed_i >= 2);
+      Region reg = empty_region();
+      if (act) {
+        uint32_t care[kCareWords];
+        const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
+#pragma unroll
+        for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
+        uint32_t slot = packed[(fbase + kCareWords) * stride + r];
+        reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+      }
+      uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
+      if (size) ++n_probe;
+      if (size > b) size = 0;  // mapping.cpp:275-277
+      uint32_t mk[NW];
+      make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
+
+      // small regions: the owning lane walks its own candidates in order
+      if (size && size <= kSmallRegion) {
+        RegionSummary sum = summary_empty();
+        for (uint32_t k = 0; k < size; ++k) {
+          uint32_t pos = sv.ent[reg.l + k].pos, gp, mm;
+          if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
+            sum = summary_merge(sum, summary_one(mm, gp));
+            ++n_verified;
+          }
+        }
+        fold_region(best, sum, strand_char);
+      }
+      // large regions: the whole wave verifies one owner's region at a time
+      unsigned long long big = __ballot(size > kSmallRegion);
+      while (big) {
+        const int owner = (int)__ffsll((long long)big) - 1;
+        big &= big - 1;
+        uint32_t o_rd[NW], o_mk[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          o_rd[w] = bcast(lr.rd[w], owner);
+          o_mk[w] = bcast(mk[w], owner);
+        }
+        const uint32_t o_l = bcast(reg.l, owner), o_size = bcast(size, owner), o_len = bcast(lr.len, owner);
+        uint32_t nv = 0;
+        RegionSummary s = coop_region<NW>(sv, si, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv);
+        n_verified += nv;
+        if ((int)lane == owner) {
+          fold_region(best, s, strand_char);
+          ++n_big;
+        }
+      }
+    }
+  }
+  if (valid) out[r] = best;
+
+  // batch statistics: too_short is counted once per strand pass (mapping.cpp:230-233)
+  uint32_t shortv = (valid && lr.len < kMinReadLen) ? 2u : 0u;
+  shortv = wave_sum_u32(shortv);
+  n_probe = wave_sum_u32(n_probe);
+  n_verified = wave_sum_u32(n_verified);
+  n_big = wave_sum_u32(n_big);
+  if (lane == 0) {
+    if (shortv) atomicAdd(&stats[0], (unsigned long long)shortv);
+    if (n_probe) atomicAdd(&stats[1], (unsigned long long)n_probe);
+    if (n_verified) atomicAdd(&stats[2], (unsigned long long)n_verified);
+    if (n_big) atomicAdd(&stats[3], (unsigned long long)n_big);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
+
+template <int NW>
+static void launch_map_se(const walt_index* idx, const uint32_t* packed, uint64_t stride, uint32_t n,
+                          uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
+                          unsigned long long* stats, hipStream_t stream) {
+  hipLaunchKernelGGL(k_map_se<NW>, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats);
+}
+
+int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n, uint32_t max_read_len,
+                  int ag, uint32_t max_mm, uint32_t b, void* d_out, void* d_stats, void* d_workspace,
+                  hipStream_t stream) {
+  if (!idx) return fail(WALT_EINVAL, "null index");
+  const unsigned need = ag ? WALT_STRANDS_GA : WALT_STRANDS_CT;
+  if ((idx->strand_mask & need) != need)
+    return fail(WALT_EINVAL, ag ? "index opened without the _GA10/_GA11 strands" : "index opened without the _CT00/_CT01 strands");
+  if (n == 0) return WALT_OK;
+  const int nw = nw_for_len(max_read_len);
+  if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
+  WALT_HIP(hipSetDevice(idx->device));
+  const uint64_t stride = se_stride(n);
+  uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
+  uint32_t* packed = err + 64;
+  WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t), stream));
+  hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(n)), dim3(kBlock), 0, stream,
+                     reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
+                     (uint32_t)(ag ? 1 : 0), idx->view.dir_digits, (uint32_t)nw, packed, stride, err);
+  BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
+  unsigned long long* stats = reinterpret_cast<unsigned long long*>(d_stats);
+  const uint32_t sb = ag ? 2u : 0u;
+  switch (nw) {
+    case 8: launch_map_se<8>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
+    case 16: launch_map_se<16>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
+    case 32: launch_map_se<32>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
+    default: launch_map_se<64>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
+  }
+  WALT_HIP(hipGetLastError());
+  return WALT_OK;
+}
+
+// err words written by k_pack_reads live at the start of the workspace
+int check_pack_errors(const void* d_workspace, hipStream_t stream) {
+  uint32_t herr[2] = {0, 0};
+  WALT_HIP(hipMemcpyAsync(herr, d_workspace, sizeof(herr), hipMemcpyDeviceToHost, stream));
+  WALT_HIP(hipStreamSynchronize(stream));
+  if (herr[1]) return fail(WALT_EINVAL, std::to_string(herr[1]) + " reads longer than max_read_len");
+  if (herr[0]) return fail(WALT_EBASE, std::to_string(herr[0]) + " reads contain a non-ACGT nucleotide");
+  return WALT_OK;
+}
+
+}  // namespace walt
+
+using namespace walt;
+
+extern "C" {
+
+size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
+  int nw = nw_for_len(max_read_len);
+  if (!nw) nw = 64;
+  return 64 * sizeof(uint32_t) + (size_t)packed_fields((uint32_t)nw) * se_stride(n) * sizeof(uint32_t);
+}
+
+int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
+                             uint32_t max_read_len, int ag_wildcard, uint32_t max_mismatches, uint32_t b,
+                             void* d_out, void* d_stats, void* d_workspace, void* stream) {
+  return map_se_device(idx, d_bases, d_offsets, n, max_read_len, ag_wildcard, max_mismatches, b, d_out, d_stats,
+                       d_workspace, reinterpret_cast<hipStream_t>(stream));
+}
+
+int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offsets, uint32_t n, int ag_wildcard,
+                      uint32_t max_mismatches, uint32_t b, walt_best_match* out, walt_batch_stats* stats) {
+  if (!idx || !offsets || (!bases && n && offsets[n] > 0) || (!out && n)) return fail(WALT_EINVAL, "walt_map_se_batch: bad argument");
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return WALT_OK;
+  WALT_HIP(hipSetDevice(idx->device));
+  uint32_t max_len = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (offsets[i + 1] < offsets[i]) return fail(WALT_EINVAL, "offsets not non-decreasing");
+    uint64_t l = offsets[i + 1] - offsets[i];
+    if (l > 1024) return fail(WALT_EINVAL, "read length above 1024 is not supported");
+    if (l > max_len) max_len = (uint32_t)l;
+  }
+  const uint64_t nbytes = offsets[n] - offsets[0];
+  void *d_bases = nullptr, *d_off = nullptr, *d_out = nullptr, *d_stats = nullptr, *d_ws = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_bases); hipFree(d_off); hipFree(d_out); hipFree(d_stats); hipFree(d_ws);
+  };
+  int rc = WALT_OK;
+  hipError_t e;
+  std::vector<uint64_t> rel(n + 1);
+  for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
+  if ((e = hipMalloc(&d_bases, nbytes + 16)) != hipSuccess || (e = hipMalloc(&d_off, (n + 1) * sizeof(uint64_t))) != hipSuccess ||
+      (e = hipMalloc(&d_out, (size_t)n * sizeof(walt_best_match))) != hipSuccess ||
+      (e = hipMalloc(&d_stats, sizeof(walt_batch_stats))) != hipSuccess ||
+      (e = hipMalloc(&d_ws, walt_se_workspace_bytes(n, max_len))) != hipSuccess) {
+    cleanup();
+    return fail(WALT_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  }
+  if ((e = hipMemcpy(d_bases, bases + offsets[0], nbytes, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemset(d_stats, 0, sizeof(walt_batch_stats))) != hipSuccess) {
+    cleanup();
+    return fail(WALT_EHIP, std::string("upload failed: ") + hipGetErrorString(e));
+  }
+  rc = map_se_device(idx, d_bases, d_off, n, max_len, ag_wildcard, max_mismatches, b, d_out, d_stats, d_ws, nullptr);
+  if (!rc) rc = check_pack_errors(d_ws, nullptr);
+  if (!rc) {
+    if ((e = hipMemcpy(out, d_out, (size_t)n * sizeof(walt_best_match), hipMemcpyDeviceToHost)) != hipSuccess)
+      rc = fail(WALT_EHIP, std::string("download failed: ") + hipGetErrorString(e));
+    walt_batch_stats st;
+    if (!rc && hipMemcpy(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess && stats) *stats = st;
+  }
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"
