@@ -1,0 +1,43 @@
+"""The C-ABI library loads on a CPU-only box and exports every function that
+include/walt_amd.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import refio
+
+
+def declared_functions():
+    hdr = open(os.path.join(refio.ROOT, "include", "walt_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = re.findall(r"\b(walt_[a-z0-9_]+)\s*\(", hdr)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    import walt_amd
+    L = ctypes.CDLL(walt_amd.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 18
+    for nm in names:
+        assert hasattr(L, nm), "libwalt_amd.so does not export %s" % nm
+
+
+def test_struct_layouts_match_reference_types():
+    import walt_amd
+    # BestMatch: 16 bytes, strand at offset 8, mismatch at 12 (mapping.hpp:39-52)
+    bm = walt_amd.best_match_dtype
+    assert bm.itemsize == 16 and bm.fields["strand"][1] == 8 and bm.fields["mismatch"][1] == 12
+    # CandidatePosition: 12 bytes, strand at 4, mismatch at 8 (paired.hpp:35-46)
+    cd = walt_amd.candidate_dtype
+    assert cd.itemsize == 12 and cd.fields["strand"][1] == 4 and cd.fields["mismatch"][1] == 8
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(g1_index_path):
+    import pytest
+    import walt_amd
+    if walt_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(walt_amd.WaltError) as ei:
+        walt_amd.Index.open(g1_index_path)
+    assert ei.value.code == -3 and "no CPU fallback" in str(ei.value)

@@ -1,0 +1,194 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI
+(include/walt_amd.h via the ctypes binding), against (a) the committed golden
+files written by the real reference binary and (b) the oracle restatement on
+seeded random inputs -- bit-exact on every record field."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import refio
+from test_harness_cpu import assert_best_equal, make_random_case, sample_reads
+from test_oracle_golden import META, PE_CASES, SE_CASES, check_against_golden, run_pe_case, run_se_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wa():
+    import walt_amd
+    assert walt_amd.device_count() >= 1, "no HIP device: the walt_amd hot path has no CPU fallback"
+    return walt_amd
+
+
+@pytest.fixture(scope="module")
+def g1_dev(wa, scratch):
+    path = os.path.join(scratch, "g1_prod.dbindex")
+    wa.makedb(os.path.join(refio.GOLDEN, "g1.fa"), path, threads=4)
+    idx = {D: wa.Index.open(path, device=0, strands=wa.STRANDS_ALL, dir_digits=D) for D in (-1, 2)}
+    yield idx
+    for i in idx.values():
+        i.close()
+
+
+def dev_se_mapper(idx):
+    def mapper(seqs, ag, m, b):
+        import walt_amd
+        bases, offsets = walt_amd.pack_reads(seqs)
+        recs, stats = idx.map_se_batch(bases, offsets, ag_wildcard=ag, max_mismatches=m, b=b)
+        return recs, int(stats["too_short"])
+    return mapper
+
+
+@pytest.mark.parametrize("D", [-1, 2])
+@pytest.mark.parametrize("case", SE_CASES)
+def test_gpu_se_reproduces_reference_files(g1_db, g1_dev, case, D):
+    check_against_golden(case, run_se_case(g1_db, case, dev_se_mapper(g1_dev[D])))
+
+
+@pytest.mark.parametrize("case", PE_CASES)
+def test_gpu_pe_reproduces_reference_files(wa, g1_db, g1_dev, case):
+    idx = g1_dev[2]
+
+    def mapper(s1, s2, m, b, k, L):
+        b1, o1 = wa.pack_reads(s1)
+        b2, o2 = wa.pack_reads(s2)
+        res, stats, ranked = idx.map_pe_batch(b1, o1, b2, o2, max_mismatches=m, b=b, top_k=k, frag_range=L,
+                                              want_ranked=True)
+        return res, ranked, (int(stats[0]["too_short"]), int(stats[1]["too_short"]))
+    check_against_golden(case, run_pe_case(g1_db, case, mapper))
+
+
+def test_gpu_se_records_equal_oracle_exact_times(wa, g1_db, g1_dev):
+    """SAM only shows times as 0/1/>=2; compare the full BestMatch records."""
+    for fq, ag in (("se_ct.fastq", False), ("se_ga.fastq", True)):
+        _, seqs, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, fq), 10 ** 7))
+        for m, b in ((6, 5000), (10, 5000), (3, 7), (0, 5000)):
+            want, work = refio.oracle_se(g1_db, seqs, ag=ag, max_mm=m, b=b)
+            for D in (-1, 2):
+                bases, offsets = wa.pack_reads(seqs)
+                got, stats = g1_dev[D].map_se_batch(bases, offsets, ag_wildcard=ag, max_mismatches=m, b=b)
+                assert_best_equal(got, want, "%s m=%d b=%d D=%d" % (fq, m, b, D))
+                assert int(stats["too_short"]) == int(work["too_short"])
+                assert int(stats["candidates"]) >= 0
+
+
+def test_gpu_pe_ranked_lists_and_pairs_equal_oracle(wa, g1_db, g1_dev):
+    _, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 10 ** 7))
+    _, s2, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_2.fastq"), 10 ** 7))
+    b1, o1 = wa.pack_reads(s1)
+    b2, o2 = wa.pack_reads(s2)
+    for k, m, L in ((2, 6, 1000), (5, 6, 1000), (50, 6, 1000), (300, 10, 400)):
+        want, (r1, n1, r2, n2), _ = refio.oracle_pe(g1_db, s1, s2, max_mm=m, b=5000, top_k=k, frag_range=L)
+        got, stats, (g1, gn1, g2, gn2) = g1_dev[-1].map_pe_batch(b1, o1, b2, o2, max_mismatches=m, b=5000, top_k=k,
+                                                                 frag_range=L, want_ranked=True)
+        assert np.array_equal(gn1, n1) and np.array_equal(gn2, n2)
+        for j in range(len(s1)):
+            for a, b_, c in ((g1, r1, n1), (g2, r2, n2)):
+                for f in ("genome_pos", "strand", "mismatch"):
+                    assert np.array_equal(a[j][:c[j]][f], b_[j][:c[j]][f]), (k, j, f)
+        for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"):
+            assert np.array_equal(got[f], want[f]), f
+        assert_best_equal(got["m1"], want["m1"], "m1")
+        assert_best_equal(got["m2"], want["m2"], "m2")
+
+
+@pytest.mark.parametrize("seed,n_chrom", [(11, 80), (12, 300), (13, 10)])
+def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
+    seqs, db = make_random_case(seed, n_chrom, scratch)
+    rng = random.Random(seed * 31)
+    reads_ct = sample_reads(rng, seqs, 3000, "CT")
+    reads_ga = sample_reads(rng, seqs, 1500, "GA")
+    want_ct, wct = refio.oracle_se(db, reads_ct, ag=False, max_mm=6, b=5000)
+    want_ga, _ = refio.oracle_se(db, reads_ga, ag=True, max_mm=4, b=50)
+    bct, oct_ = wa.pack_reads(reads_ct)
+    bga, oga = wa.pack_reads(reads_ga)
+    any_bad = 0
+    for D in (0, 1, 3):
+        idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_digits=D)
+        any_bad += sum(idx.bad_buckets(s) for s in range(4))
+        got, st = idx.map_se_batch(bct, oct_, ag_wildcard=False, max_mismatches=6, b=5000)
+        assert_best_equal(got, want_ct, "CT D=%d" % D)
+        assert int(st["too_short"]) == int(wct["too_short"])
+        got, _ = idx.map_se_batch(bga, oga, ag_wildcard=True, max_mismatches=4, b=50)
+        assert_best_equal(got, want_ga, "GA D=%d" % D)
+        if D == 1:
+            for k in (2, 50):
+                # any reads can serve as "mate 2": it is mapped with G->A on the _GA1x strands
+                res, _, (g1, gn1, g2, gn2) = idx.map_pe_batch(bct, oct_, bct, oct_, max_mismatches=6, top_k=k,
+                                                              want_ranked=True)
+                for ag, gr, gn in ((False, g1, gn1), (True, g2, gn2)):
+                    ro, no, _ = refio.oracle_pe_topk(db, reads_ct, ag, 6, 5000, k)
+                    assert np.array_equal(gn, no)
+                    for j in range(len(reads_ct)):
+                        assert np.array_equal(gr[j][:no[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), (k, j)
+                        assert np.array_equal(gr[j][:no[j]]["mismatch"], ro[j][:no[j]]["mismatch"]), (k, j)
+        idx.close()
+    assert any_bad > 0
+
+
+def test_gpu_long_reads_all_word_widths(wa, scratch):
+    """Reads of 300/600/1000 bp take the 32- and 64-word kernel instances."""
+    rng = random.Random(5)
+    g = "".join(rng.choice("ACGT") for _ in range(20000))
+    fa = os.path.join(scratch, "long.fa")
+    with open(fa, "w") as f:
+        f.write(">L\n%s\n" % g)
+    path = os.path.join(scratch, "long.dbindex")
+    wa.makedb(fa, path, threads=2)
+    db = refio.DbIndex(path)
+    idx = wa.Index.open(path, device=0, strands=wa.STRANDS_CT)
+    for L in (129, 256, 257, 300, 512, 600, 998):
+        reads = []
+        for _ in range(64):
+            p = rng.randrange(0, len(g) - L)
+            s = g[p:p + L]
+            if rng.random() < 0.5:
+                s = refio.revcomp(s)
+            s = "".join("T" if c == "C" else c for c in s)
+            s = "".join(rng.choice("ACGT") if rng.random() < 0.01 else c for c in s)
+            reads.append(s)
+        want, _ = refio.oracle_se(db, reads, max_mm=15)
+        got, _ = idx.map_se_batch(*wa.pack_reads(reads), max_mismatches=15)
+        assert_best_equal(got, want, "L=%d" % L)
+    idx.close()
+
+
+def test_gpu_errors_and_edges(wa, g1_dev):
+    idx = g1_dev[-1]
+    out, stats = idx.map_se_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert out.size == 0
+    with pytest.raises(wa.WaltError) as ei:
+        idx.map_se_batch(*wa.pack_reads(["ACGTNACGT" * 12]))
+    assert ei.value.code == -4  # WALT_EBASE: the reference exits in getBits (util.hpp:117-119)
+    with pytest.raises(wa.WaltError):
+        idx.map_pe_batch(*wa.pack_reads(["A" * 50]), *wa.pack_reads(["A" * 50]), top_k=1)  # walt.cpp:245-246
+    with pytest.raises(wa.WaltError):
+        wa.Index.open("/nonexistent/x.dbindex")
+    # all reads too short
+    out, stats = idx.map_se_batch(*wa.pack_reads(["ACGT" * 5, "A" * 37]))
+    assert int(stats["too_short"]) == 4 and out["times"].tolist() == [0, 0]
+
+
+def test_gpu_device_pointer_api_with_torch(wa, g1_db, g1_dev):
+    import torch
+    idx = g1_dev[-1]
+    _, seqs, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "se_ct.fastq"), 10 ** 7))
+    bases, offsets = wa.pack_reads(seqs)
+    n = len(seqs)
+    dev = torch.device("cuda:0")
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    max_len = int((offsets[1:] - offsets[:-1]).max())
+    d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+    d_ws = torch.empty(wa.lib().walt_se_workspace_bytes(n, max_len), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, max_len, d_out.data_ptr(), d_stats.data_ptr(),
+                            d_ws.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(wa.best_match_dtype)
+    want, work = refio.oracle_se(g1_db, seqs)
+    assert_best_equal(got, want, "device api")
+    assert int(d_stats[0]) == int(work["too_short"])

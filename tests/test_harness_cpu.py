@@ -1,0 +1,145 @@
+"""CPU checks of the per-lane kernel logic (core.h / index_core.h compiled with
+g++ by tests/host_harness.cpp) against the oracle: derived index structures,
+directory + key search vs the literal LowerBound/UpperBound narrowing, packed
+reads, masked mismatch counting, BestMatch fold, libstdc++ heap emulation and
+the pair merge.  The HIP kernels use exactly these functions per lane."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import refio
+from test_oracle_golden import META, check_against_golden, run_pe_case, run_se_case
+
+
+def assert_best_equal(got, want, what=""):
+    for f in ("genome_pos", "times", "strand", "mismatch"):
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert bad.size == 0, "%s field %s differs at %s: got %s want %s" % (
+            what, f, bad[:5], got[f][bad[:5]], want[f][bad[:5]])
+
+
+@pytest.fixture(scope="module")
+def g1_harness(g1_db):
+    hs = {D: refio.HarnessIndex(g1_db, D) for D in (0, 2)}
+    yield hs
+    for h in hs.values():
+        h.close()
+
+
+@pytest.mark.parametrize("D", [0, 2])
+@pytest.mark.parametrize("case", ["se_sam_au", "se_mr_au", "se_ag_sam_au", "se_sam_au_b2", "se_sam_au_N100",
+                                  "se_sam_au_m10"])
+def test_harness_se_reproduces_reference_files(g1_db, g1_harness, case, D):
+    h = g1_harness[D]
+    check_against_golden(case, run_se_case(g1_db, case, lambda s, ag, m, b: h.map_se(s, ag, m, b)))
+
+
+@pytest.mark.parametrize("case", ["pe_sam_au", "pe_mr_au", "pe_sam_au_k3", "pe_sam_au_k300", "pe_sam_au_m10_b20",
+                                  "pe_sam_au_L200"])
+def test_harness_pe_reproduces_reference_files(g1_db, g1_harness, case):
+    h = g1_harness[2]
+
+    def mapper(s1, s2, m, b, k, L):
+        r1, n1, t1 = h.pe_topk(s1, False, m, b, k)
+        r2, n2, t2 = h.pe_topk(s2, True, m, b, k)
+        res = h.pe_merge(r1, n1, r2, n2, s1, s2, k, L, m)
+        return res, (r1, n1, r2, n2), (t1, t2)
+    check_against_golden(case, run_pe_case(g1_db, case, mapper))
+
+
+def test_harness_pe_ranked_lists_equal_oracle(g1_db, g1_harness):
+    """Pop order of the top-k heap == libstdc++ priority_queue (paired.hpp:51-74)."""
+    h = g1_harness[0]
+    names, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 10 ** 7))
+    for k in (2, 3, 7, 50, 300):
+        for ag, seqs in ((False, s1),):
+            r, n, _ = h.pe_topk(seqs, ag, 6, 5000, k)
+            ro, no, _ = refio.oracle_pe_topk(g1_db, seqs, ag, 6, 5000, k)
+            assert np.array_equal(n, no)
+            for j in range(len(seqs)):
+                a, b = r[j][:n[j]], ro[j][:no[j]]
+                assert np.array_equal(a["genome_pos"], b["genome_pos"]), (k, j)
+                assert np.array_equal(a["mismatch"], b["mismatch"]) and np.array_equal(a["strand"], b["strand"])
+
+
+# ---------------------------------------------------------------------------
+# random genomes: many short chromosomes (chromosome-end entries make buckets
+# BAD -> literal path), planted repeats, mixed read lengths
+# ---------------------------------------------------------------------------
+def make_random_case(seed, n_chrom, tmpdir):
+    rng = random.Random(seed)
+    seqs = []
+    unit = "".join(rng.choice("ACGT") for _ in range(220))
+    for i in range(n_chrom):
+        L = rng.choice([40, 90, 150, 300, 700, 2000, 5000])
+        s = [rng.choice("ACGT") for _ in range(L)]
+        if L >= 700 and rng.random() < 0.6:  # shared repeat, sometimes running into the chromosome end
+            p = rng.randrange(0, L - 100)
+            ln = min(220, L - p)
+            s[p:p + ln] = unit[:ln]
+        seqs.append(("c%d" % i, "".join(s)))
+    fa = os.path.join(tmpdir, "rnd_%d.fa" % seed)
+    with open(fa, "w") as f:
+        for nm, s in seqs:
+            f.write(">%s\n%s\n" % (nm, s))
+    idx = os.path.join(tmpdir, "rnd_%d.dbindex" % seed)
+    assert refio.harness().walt_makedb(fa.encode(), idx.encode(), 4) == 0
+    return seqs, refio.DbIndex(idx)
+
+
+def sample_reads(rng, seqs, n, conv):
+    a, b = ("C", "T") if conv == "CT" else ("G", "A")
+    out = []
+    while len(out) < n:
+        nm, g = seqs[rng.randrange(len(seqs))]
+        L = rng.choice([38, 45, 60, 100, 100, 100, 131, 134, 135, 150, 200])
+        if len(g) < L:
+            continue
+        p = rng.randrange(0, len(g) - L + 1)
+        if rng.random() < 0.3:
+            p = rng.choice([0, len(g) - L, max(0, len(g) - L - 1)])  # chromosome edges
+        s = g[p:p + L]
+        if rng.random() < 0.5:
+            s = refio.revcomp(s)
+        s = "".join(b if (c == a and rng.random() < 0.9) else c for c in s)
+        rate = rng.choice([0.0, 0.01, 0.03])
+        s = "".join(rng.choice("ACGT") if rng.random() < rate else c for c in s)
+        out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("seed,n_chrom", [(1, 60), (2, 200), (3, 12)])
+def test_harness_random_genomes_vs_oracle(scratch, seed, n_chrom):
+    seqs, db = make_random_case(seed, n_chrom, scratch)
+    rng = random.Random(seed * 77)
+    reads_ct = sample_reads(rng, seqs, 1500, "CT")
+    reads_ga = sample_reads(rng, seqs, 700, "GA")
+    want_ct, wct = refio.oracle_se(db, reads_ct, ag=False, max_mm=6, b=5000)
+    want_ga, _ = refio.oracle_se(db, reads_ga, ag=True, max_mm=4, b=50)
+    any_bad = False
+    for D in (0, 1, 3):
+        h = refio.HarnessIndex(db, D)
+        any_bad = any_bad or any(v > 0 for v in h.bad.values())
+        got, ts = h.map_se(reads_ct, False, 6, 5000)
+        assert_best_equal(got, want_ct, "D=%d CT" % D)
+        assert ts == int(wct["too_short"])
+        got, _ = h.map_se(reads_ga, True, 4, 50)
+        assert_best_equal(got, want_ga, "D=%d GA" % D)
+        if D == 1:
+            # every bucket through the literal path must give the same answer
+            for s in range(4):
+                h.force_bad(s, True)
+            got, _ = h.map_se(reads_ct, False, 6, 5000)
+            assert_best_equal(got, want_ct, "forced literal")
+            # paired-end top-k lists against the oracle's priority_queue
+            for k in (2, 5, 50):
+                r, n, _ = h.pe_topk(reads_ct[:400], False, 6, 5000, k)
+                ro, no, _ = refio.oracle_pe_topk(db, reads_ct[:400], False, 6, 5000, k)
+                assert np.array_equal(n, no)
+                for j in range(400):
+                    assert np.array_equal(r[j][:n[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), (k, j)
+                    assert np.array_equal(r[j][:n[j]]["mismatch"], ro[j][:no[j]]["mismatch"])
+        h.close()
+    assert any_bad, "test genome should contain BAD (chromosome-end) buckets"

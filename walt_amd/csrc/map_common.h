@@ -86,11 +86,12 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {  // lane is wa
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
-// Packing kernel: ASCII reads -> packed records (index_core.h pack_read), one
-// read per thread.  err[0] counts reads with a non-ACGT base.
-__global__ void k_pack_reads(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n,
-                             uint32_t ga, uint32_t D, uint32_t nw, uint32_t* __restrict__ packed,
-                             uint64_t stride, uint32_t* __restrict__ err);
+// Packing: ASCII reads -> packed records (index_core.h pack_read).  Defined in
+// map_se.hip; err[0] counts reads with a non-ACGT base, err[1] reads longer
+// than 16*nw.
+void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t D,
+                       uint32_t nw, uint32_t* d_packed, uint64_t stride, uint32_t* d_err, hipStream_t stream);
+int check_pack_errors(const void* d_workspace, hipStream_t stream);
 
 }  // namespace walt
 #endif

@@ -1,0 +1,362 @@
+// map_pe.hip -- paired-end seed-and-extend, top-k and pair merge on MI355X.
+//
+// Replaces, per batch: the mate / strand loops around PairEndMapping
+// (reference paired.cpp:642-672, body 106-201), the per-read
+// std::priority_queue top-k (paired.hpp:51-74) including its libstdc++ tie
+// order, the heap drain (paired.cpp:685-692) and the pair search + single-mate
+// fallback of MergePairedEndResults (paired.cpp:474-545), which the reference
+// runs serially on the host.
+//
+// Kernels:
+//   k_pe_topk   one read per lane (lookup as in map_se.hip); candidates with
+//               mismatch <= max_mm are pushed IN CANDIDATE ORDER into the
+//               read's heap in HBM; large regions are verified by the whole
+//               wave and pushed by the owner lane in lane order.
+//   k_pe_drain  pops every heap (-> ascending array in place, std::pop_heap
+//               leaves the popped top at the end) and writes the ranked list in
+//               pop order.
+//   k_pe_merge  one pair per lane, pair_merge() of core.h.
+#include <string.h>
+
+#include "map_common.h"
+
+namespace walt {
+
+constexpr uint32_t kPeChunk = 1u << 21;  // pairs processed per workspace pass
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t* __restrict__ packed,
+                                                     uint64_t stride, uint32_t n, uint32_t strand_base,
+                                                     uint32_t max_mm, uint32_t b, uint32_t top_k,
+                                                     const uint32_t* __restrict__ mask_table,
+                                                     HeapEnt* __restrict__ heaps, uint32_t* __restrict__ heap_n,
+                                                     unsigned long long* __restrict__ stats) {
+  __shared__ BlockShared sh;
+  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t n_chrom = iv.n_chrom;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = r < n;
+
+  LaneRead<NW> lr;
+  load_lane_read<NW>(lr, packed, stride, r, valid);
+  const bool mappable = valid && lr.len >= kMinReadLen;
+  HeapEnt* heap = heaps + (uint64_t)(valid ? r : 0) * top_k;
+  uint32_t hsize = 0;
+  uint32_t n_probe = 0, n_verified = 0, n_big = 0;
+
+  for (uint32_t fi = 0; fi < 2; ++fi) {
+    const StrandView& sv = iv.s[strand_base + fi];
+#pragma unroll 1
+    for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+      // paired.cpp:133-141: stop once the heap is full of exact (seed >= 1) or
+      // one-mismatch (seed >= 2) candidates; top only decreases, so per-seed
+      // predicates equal the reference's `break`.
+      const bool full = hsize >= top_k;
+      const uint32_t top_mm = hsize ? heap_mm(heap[0]) : 0xFFFFFFFFu;
+      bool act = mappable && !(full && top_mm == 0 && seed_i) && !(full && top_mm == 1 && seed_i >= 2);
+      Region reg = empty_region();
+      if (act) {
+        uint32_t care[kCareWords];
+        const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
+#pragma unroll
+        for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
+        uint32_t slot = packed[(fbase + kCareWords) * stride + r];
+        reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+      }
+      uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
+      if (size) ++n_probe;
+      if (size > b) size = 0;  // paired.cpp:161-163
+      uint32_t mk[NW];
+      make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
+
+      if (size && size <= kSmallRegion) {
+        for (uint32_t k = 0; k < size; ++k) {
+          uint32_t pos = sv.ent[reg.l + k].pos, gp, mm;
+          if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
+            ++n_verified;
+            if (mm <= max_mm) {  // paired.cpp:192-195
+              HeapEnt e; e.pos = gp; e.mms = mm | (fi << 31);
+              topk_push(heap, hsize, top_k, e);
+            }
+          }
+        }
+      }
+      unsigned long long big = __ballot(size > kSmallRegion);
+      while (big) {
+        const int owner = (int)__ffsll((long long)big) - 1;
+        big &= big - 1;
+        uint32_t o_rd[NW], o_mk[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          o_rd[w] = bcast(lr.rd[w], owner);
+          o_mk[w] = bcast(mk[w], owner);
+        }
+        const uint32_t o_l = bcast(reg.l, owner), o_size = bcast(size, owner), o_len = bcast(lr.len, owner);
+        for (uint32_t base = 0; base < o_size; base += 64) {
+          uint32_t k = base + lane;
+          uint32_t mm = 0xFFFFFFFFu, gp = 0;
+          if (k < o_size) {
+            uint32_t pos = sv.ent[o_l + k].pos, m;
+            if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, o_len, o_rd, o_mk, gp, m)) {
+              mm = m;
+              ++n_verified;
+            }
+          }
+          // candidates that can still enter the owner's heap, judged against the
+          // heap state at the start of this chunk (top only decreases, so this
+          // never drops a candidate TopCandidates::Push would have accepted)
+          const uint32_t o_hsize = bcast(hsize, owner);
+          uint32_t o_top = 0xFFFFFFFFu;
+          if ((int)lane == owner && hsize) o_top = heap_mm(heap[0]);
+          o_top = bcast(o_top, owner);
+          const bool o_full = o_hsize >= top_k;
+          unsigned long long push = __ballot(mm <= max_mm && (!o_full || mm < o_top));
+          while (push) {
+            const int src = (int)__ffsll((long long)push) - 1;
+            push &= push - 1;
+            const uint32_t c_gp = bcast(gp, src), c_mm = bcast(mm, src);
+            if ((int)lane == owner) {
+              HeapEnt e; e.pos = c_gp; e.mms = c_mm | (fi << 31);
+              topk_push(heap, hsize, top_k, e);
+            }
+          }
+        }
+        if ((int)lane == owner) ++n_big;
+      }
+    }
+  }
+  if (valid) heap_n[r] = hsize;
+
+  uint32_t shortv = (valid && lr.len < kMinReadLen) ? 2u : 0u;  // paired.cpp:112-115, once per strand pass
+  shortv = wave_sum_u32(shortv);
+  n_probe = wave_sum_u32(n_probe);
+  n_verified = wave_sum_u32(n_verified);
+  n_big = wave_sum_u32(n_big);
+  if (lane == 0) {
+    if (shortv) atomicAdd(&stats[0], (unsigned long long)shortv);
+    if (n_probe) atomicAdd(&stats[1], (unsigned long long)n_probe);
+    if (n_verified) atomicAdd(&stats[2], (unsigned long long)n_verified);
+    if (n_big) atomicAdd(&stats[3], (unsigned long long)n_big);
+  }
+}
+
+// paired.cpp:685-692: pop everything; ranked[r][i] = i-th popped (descending mismatch).
+__global__ void k_pe_drain(HeapEnt* __restrict__ heaps, const uint32_t* __restrict__ heap_n, uint32_t n,
+                           uint32_t top_k, Candidate* __restrict__ ranked) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  HeapEnt* heap = heaps + (uint64_t)r * top_k;
+  Candidate* out = ranked + (uint64_t)r * top_k;
+  uint32_t hsize = heap_n[r];
+  uint32_t i = 0;
+  while (hsize) {
+    HeapEnt e = heap_pop(heap, hsize);
+    Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
+    out[i++] = c;
+  }
+}
+
+__global__ void k_pe_merge(IndexView iv, const Candidate* __restrict__ ranked1, const uint32_t* __restrict__ n1,
+                           const Candidate* __restrict__ ranked2, const uint32_t* __restrict__ n2,
+                           const uint32_t* __restrict__ len1, const uint32_t* __restrict__ len2, uint32_t n,
+                           uint32_t top_k, int frag_range, uint32_t max_mm, PairResult* __restrict__ out) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  PairResult pr;
+  pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r], len1[r], len2[r],
+             iv.start_index, iv.n_chrom, frag_range, max_mm, pr);
+  out[r] = pr;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct PeWorkspace {
+  uint32_t* err;
+  uint32_t* packed[2];
+  HeapEnt* heaps[2];
+  uint32_t* heap_n[2];
+  Candidate* ranked[2];
+  uint64_t stride;
+  uint64_t total_bytes;
+};
+
+static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) {
+  PeWorkspace w;
+  uint8_t* p = reinterpret_cast<uint8_t*>(base);
+  uint64_t off = 0;
+  auto take = [&](uint64_t bytes) {
+    uint8_t* q = p ? p + off : nullptr;
+    off += align_up(bytes, 256);
+    return q;
+  };
+  w.stride = align_up(chunk ? chunk : 1, 64);
+  w.err = reinterpret_cast<uint32_t*>(take(64 * sizeof(uint32_t)));
+  for (int m = 0; m < 2; ++m) w.packed[m] = reinterpret_cast<uint32_t*>(take((uint64_t)packed_fields((uint32_t)nw) * w.stride * 4));
+  for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
+  for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
+  for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
+  w.total_bytes = off;
+  return w;
+}
+
+template <int NW>
+static void launch_pe_topk(const walt_index* idx, const uint32_t* packed, uint64_t stride, uint32_t n, uint32_t sb,
+                           uint32_t max_mm, uint32_t b, uint32_t top_k, HeapEnt* heaps, uint32_t* heap_n,
+                           unsigned long long* stats, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, packed, stride, n, sb,
+                     max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats);
+}
+
+// one chunk (n <= chunk capacity of the workspace)
+static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_off1, const uint8_t* d_bases2,
+                    const uint64_t* d_off2, uint32_t n, int nw, uint32_t max_mm, uint32_t b, uint32_t top_k,
+                    int frag_range, PairResult* d_out, unsigned long long* d_stats, const PeWorkspace& w,
+                    hipStream_t stream) {
+  const uint8_t* bases[2] = {d_bases1, d_bases2};
+  const uint64_t* offs[2] = {d_off1, d_off2};
+  for (int m = 0; m < 2; ++m) {
+    // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
+    launch_pack_reads(bases[m], offs[m], n, (uint32_t)m, idx->view.dir_digits, (uint32_t)nw, w.packed[m], w.stride,
+                      w.err, stream);
+    unsigned long long* st = d_stats + 4 * m;
+    const uint32_t sb = m ? 2u : 0u;
+    switch (nw) {
+      case 8: launch_pe_topk<8>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
+      case 16: launch_pe_topk<16>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
+      case 32: launch_pe_topk<32>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
+      default: launch_pe_topk<64>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
+    }
+    hipLaunchKernelGGL(k_pe_drain, dim3(grid_for(n)), dim3(kBlock), 0, stream, w.heaps[m], w.heap_n[m], n, top_k,
+                       w.ranked[m]);
+  }
+  hipLaunchKernelGGL(k_pe_merge, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, w.ranked[0], w.heap_n[0],
+                     w.ranked[1], w.heap_n[1], w.packed[0], w.packed[1], n, top_k, frag_range, max_mm, d_out);
+  WALT_HIP(hipGetLastError());
+  return WALT_OK;
+}
+
+static int pe_check_args(walt_index* idx, uint32_t top_k, uint32_t max_read_len, int* nw) {
+  if (!idx) return fail(WALT_EINVAL, "null index");
+  if ((idx->strand_mask & WALT_STRANDS_ALL) != WALT_STRANDS_ALL)
+    return fail(WALT_EINVAL, "paired-end mapping needs all four strand indexes resident");
+  if (top_k < 2 || top_k > 300) return fail(WALT_EINVAL, "paired-end candidates must be in [2, 300]");  // walt.cpp:245-246
+  *nw = nw_for_len(max_read_len);
+  if (!*nw) return fail(WALT_EINVAL, "read length above 1024 is not supported");
+  return WALT_OK;
+}
+
+}  // namespace walt
+
+using namespace walt;
+
+extern "C" {
+
+size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k) {
+  int nw = nw_for_len(max_read_len);
+  if (!nw) nw = 64;
+  uint32_t chunk = n < kPeChunk ? n : kPeChunk;
+  return (size_t)carve_pe(nullptr, chunk, nw, top_k).total_bytes;
+}
+
+int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* d_offsets1, const void* d_bases2,
+                             const void* d_offsets2, uint32_t n, uint32_t max_read_len, uint32_t max_mismatches,
+                             uint32_t b, uint32_t top_k, int frag_range, void* d_out, void* d_stats,
+                             void* d_workspace, void* stream_) {
+  int nw = 0;
+  int rc = pe_check_args(idx, top_k, max_read_len, &nw);
+  if (rc) return rc;
+  if (n == 0) return WALT_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  WALT_HIP(hipSetDevice(idx->device));
+  const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
+  PeWorkspace w = carve_pe(d_workspace, chunk, nw, top_k);
+  WALT_HIP(hipMemsetAsync(w.err, 0, 64 * sizeof(uint32_t), stream));
+  for (uint32_t start = 0; start < n; start += chunk) {
+    uint32_t cnt = n - start < chunk ? n - start : chunk;
+    rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases1), reinterpret_cast<const uint64_t*>(d_offsets1) + start,
+                  reinterpret_cast<const uint8_t*>(d_bases2), reinterpret_cast<const uint64_t*>(d_offsets2) + start, cnt,
+                  nw, max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
+                  reinterpret_cast<unsigned long long*>(d_stats), w, stream);
+    if (rc) return rc;
+  }
+  return WALT_OK;
+}
+
+int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offsets1, const char* bases2,
+                      const uint64_t* offsets2, uint32_t n, uint32_t max_mismatches, uint32_t b, uint32_t top_k,
+                      int frag_range, walt_pair_result* out, walt_candidate* ranked1, uint32_t* ranked_n1,
+                      walt_candidate* ranked2, uint32_t* ranked_n2, walt_batch_stats* stats) {
+  if (!offsets1 || !offsets2 || (!out && n)) return fail(WALT_EINVAL, "walt_map_pe_batch: bad argument");
+  if (stats) memset(stats, 0, 2 * sizeof(*stats));
+  uint32_t max_len = 0;
+  const uint64_t* offs[2] = {offsets1, offsets2};
+  for (int m = 0; m < 2; ++m)
+    for (uint32_t i = 0; i < n; ++i) {
+      if (offs[m][i + 1] < offs[m][i]) return fail(WALT_EINVAL, "offsets not non-decreasing");
+      uint64_t l = offs[m][i + 1] - offs[m][i];
+      if (l > 1024) return fail(WALT_EINVAL, "read length above 1024 is not supported");
+      if (l > max_len) max_len = (uint32_t)l;
+    }
+  int nw = 0;
+  int rc = pe_check_args(idx, top_k, max_len, &nw);
+  if (rc) return rc;
+  if (n == 0) return WALT_OK;
+  WALT_HIP(hipSetDevice(idx->device));
+  const char* bases[2] = {bases1, bases2};
+  void *d_bases[2] = {nullptr, nullptr}, *d_off[2] = {nullptr, nullptr}, *d_out = nullptr, *d_stats = nullptr, *d_ws = nullptr;
+  auto cleanup = [&]() {
+    for (int m = 0; m < 2; ++m) { hipFree(d_bases[m]); hipFree(d_off[m]); }
+    hipFree(d_out); hipFree(d_stats); hipFree(d_ws);
+  };
+  hipError_t e = hipSuccess;
+  for (int m = 0; m < 2 && e == hipSuccess; ++m) {
+    const uint64_t nbytes = offs[m][n] - offs[m][0];
+    std::vector<uint64_t> rel(n + 1);
+    for (uint32_t i = 0; i <= n; ++i) rel[i] = offs[m][i] - offs[m][0];
+    if ((e = hipMalloc(&d_bases[m], nbytes + 16)) != hipSuccess) break;
+    if ((e = hipMalloc(&d_off[m], (n + 1) * sizeof(uint64_t))) != hipSuccess) break;
+    if ((e = hipMemcpy(d_bases[m], bases[m] + offs[m][0], nbytes, hipMemcpyHostToDevice)) != hipSuccess) break;
+    e = hipMemcpy(d_off[m], rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+  }
+  const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
+  const size_t ws_bytes = carve_pe(nullptr, chunk, nw, top_k).total_bytes;
+  if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * sizeof(walt_pair_result));
+  if (e == hipSuccess) e = hipMalloc(&d_stats, 2 * sizeof(walt_batch_stats));
+  if (e == hipSuccess) e = hipMalloc(&d_ws, ws_bytes);
+  if (e == hipSuccess) e = hipMemset(d_stats, 0, 2 * sizeof(walt_batch_stats));
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
+  }
+  PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k);
+  hipMemset(w.err, 0, 64 * sizeof(uint32_t));
+  for (uint32_t start = 0; start < n && !rc; start += chunk) {
+    uint32_t cnt = n - start < chunk ? n - start : chunk;
+    rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases[0]), reinterpret_cast<const uint64_t*>(d_off[0]) + start,
+                  reinterpret_cast<const uint8_t*>(d_bases[1]), reinterpret_cast<const uint64_t*>(d_off[1]) + start, cnt, nw,
+                  max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
+                  reinterpret_cast<unsigned long long*>(d_stats), w, nullptr);
+    if (rc) break;
+    if (hipDeviceSynchronize() != hipSuccess) { rc = fail(WALT_EHIP, "paired-end kernels failed"); break; }
+    walt_candidate* rk[2] = {ranked1, ranked2};
+    uint32_t* rn[2] = {ranked_n1, ranked_n2};
+    for (int m = 0; m < 2; ++m) {
+      if (rk[m]) hipMemcpy(rk[m] + (size_t)start * top_k, w.ranked[m], (size_t)cnt * top_k * sizeof(walt_candidate), hipMemcpyDeviceToHost);
+      if (rn[m]) hipMemcpy(rn[m] + start, w.heap_n[m], (size_t)cnt * 4, hipMemcpyDeviceToHost);
+    }
+  }
+  if (!rc) rc = check_pack_errors(d_ws, nullptr);
+  if (!rc) {
+    if (hipMemcpy(out, d_out, (size_t)n * sizeof(walt_pair_result), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(WALT_EHIP, "download failed");
+    if (!rc && stats) hipMemcpy(stats, d_stats, 2 * sizeof(walt_batch_stats), hipMemcpyDeviceToHost);
+  }
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"

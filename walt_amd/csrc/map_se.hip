@@ -17,7 +17,7 @@
 
 namespace walt {
 
-__global__ void k_pack_reads(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n,
+static __global__ void k_pack_reads(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n,
                              uint32_t ga, uint32_t D, uint32_t nw, uint32_t* __restrict__ packed,
                              uint64_t stride, uint32_t* __restrict__ err) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,6 +29,12 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ bases, const uint64_t* 
     len64 = 0;
   }
   if (!pack_read(bases + o, (uint32_t)len64, ga, D, nw, packed + r, stride)) atomicAdd(err, 1u);
+}
+
+void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t D,
+                       uint32_t nw, uint32_t* d_packed, uint64_t stride, uint32_t* d_err, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_bases, d_offsets, n, ga, D, nw,
+                     d_packed, stride, d_err);
 }
 
 // ---------------------------------------------------------------------------
@@ -192,9 +198,8 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   uint32_t* packed = err + 64;
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t), stream));
-  hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(n)), dim3(kBlock), 0, stream,
-                     reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
-                     (uint32_t)(ag ? 1 : 0), idx->view.dir_digits, (uint32_t)nw, packed, stride, err);
+  launch_pack_reads(reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
+                    (uint32_t)(ag ? 1 : 0), idx->view.dir_digits, (uint32_t)nw, packed, stride, err, stream);
   BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
   unsigned long long* stats = reinterpret_cast<unsigned long long*>(d_stats);
   const uint32_t sb = ag ? 2u : 0u;
