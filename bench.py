@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- mapped reads/s of the single-end seed-and-extend hot path on
+N x MI355X (BASELINE.json: metric "mapped reads/sec (100 bp, hg19)").
+
+Workload at N=1 (BASELINE.json configs[1]): hg19-scale synthetic genome (24
+chromosomes with hg19's lengths, 3.096 Gbp, iid bases + implanted repeat
+families), its _CT00/_CT01 strand indexes built on the GPU by the product's
+makedb-compatible builder, 50 M synthetic 100 bp single-end reads (both
+strands, 95 % C->T, 1 % substitutions), -m 6 -b 5000.  A step = one pass of the
+hot path over the whole resident batch (read packing + mapping kernels, both
+strand passes).  For N > 1 every rank holds a full index replica and its own
+50 M-read shard (weak scaling, BASELINE.json configs[3]); the only collective is
+the final all-reduce of the mapping statistics over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : algorithmic bytes of the reference algorithm per
+                 launch / HIP-event duration of the mapping kernel, vs 8 TB/s
+  cpu_baseline : the oracle restatement (bit-exact to the reference, OpenMP on
+                 all host cores) timed on a bounded sample of the same reads.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HG19 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431,
+        135534747, 135006516, 133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983,
+        63025520, 48129895, 51304566, 155270560, 59373566]
+HG19_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def make_genome(torch, dev, scale, seed):
+    """ASCII genome on the GPU: iid bases + repeat families (deterministic per seed)."""
+    lens = [max(1000, int(l * scale)) for l in HG19]
+    L = sum(lens)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    codes = torch.empty(L, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for s in range(0, L, step):
+        e = min(L, s + step)
+        codes[s:e] = torch.randint(0, 4, (e - s,), generator=g, device=dev, dtype=torch.uint8)
+
+    def implant(unit_len, copies, divergence):
+        if copies < 1:
+            return
+        unit = torch.randint(0, 4, (unit_len,), generator=g, device=dev, dtype=torch.uint8)
+        slot = max(unit_len + 64, L // (copies + 1))
+        nslots = (L - unit_len - 64) // slot
+        copies_eff = min(copies, nslots)
+        which = torch.randperm(nslots, generator=g, device=dev)[:copies_eff]
+        jitter = torch.randint(0, max(1, slot - unit_len - 32), (copies_eff,), generator=g, device=dev)
+        starts = which * slot + jitter
+        for c0 in range(0, copies_eff, 1 << 20):
+            st = starts[c0:c0 + (1 << 20)]
+            idx = (st[:, None] + torch.arange(unit_len, device=dev)[None, :]).reshape(-1)
+            vals = unit.repeat(st.numel())
+            if divergence > 0:
+                mut = torch.rand(vals.numel(), generator=g, device=dev) < divergence
+                rnd = torch.randint(1, 4, (vals.numel(),), generator=g, device=dev, dtype=torch.uint8)
+                vals = torch.where(mut, (vals + rnd) & 3, vals)
+            codes[idx] = vals
+
+    implant(300, int(20000 * scale), 0.10)    # SINE-like family
+    implant(6000, int(500 * scale), 0.02)     # LINE-like family
+    implant(48, int(600000 * scale), 0.0)     # exact micro-repeat: raw bucket >= 500000 is erased (reference.cpp:211)
+    implant(150, int(8000 * scale), 0.0)      # exact repeat: narrowed region > -b 5000 is skipped (mapping.cpp:275)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    ascii_g = lut[codes.long()] if L < (1 << 28) else torch.cat([lut[codes[s:s + step].long()] for s in range(0, L, step)])
+    return ascii_g, lens
+
+
+def make_reads(torch, dev, genome_ascii, n, read_len, seed):
+    """n x read_len ASCII reads on the GPU: both strands, 95 % C->T, 1 % substitutions."""
+    L = genome_ascii.numel()
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = torch.empty((n, read_len), dtype=torch.uint8, device=dev)
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in ((65, 84), (67, 71), (71, 67), (84, 65)):
+        comp[a] = b
+    ar = torch.arange(read_len, device=dev)
+    chunk = 1 << 22
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        pos = torch.randint(0, L - read_len, (m,), generator=g, device=dev)
+        r = genome_ascii[pos[:, None] + ar[None, :]]
+        rev = torch.rand(m, generator=g, device=dev) < 0.5
+        rc = comp[r.flip(1).long()]
+        r = torch.where(rev[:, None], rc, r)
+        conv = (r == 67) & (torch.rand(r.shape, generator=g, device=dev) < 0.95)
+        r = torch.where(conv, torch.full_like(r, 84), r)
+        sub = torch.rand(r.shape, generator=g, device=dev) < 0.01
+        lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+        rnd = lut[torch.randint(0, 4, r.shape, generator=g, device=dev)]
+        r = torch.where(sub, rnd, r)
+        out[s:s + m] = r
+    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * read_len
+    return out.reshape(-1), offsets
+
+
+def cpu_baseline(idx, reads_host, read_len, n_sample, lens, max_mm, b):
+    """Oracle restatement on the host cores, one strand index in memory at a time
+    (as the reference itself does, mapping.cpp:491-492)."""
+    import refio
+    cores = len(os.sched_getaffinity(0))
+    orc = refio.oracle()
+    n = n_sample
+    bases = np.ascontiguousarray(reads_host[:n * read_len])
+    offsets = (np.arange(n + 1, dtype=np.uint64) * read_len)
+    start = np.zeros(len(lens) + 1, dtype=np.uint32)
+    start[1:] = np.cumsum(lens, dtype=np.uint64).astype(np.uint32)
+    out = np.zeros(n, dtype=refio.best_dtype)
+    work = np.zeros(1, dtype=refio.work_dtype)
+    orc.orc_se_init(out.ctypes.data, n, max_mm)
+    elapsed = 0.0
+    for strand, ch in ((0, b"+"), (1, b"-")):
+        g, cnt, ix = idx.export_strand(strand)
+        x = refio.make_orc_strand(g, cnt, ix, start)
+        t0 = time.perf_counter()
+        orc.orc_se_map_strand(ctypes.addressof(x), ch, bases.ctypes.data, offsets.ctypes.data, n, 0, b, cores,
+                              out.ctypes.data, work.ctypes.data)
+        elapsed += time.perf_counter() - t0
+        del g, cnt, ix, x
+    return out, work[0], elapsed, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=3095.677412, help="synthetic genome size (hg19 = 3095.68)")
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=400_000)
+    ap.add_argument("--max-mismatches", type=int, default=6)
+    ap.add_argument("--bucket", type=int, default=5000)
+    ap.add_argument("--dir-digits", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import walt_amd  # loads the HIP library (and the HIP runtime torch will share)
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if walt_amd.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the walt_amd hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    scale = args.genome_mbp * 1e6 / sum(HG19)
+    t0 = time.perf_counter()
+    genome_ascii, lens = make_genome(torch, dev, scale, seed=2)
+    torch.cuda.synchronize()
+    t_genome = time.perf_counter() - t0
+    log("genome: %d bp in %d chromosomes (%.1f s)" % (sum(lens), len(lens), t_genome))
+
+    torch.cuda.empty_cache()  # hand the generator's cached blocks back: the library allocates with hipMalloc
+    t0 = time.perf_counter()
+    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, HG19_NAMES, device=local,
+                                      strands=walt_amd.STRANDS_CT, dir_digits=args.dir_digits)
+    t_index = time.perf_counter() - t0
+    log("index: CT00 %d + CT01 %d entries, dir_digits %d, %.1f GB in HBM, bad buckets %d/%d (%.1f s)" % (
+        idx.index_size(0), idx.index_size(1), idx.dir_digits, idx.device_bytes / 1e9, idx.bad_buckets(0),
+        idx.bad_buckets(1), t_index))
+
+    n = args.reads
+    t0 = time.perf_counter()
+    d_bases, d_off = make_reads(torch, dev, genome_ascii, n, args.read_len, seed=1000 + rank)
+    torch.cuda.synchronize()
+    log("reads: %d x %d bp (%.1f s)" % (n, args.read_len, time.perf_counter() - t0))
+    reads_sample_host = None
+    if rank == 0 and not args.no_cpu_baseline:
+        reads_sample_host = d_bases[:args.cpu_sample * args.read_len].cpu().numpy()
+    del genome_ascii
+    torch.cuda.empty_cache()
+
+    d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+    d_ws = torch.empty(walt_amd.lib().walt_se_workspace_bytes(n, args.read_len), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    idx.profile_enable(True)
+
+    def step():
+        idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, args.read_len, d_out.data_ptr(),
+                                d_stats.data_ptr(), d_ws.data_ptr(), stream=stream,
+                                max_mismatches=args.max_mismatches, b=args.bucket)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    pack_ms, map_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        p_ms, m_ms = idx.profile_last()  # waits for this step's events (same stream)
+        pack_ms.append(p_ms)
+        map_ms.append(m_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # mapping statistics of the last step; the ONLY data-path collective is this
+    # final sum over ranks (RCCL), mirroring StatSingleReads (mapping.hpp:94-100)
+    res = d_out.view(torch.int32).view(n, 4)
+    times = res[:, 1]
+    st = torch.stack([torch.tensor(n, device=dev), (times == 1).sum(), (times >= 2).sum(), (times == 0).sum()]).to(torch.int64)
+    if world > 1:
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+    total, uniq, amb, unm = [int(v) for v in st.tolist()]
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * n * args.steps / elapsed
+    if rank == 0:
+        out = {
+            "metric": "mapped reads/sec (100 bp single-end, hg19-scale index, -m 6 -b 5000)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "configs[1]: hg19-scale synthetic genome (%d bp, 24 chromosomes, repeat families), "
+                                   "%d x %d bp single-end C->T reads per GPU, -m %d -b %d" % (
+                                       sum(lens), n, args.read_len, args.max_mismatches, args.bucket),
+                       "genome_bp": int(sum(lens)), "reads_per_gpu": n, "read_len": args.read_len,
+                       "max_mismatches": args.max_mismatches, "bucket_cap": args.bucket,
+                       "index_dir_digits": idx.dir_digits, "index_hbm_gb": round(idx.device_bytes / 1e9, 2),
+                       "index_build_s": round(t_index, 1), "parallelism": "replica-per-gpu x%d" % world},
+            "mapping": {"total": total, "unique": uniq, "ambiguous": amb, "unmapped": unm},
+            "kernel_ms": {"pack_reads": float(np.mean(pack_ms)), "map_se": float(np.mean(map_ms))},
+        }
+        if not args.no_cpu_baseline:
+            ns = min(args.cpu_sample, n)
+            ref, work, cpu_s, cores = cpu_baseline(idx, reads_sample_host, args.read_len, ns, lens,
+                                                   args.max_mismatches, args.bucket)
+            got = d_out[:ns * 16].cpu().numpy().view(walt_amd.best_match_dtype)
+            same = all(np.array_equal(got[f], ref[f]) for f in ("genome_pos", "times", "strand", "mismatch"))
+            # B = L_in + 16 + sum_probes [8 + S (4 + g) + C (4 + V)], packed genome: g = 0.25, V = L/4
+            P, S, C = float(work["probes"]) / ns, float(work["steps"]) / ns, float(work["cands"]) / ns
+            bytes_per_read = args.read_len + 16 + 8 * P + S * 4.25 + C * (4 + args.read_len / 4.0)
+            kern_s = float(np.mean(map_ms)) / 1e3
+            achieved = bytes_per_read * n / kern_s
+            out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_map_se<8>",
+                               "algorithmic_bytes_per_read": bytes_per_read,
+                               "per_read": {"probes": P, "search_steps": S, "candidates": C}}
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d reads of rank 0's batch, both strand passes, oracle "
+                                             "restatement with OpenMP; index in host memory" % ns,
+                                   "bit_exact_vs_gpu": bool(same)}
+        print(json.dumps(out), flush=True)
+    idx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,9 +150,42 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
                              uint32_t top_k, int frag_range, void* d_out, void* d_stats /*[2]*/,
                              void* d_workspace, void* stream);
 
-/* ---- makedb-compatible index builder (host; reference.cpp:79-322,
- *      makedb.cpp:46-159).  Byte-identical files for N-free FASTA. ---------- */
+/* ---- makedb-compatible index builders (reference.cpp:79-322,
+ *      makedb.cpp:46-159) ---------------------------------------------------- */
+
+/* Host builder: reads FASTA (file or directory of .fa), writes the five .dbindex
+ * files.  Byte-identical to the reference makedb for N-free FASTA. */
 int walt_makedb(const char* fasta_path, const char* out_dbindex_path, int threads);
+
+/* GPU builder: d_genome_ascii is the concatenated genome (upper-case ACGT, no N)
+ * in HBM on `device`; builds the selected strand indexes there and leaves them
+ * resident (BuildIndex, makedb.cpp:46-85).  Same result as the reference makedb
+ * except for the order of entries whose 60 care characters are all equal
+ * (std::sort leaves those in an unspecified order, reference.cpp:296-298). */
+int walt_index_build_device(const void* d_genome_ascii, uint32_t n_chrom, const uint32_t* chrom_len,
+                            const char* const* chrom_names, int device, unsigned strand_mask,
+                            int dir_digits, walt_index** out);
+
+/* HashTable::index_size of a resident strand (reference.hpp:84). */
+uint32_t walt_index_size(const walt_index* idx, int strand);
+
+/* Copy a resident strand back to host arrays laid out like the strand file
+ * (reference.cpp:302-322): genome_out[genome_len] chars, counter_out[4^12+1],
+ * index_out[index_size].  Any pointer may be NULL. */
+int walt_index_export_strand(const walt_index* idx, int strand, uint8_t* genome_out,
+                             uint32_t* counter_out, uint32_t* index_out);
+
+/* WriteIndex x4 + WriteIndexHeadInfo (reference.cpp:302-322, 353-379) from the
+ * resident index; needs all four strands. */
+int walt_index_write(const walt_index* idx, const char* dbindex_path);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------- */
+
+/* When enabled, the *_device batch calls record HIP events on their stream
+ * around the read-packing and the mapping kernels; walt_profile_last waits for
+ * the last call's events and returns the two durations in milliseconds. */
+int walt_profile_enable(walt_index* idx, int on);
+int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms);
 
 #ifdef __cplusplus
 }

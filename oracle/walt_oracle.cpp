@@ -298,6 +298,35 @@ void orc_se_map_batch(const orc_strand* strands /*[2]*/, const char* bases,
   if (work_out) *work_out = total;
 }
 
+// One strand pass of the same loop (mapping.cpp:491-500 body for one fi): `out`
+// carries the BestMatch state in and out, so a caller that can hold only one
+// strand index in host memory at a time (as the reference does) calls this
+// once with '+' and once with '-'.  orc_se_init gives the initial state.
+void orc_se_init(orc_best* out, uint32_t n, uint32_t max_mm) {
+  for (uint32_t j = 0; j < n; ++j) {
+    out[j].genome_pos = 0; out[j].times = 0; out[j].strand = '+';
+    out[j].pad_[0] = out[j].pad_[1] = out[j].pad_[2] = 0;
+    out[j].mismatch = max_mm;
+  }
+}
+void orc_se_map_strand(const orc_strand* x, char strand, const char* bases, const uint64_t* offsets,
+                       uint32_t n, int ag_wildcard, uint32_t b, int threads, orc_best* out,
+                       orc_work* work_out) {
+  orc_tables_init();
+  if (threads < 1) threads = 1;
+  uint64_t p = 0, s = 0, c = 0, t = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 256) reduction(+ : p, s, c, t)
+  for (int64_t j = 0; j < (int64_t)n; ++j) {
+    orc_work w = {0, 0, 0, 0};
+    orc_se_map_read(x, bases + offsets[j], (uint32_t)(offsets[j + 1] - offsets[j]), strand, ag_wildcard, b,
+                    &out[j], &w);
+    p += w.probes; s += w.steps; c += w.cands; t += w.too_short;
+  }
+  if (work_out) {
+    work_out->probes += p; work_out->steps += s; work_out->cands += c; work_out->too_short += t;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Paired-end.
 // ---------------------------------------------------------------------------

@@ -75,6 +75,8 @@ def oracle():
         L.orc_hash.argtypes = [ctypes.c_char_p]
         L.orc_hash.restype = u32
         L.orc_se_map_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, ci, vp, vp]
+        L.orc_se_init.argtypes = [vp, u32, u32]
+        L.orc_se_map_strand.argtypes = [vp, ctypes.c_char, vp, vp, u32, ci, u32, ci, vp, vp]
         L.orc_pe_topk_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, u32, ci, vp, vp, vp]
         L.orc_pe_merge_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32, vp, u32, ci, u32, vp]
         _oracle = L
@@ -108,6 +110,25 @@ def harness():
 STRAND_SUFFIX = ("_CT00", "_CT01", "_GA10", "_GA11")
 
 
+class OrcStrand(ctypes.Structure):
+    _fields_ = [("genome", ctypes.c_void_p), ("genome_len", ctypes.c_uint64), ("counter", ctypes.c_void_p),
+                ("index", ctypes.c_void_p), ("index_size", ctypes.c_uint32), ("start_index", ctypes.c_void_p),
+                ("n_chrom", ctypes.c_uint32)]
+
+
+def make_orc_strand(genome, counter, index, start_index):
+    """orc_strand over numpy arrays (kept alive by the caller)."""
+    x = OrcStrand()
+    x.genome = genome.ctypes.data
+    x.genome_len = genome.size
+    x.counter = counter.ctypes.data
+    x.index = index.ctypes.data
+    x.index_size = index.size
+    x.start_index = start_index.ctypes.data
+    x.n_chrom = start_index.size - 1
+    return x
+
+
 class DbIndex:
     def __init__(self, path, strands=(0, 1, 2, 3)):
         self.path = path
@@ -137,10 +158,6 @@ class DbIndex:
 
     def oracle_strands(self, s0):
         """ctypes array of two orc_strand structs for strands s0, s0+1."""
-        class OrcStrand(ctypes.Structure):
-            _fields_ = [("genome", ctypes.c_void_p), ("genome_len", ctypes.c_uint64), ("counter", ctypes.c_void_p),
-                        ("index", ctypes.c_void_p), ("index_size", ctypes.c_uint32), ("start_index", ctypes.c_void_p),
-                        ("n_chrom", ctypes.c_uint32)]
         arr = (OrcStrand * 2)()
         for k in range(2):
             s = s0 + k

@@ -47,6 +47,28 @@ class WaltError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 (same SONAME as /opt/rocm's); if libwalt_amd.so pulled in the system
+    copy first, a later `import torch` would load a second runtime and find no GPU.
+    So when torch is installed, its bundled runtime is loaded first (by path, without
+    importing torch) and libwalt_amd.so's NEEDED libamdhip64.so.7 resolves to it.
+    WALT_AMD_HIP_RUNTIME=<path> overrides; empty string disables the preload."""
+    import importlib.util
+    path = os.environ.get("WALT_AMD_HIP_RUNTIME")
+    if path is None:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+    if path:
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib():
     """Load libwalt_amd.so (fails loudly when it has not been built)."""
     global _lib
@@ -56,6 +78,7 @@ def lib():
         raise ImportError(
             "walt_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    _preload_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     c = ctypes
     vp, u32, u64, ci = c.c_void_p, c.c_uint32, c.c_uint64, c.c_int
@@ -88,6 +111,13 @@ def lib():
     L.walt_pe_workspace_bytes.restype = c.c_size_t
     L.walt_map_pe_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, ci, vp, vp, vp, vp]
     L.walt_makedb.argtypes = [c.c_char_p, c.c_char_p, ci]
+    L.walt_index_build_device.argtypes = [vp, u32, vp, vp, ci, c.c_uint, ci, c.POINTER(vp)]
+    L.walt_index_size.argtypes = [vp, ci]
+    L.walt_index_size.restype = u32
+    L.walt_index_export_strand.argtypes = [vp, ci, vp, vp, vp]
+    L.walt_index_write.argtypes = [vp, c.c_char_p]
+    L.walt_profile_enable.argtypes = [vp, ci]
+    L.walt_profile_last.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_float)]
     _lib = L
     return L
 
@@ -162,6 +192,43 @@ class Index:
                                           ctypes.cast(sz, ctypes.c_void_p), int(device), int(dir_digits),
                                           ctypes.byref(h)))
         return cls(h)
+
+    @classmethod
+    def build_device(cls, d_genome_ascii, chrom_len, chrom_names=None, device=0, strands=STRANDS_ALL,
+                     dir_digits=-1):
+        """GPU makedb: d_genome_ascii is an HBM address of the ACGT genome (makedb.cpp:46-85)."""
+        n = len(chrom_len)
+        cl = np.ascontiguousarray(chrom_len, dtype=np.uint32)
+        names = None
+        if chrom_names is not None:
+            arr = (ctypes.c_char_p * n)(*[os.fsencode(x) for x in chrom_names])
+            names = ctypes.cast(arr, ctypes.c_void_p)
+        h = ctypes.c_void_p()
+        _check(lib().walt_index_build_device(d_genome_ascii, n, cl.ctypes.data, names, int(device), int(strands),
+                                             int(dir_digits), ctypes.byref(h)))
+        return cls(h)
+
+    def index_size(self, strand):
+        return lib().walt_index_size(self._h, strand)
+
+    def export_strand(self, strand, want_genome=True):
+        """(genome bytes, counter, index) numpy arrays of a resident strand (reference.cpp:302-322 layout)."""
+        g = np.empty(self.genome_len, dtype=np.uint8) if want_genome else None
+        cnt = np.empty((1 << 24) + 1, dtype=np.uint32)
+        ix = np.empty(self.index_size(strand), dtype=np.uint32)
+        _check(lib().walt_index_export_strand(self._h, strand, _ptr(g), _ptr(cnt), _ptr(ix)))
+        return g, cnt, ix
+
+    def write(self, dbindex_path):
+        _check(lib().walt_index_write(self._h, os.fsencode(dbindex_path)))
+
+    def profile_enable(self, on=True):
+        _check(lib().walt_profile_enable(self._h, int(on)))
+
+    def profile_last(self):
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        _check(lib().walt_profile_last(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def close(self):
         if self._h:

@@ -29,6 +29,10 @@ struct walt_index {
   uint64_t device_bytes = 0;
   uint64_t bad_buckets[4] = {0, 0, 0, 0};
   unsigned strand_mask = 0;
+  // measurement hooks (walt_profile_enable / walt_profile_last)
+  bool profile = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before pack, before map, after map
+  bool ev_valid = false;
 };
 
 namespace walt {
@@ -52,6 +56,10 @@ inline int nw_for_len(uint32_t max_len) {
 // index/bytes may be freed by the caller afterwards; counter is copied.
 int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, const uint32_t* d_counter,
                         const uint32_t* d_index, uint32_t index_size, hipStream_t stream);
+int alloc_strand_g2(walt_index* idx, uint32_t** g2_out, hipStream_t stream);
+int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32_t* d_counter,
+                         const uint32_t* d_index, uint32_t index_size, hipStream_t stream);
+int new_index(int device, const IndexHead& head, int dir_digits, walt_index** out);
 int finish_index_device(walt_index* idx);  // start_index, mask table
 int choose_dir_digits(uint64_t max_index_size, int requested);
 

@@ -133,30 +133,34 @@ int choose_dir_digits(uint64_t max_index_size, int requested) {
   return D;
 }
 
-int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, const uint32_t* d_counter,
-                        const uint32_t* d_index, uint32_t index_size, hipStream_t stream) {
+int alloc_strand_g2(walt_index* idx, uint32_t** g2_out, hipStream_t stream) {
+  const uint32_t nwords = (idx->head.genome_len + 15) / 16;
+  int rc = dev_alloc(idx, g2_out, (uint64_t)nwords + kG2PadWords);
+  if (rc) return rc;
+  WALT_HIP(hipMemsetAsync(*g2_out + nwords, 0, kG2PadWords * sizeof(uint32_t), stream));
+  return WALT_OK;
+}
+
+// Derived structures of one strand from its packed genome (already owned by
+// idx) and the DEVICE-resident counter[] / index[] arrays.
+int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32_t* d_counter,
+                         const uint32_t* d_index, uint32_t index_size, hipStream_t stream) {
   const uint32_t genome_len = idx->head.genome_len;
   const uint32_t ga = strand >= 2 ? 1u : 0u;
   const uint32_t D = idx->view.dir_digits;
   const uint32_t slots = idx->view.dir_slots;
   StrandView& sv = idx->view.s[strand];
-  uint32_t *g2 = nullptr, *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr;
+  uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr;
   Ent* ent = nullptr;
-  const uint32_t nwords = (genome_len + 15) / 16;
   int rc;
-  if ((rc = dev_alloc(idx, &g2, (uint64_t)nwords + kG2PadWords))) return rc;
   if ((rc = dev_alloc(idx, &cnt, (uint64_t)kNumBuckets + 1))) return rc;
   if ((rc = dev_alloc(idx, &bad, kNumBuckets / 32))) return rc;
   if ((rc = dev_alloc(idx, &dir, (uint64_t)slots + 1))) return rc;
   if ((rc = dev_alloc(idx, &ent, (uint64_t)index_size + 1))) return rc;
   WALT_HIP(hipMalloc(reinterpret_cast<void**>(&err), 4 * sizeof(uint32_t)));
   WALT_HIP(hipMemsetAsync(err, 0, 4 * sizeof(uint32_t), stream));
-  WALT_HIP(hipMemsetAsync(g2 + nwords, 0, kG2PadWords * sizeof(uint32_t), stream));
   WALT_HIP(hipMemsetAsync(bad, 0, kNumBuckets / 8, stream));
   WALT_HIP(hipMemcpyAsync(cnt, d_counter, ((uint64_t)kNumBuckets + 1) * 4, hipMemcpyDeviceToDevice, stream));
-  if (nwords)
-    hipLaunchKernelGGL(k_pack_genome, dim3(grid_for(nwords)), dim3(kBlock), 0, stream, d_bytes, genome_len, ga, g2,
-                       nwords, err);
   if (index_size) {
     hipLaunchKernelGGL(k_make_ent, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, genome_len, d_index,
                        index_size, ent, bad, err);
@@ -164,10 +168,9 @@ int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, con
   uint32_t herr[4] = {0, 0, 0, 0};
   WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipStreamSynchronize(stream));
-  if (herr[0] || herr[1]) {
+  if (herr[1]) {
     hipFree(err);
-    return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[0]) +
-                                  " genome bytes outside the converted alphabet, " + std::to_string(herr[1]) +
+    return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[1]) +
                                   " index positions beyond the genome");
   }
   if (index_size) {
@@ -201,6 +204,29 @@ int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, con
   return WALT_OK;
 }
 
+int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, const uint32_t* d_counter,
+                        const uint32_t* d_index, uint32_t index_size, hipStream_t stream) {
+  const uint32_t genome_len = idx->head.genome_len;
+  const uint32_t ga = strand >= 2 ? 1u : 0u;
+  const uint32_t nwords = (genome_len + 15) / 16;
+  uint32_t *g2 = nullptr, *err = nullptr;
+  int rc = alloc_strand_g2(idx, &g2, stream);
+  if (rc) return rc;
+  WALT_HIP(hipMalloc(reinterpret_cast<void**>(&err), sizeof(uint32_t)));
+  WALT_HIP(hipMemsetAsync(err, 0, sizeof(uint32_t), stream));
+  if (nwords)
+    hipLaunchKernelGGL(k_pack_genome, dim3(grid_for(nwords)), dim3(kBlock), 0, stream, d_bytes, genome_len, ga, g2,
+                       nwords, err);
+  uint32_t herr = 0;
+  WALT_HIP(hipMemcpyAsync(&herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
+  WALT_HIP(hipStreamSynchronize(stream));
+  hipFree(err);
+  if (herr)
+    return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr) +
+                                  " genome bytes outside the converted alphabet");
+  return finish_strand_device(idx, strand, g2, d_counter, d_index, index_size, stream);
+}
+
 int finish_index_device(walt_index* idx) {
   const uint32_t n = (uint32_t)idx->head.lengths.size();
   idx->start_index.assign(n + 1, 0);
@@ -217,7 +243,7 @@ int finish_index_device(walt_index* idx) {
   return WALT_OK;
 }
 
-static int new_index(int device, const IndexHead& head, int dir_digits, walt_index** out) {
+int new_index(int device, const IndexHead& head, int dir_digits, walt_index** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(WALT_EHIP, "no HIP device available (the walt_amd hot path has no CPU fallback)");
@@ -350,6 +376,8 @@ void walt_index_close(walt_index* idx) {
   if (!idx) return;
   hipSetDevice(idx->device);
   for (void* p : idx->allocs) hipFree(p);
+  for (int i = 0; i < 3; ++i)
+    if (idx->ev[i]) hipEventDestroy(idx->ev[i]);
   delete idx;
 }
 

@@ -198,8 +198,10 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   uint32_t* packed = err + 64;
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t), stream));
+  if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
   launch_pack_reads(reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
                     (uint32_t)(ag ? 1 : 0), idx->view.dir_digits, (uint32_t)nw, packed, stride, err, stream);
+  if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[1], stream));
   BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
   unsigned long long* stats = reinterpret_cast<unsigned long long*>(d_stats);
   const uint32_t sb = ag ? 2u : 0u;
@@ -208,6 +210,10 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
     case 16: launch_map_se<16>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
     case 32: launch_map_se<32>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
     default: launch_map_se<64>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
+  }
+  if (idx->profile) {
+    WALT_HIP(hipEventRecord(idx->ev[2], stream));
+    idx->ev_valid = true;
   }
   WALT_HIP(hipGetLastError());
   return WALT_OK;
@@ -228,6 +234,27 @@ int check_pack_errors(const void* d_workspace, hipStream_t stream) {
 using namespace walt;
 
 extern "C" {
+
+int walt_profile_enable(walt_index* idx, int on) {
+  if (!idx) return fail(WALT_EINVAL, "null index");
+  WALT_HIP(hipSetDevice(idx->device));
+  if (on && !idx->ev[0])
+    for (int i = 0; i < 3; ++i) WALT_HIP(hipEventCreate(&idx->ev[i]));
+  idx->profile = on != 0;
+  idx->ev_valid = false;
+  return WALT_OK;
+}
+
+int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms) {
+  if (!idx || !idx->profile || !idx->ev_valid) return fail(WALT_EINVAL, "no profiled call recorded");
+  WALT_HIP(hipEventSynchronize(idx->ev[2]));
+  float a = 0, b = 0;
+  WALT_HIP(hipEventElapsedTime(&a, idx->ev[0], idx->ev[1]));
+  WALT_HIP(hipEventElapsedTime(&b, idx->ev[1], idx->ev[2]));
+  if (pack_ms) *pack_ms = a;
+  if (map_ms) *map_ms = b;
+  return WALT_OK;
+}
 
 size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
