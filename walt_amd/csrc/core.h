@@ -199,6 +199,8 @@ WALT_HD uint64_t target_key(const uint32_t* care) {
 }
 WALT_HD uint64_t key_mask(uint32_t nk) { return nk >= 32 ? ~0ull : ~(~0ull >> (2 * nk)); }
 
+WALT_HD bool bucket_is_bad(const StrandView& sv, uint32_t h) { return (sv.bad[h >> 5] >> (h & 31)) & 1u; }
+
 // Full seed lookup for one (read, strand, seed shift): the region
 // SingleEndMapping gets from counter[] + IndexRegion (mapping.cpp:265-274).
 // care/slot come from the packed read.  Returns empty_region() when the bucket
@@ -207,7 +209,7 @@ WALT_HD Region seed_lookup(const IndexView& iv, const StrandView& sv, const uint
                            uint32_t seed_len) {
   uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
   uint32_t n = seed_len - kKeyWeight;
-  if ((sv.bad[h >> 5] >> (h & 31)) & 1u) {
+  if (bucket_is_bad(sv, h)) {
     uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
     if (first == second) return empty_region();          // mapping.cpp:271-272
     return lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);

@@ -24,26 +24,25 @@ namespace walt {
 
 constexpr uint32_t kPeChunk = 1u << 21;  // pairs processed per workspace pass
 
-template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t* __restrict__ packed,
-                                                     uint64_t stride, uint32_t n, uint32_t strand_base,
-                                                     uint32_t max_mm, uint32_t b, uint32_t top_k,
-                                                     const uint32_t* __restrict__ mask_table,
-                                                     HeapEnt* __restrict__ heaps, uint32_t* __restrict__ heap_n,
-                                                     unsigned long long* __restrict__ stats) {
-  __shared__ BlockShared sh;
-  const uint32_t* si = block_prologue(sh, iv, mask_table);
+// One read per lane.  LITERAL as in map_se.hip: pass 1 defers reads that hit a
+// BAD bucket, pass 2 maps them from scratch (their heap restarts empty).
+template <int NW, bool LITERAL>
+__device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
+                                           const uint32_t* __restrict__ packed, uint64_t stride, uint32_t r,
+                                           bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
+                                           uint32_t top_k, HeapEnt* __restrict__ heaps,
+                                           uint32_t* __restrict__ heap_n, uint32_t* __restrict__ defer_count,
+                                           uint32_t* __restrict__ defer_list, uint32_t& n_probe,
+                                           uint32_t& n_verified, uint32_t& n_big, uint32_t& len_out) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = r < n;
-
   LaneRead<NW> lr;
   load_lane_read<NW>(lr, packed, stride, r, valid);
-  const bool mappable = valid && lr.len >= kMinReadLen;
+  len_out = lr.len;
+  bool mappable = valid && lr.len >= kMinReadLen;
+  bool deferred = false;
   HeapEnt* heap = heaps + (uint64_t)(valid ? r : 0) * top_k;
   uint32_t hsize = 0;
-  uint32_t n_probe = 0, n_verified = 0, n_big = 0;
 
   for (uint32_t fi = 0; fi < 2; ++fi) {
     const StrandView& sv = iv.s[strand_base + fi];
@@ -62,7 +61,12 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
 #pragma unroll
         for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
         uint32_t slot = packed[(fbase + kCareWords) * stride + r];
-        reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+        if (!LITERAL && bucket_is_bad(sv, care[0] >> 8)) {
+          deferred = true;
+          mappable = false;
+        } else {
+          reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+        }
       }
       uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
       if (size) ++n_probe;
@@ -126,19 +130,70 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
       }
     }
   }
-  if (valid) heap_n[r] = hsize;
+  if (!LITERAL && deferred) {
+    defer_list[atomicAdd(defer_count, 1u)] = r;
+  } else if (valid) {
+    heap_n[r] = hsize;
+  }
+}
 
-  uint32_t shortv = (valid && lr.len < kMinReadLen) ? 2u : 0u;  // paired.cpp:112-115, once per strand pass
+__device__ __forceinline__ void pe_flush(uint32_t shortv, uint32_t n_probe, uint32_t n_verified, uint32_t n_big,
+                                         unsigned long long* __restrict__ stats) {
   shortv = wave_sum_u32(shortv);
   n_probe = wave_sum_u32(n_probe);
   n_verified = wave_sum_u32(n_verified);
   n_big = wave_sum_u32(n_big);
-  if (lane == 0) {
+  if ((threadIdx.x & 63) == 0) {
     if (shortv) atomicAdd(&stats[0], (unsigned long long)shortv);
     if (n_probe) atomicAdd(&stats[1], (unsigned long long)n_probe);
     if (n_verified) atomicAdd(&stats[2], (unsigned long long)n_verified);
     if (n_big) atomicAdd(&stats[3], (unsigned long long)n_big);
   }
+}
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t* __restrict__ packed,
+                                                     uint64_t stride, uint32_t n, uint32_t strand_base,
+                                                     uint32_t max_mm, uint32_t b, uint32_t top_k,
+                                                     const uint32_t* __restrict__ mask_table,
+                                                     HeapEnt* __restrict__ heaps, uint32_t* __restrict__ heap_n,
+                                                     unsigned long long* __restrict__ stats,
+                                                     uint32_t* __restrict__ defer_count,
+                                                     uint32_t* __restrict__ defer_list) {
+  __shared__ BlockShared sh;
+  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = r < n;
+  uint32_t n_probe = 0, n_verified = 0, n_big = 0, len;
+  pe_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, top_k, heaps, heap_n,
+                        defer_count, defer_list, n_probe, n_verified, n_big, len);
+  // paired.cpp:112-115: too_short once per strand pass
+  pe_flush((valid && len < kMinReadLen) ? 2u : 0u, n_probe, n_verified, n_big, stats);
+}
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const uint32_t* __restrict__ packed,
+                                                             uint64_t stride, uint32_t strand_base, uint32_t max_mm,
+                                                             uint32_t b, uint32_t top_k,
+                                                             const uint32_t* __restrict__ mask_table,
+                                                             HeapEnt* __restrict__ heaps,
+                                                             uint32_t* __restrict__ heap_n,
+                                                             unsigned long long* __restrict__ stats,
+                                                             const uint32_t* __restrict__ defer_count,
+                                                             const uint32_t* __restrict__ defer_list) {
+  __shared__ BlockShared sh;
+  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t count = *defer_count;
+  uint32_t n_probe = 0, n_verified = 0, n_big = 0;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < count;
+    const uint32_t r = valid ? defer_list[i] : 0;
+    uint32_t len;
+    pe_process<NW, true>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, top_k, heaps, heap_n,
+                         nullptr, nullptr, n_probe, n_verified, n_big, len);
+  }
+  pe_flush(0, n_probe, n_verified, n_big, stats);
 }
 
 // paired.cpp:685-692: pop everything; ranked[r][i] = i-th popped (descending mismatch).
@@ -179,6 +234,7 @@ struct PeWorkspace {
   uint32_t* packed[2];
   HeapEnt* heaps[2];
   uint32_t* heap_n[2];
+  uint32_t* defer_list[2];
   Candidate* ranked[2];
   uint64_t stride;
   uint64_t total_bytes;
@@ -198,6 +254,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
   for (int m = 0; m < 2; ++m) w.packed[m] = reinterpret_cast<uint32_t*>(take((uint64_t)packed_fields((uint32_t)nw) * w.stride * 4));
   for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
   for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
+  for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
   for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
   w.total_bytes = off;
   return w;
@@ -206,9 +263,13 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
 template <int NW>
 static void launch_pe_topk(const walt_index* idx, const uint32_t* packed, uint64_t stride, uint32_t n, uint32_t sb,
                            uint32_t max_mm, uint32_t b, uint32_t top_k, HeapEnt* heaps, uint32_t* heap_n,
-                           unsigned long long* stats, hipStream_t stream) {
+                           unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
+                           hipStream_t stream) {
   hipLaunchKernelGGL(k_pe_topk<NW>, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, packed, stride, n, sb,
-                     max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats);
+                     max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
+  unsigned g2 = grid_for(n) < 1024u ? grid_for(n) : 1024u;
+  hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride, sb, max_mm,
+                     b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
 }
 
 // one chunk (n <= chunk capacity of the workspace)
@@ -218,6 +279,8 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
                     hipStream_t stream) {
   const uint8_t* bases[2] = {d_bases1, d_bases2};
   const uint64_t* offs[2] = {d_off1, d_off2};
+  // err words: [0..1] pack errors (kept across chunks), [8 + m] deferred-read count of mate m (per chunk)
+  WALT_HIP(hipMemsetAsync(w.err + 8, 0, 2 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) {
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
     launch_pack_reads(bases[m], offs[m], n, (uint32_t)m, idx->view.dir_digits, (uint32_t)nw, w.packed[m], w.stride,
@@ -225,10 +288,10 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     unsigned long long* st = d_stats + 4 * m;
     const uint32_t sb = m ? 2u : 0u;
     switch (nw) {
-      case 8: launch_pe_topk<8>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
-      case 16: launch_pe_topk<16>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
-      case 32: launch_pe_topk<32>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
-      default: launch_pe_topk<64>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, stream); break;
+      case 8: launch_pe_topk<8>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
+      case 16: launch_pe_topk<16>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
+      case 32: launch_pe_topk<32>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
+      default: launch_pe_topk<64>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
     }
     hipLaunchKernelGGL(k_pe_drain, dim3(grid_for(n)), dim3(kBlock), 0, stream, w.heaps[m], w.heap_n[m], n, top_k,
                        w.ranked[m]);

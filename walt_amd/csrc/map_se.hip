@@ -17,18 +17,45 @@
 
 namespace walt {
 
-static __global__ void k_pack_reads(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint32_t n,
-                             uint32_t ga, uint32_t D, uint32_t nw, uint32_t* __restrict__ packed,
-                             uint64_t stride, uint32_t* __restrict__ err) {
-  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+// Read packing: a block stages the contiguous ASCII bytes of its 256 reads in
+// LDS with coalesced 16-byte loads, then every thread packs its own read from
+// LDS (index_core.h pack_read); the SoA output is coalesced across threads.
+// Blocks whose reads span more than kPackLdsBytes read HBM directly.
+constexpr uint32_t kPackLdsBytes = 40 * 1024;
+
+static __global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict__ bases,
+                                                               const uint64_t* __restrict__ offsets, uint32_t n,
+                                                               uint32_t ga, uint32_t D, uint32_t nw,
+                                                               uint32_t* __restrict__ packed, uint64_t stride,
+                                                               uint32_t* __restrict__ err) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kPackLdsBytes];
+  const uint32_t r0 = blockIdx.x * blockDim.x;
+  const uint32_t cnt = n - r0 < blockDim.x ? n - r0 : blockDim.x;
+  const uint64_t o0 = offsets[r0], o1 = offsets[r0 + cnt];
+  // 16-byte aligned window [a0, o1) of the input that covers this block's reads
+  const uint64_t a0 = o0 - ((reinterpret_cast<uintptr_t>(bases) + o0) & 15);
+  const uint64_t span = o1 - a0;
+  const bool use_lds = span <= kPackLdsBytes;
+  if (use_lds) {
+    for (uint64_t i = (uint64_t)threadIdx.x * 16; i < span; i += (uint64_t)blockDim.x * 16) {
+      if (i + 16 <= span) {
+        *reinterpret_cast<uint4*>(lds + i) = *reinterpret_cast<const uint4*>(bases + a0 + i);
+      } else {
+        for (uint64_t k = i; k < span; ++k) lds[k] = bases[a0 + k];
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t r = r0 + threadIdx.x;
   if (r >= n) return;
-  uint64_t o = offsets[r];
+  const uint64_t o = offsets[r];
   uint64_t len64 = offsets[r + 1] - o;
   if (len64 > 16ull * nw) {
     atomicAdd(err + 1, 1u);
     len64 = 0;
   }
-  if (!pack_read(bases + o, (uint32_t)len64, ga, D, nw, packed + r, stride)) atomicAdd(err, 1u);
+  const uint8_t* src = use_lds ? lds + (o - a0) : bases + o;
+  if (!pack_read(src, (uint32_t)len64, ga, D, nw, packed + r, stride)) atomicAdd(err, 1u);
 }
 
 void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t D,
@@ -73,27 +100,31 @@ __device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const
   return acc;
 }
 
-template <int NW>
-__global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
-                                                    uint64_t stride, uint32_t n, uint32_t strand_base,
-                                                    uint32_t max_mm, uint32_t b,
-                                                    const uint32_t* __restrict__ mask_table,
-                                                    BestMatch* __restrict__ out,
-                                                    unsigned long long* __restrict__ stats) {
-  __shared__ BlockShared sh;
-  const uint32_t* si = block_prologue(sh, iv, mask_table);
+// Work for one read per lane.  LITERAL = false (pass 1): a lane whose probe
+// lands in a BAD bucket (literal LowerBound/UpperBound search, ~100x the
+// dependent loads of the key search) stops and appends its read to the deferred
+// list, so that one slow lane cannot hold up its 63 wave-mates.  LITERAL = true
+// (pass 2) maps the deferred reads from scratch with the literal search enabled.
+struct MapCounters {
+  uint32_t probes, verified, big;
+};
+
+template <int NW, bool LITERAL>
+__device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
+                                           const uint32_t* __restrict__ packed, uint64_t stride, uint32_t r,
+                                           bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
+                                           BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
+                                           uint32_t* __restrict__ defer_list, MapCounters& ctr, uint32_t& len_out) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = r < n;
-
   LaneRead<NW> lr;
   load_lane_read<NW>(lr, packed, stride, r, valid);
-  const bool mappable = valid && lr.len >= kMinReadLen;
+  len_out = lr.len;
+  bool mappable = valid && lr.len >= kMinReadLen;
+  bool deferred = false;
 
   BestMatch best;  // mapping.cpp:486
   best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
-  uint32_t n_probe = 0, n_verified = 0, n_big = 0;
 
   for (uint32_t fi = 0; fi < 2; ++fi) {
     const StrandView& sv = iv.s[strand_base + fi];
@@ -110,10 +141,15 @@ __global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t*
 #pragma unroll
         for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
         uint32_t slot = packed[(fbase + kCareWords) * stride + r];
-        reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+        if (!LITERAL && bucket_is_bad(sv, care[0] >> 8)) {
+          deferred = true;
+          mappable = false;
+        } else {
+          reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+        }
       }
       uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
-      if (size) ++n_probe;
+      if (size) ++ctr.probes;
       if (size > b) size = 0;  // mapping.cpp:275-277
       uint32_t mk[NW];
       make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
@@ -125,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t*
           uint32_t pos = sv.ent[reg.l + k].pos, gp, mm;
           if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
             sum = summary_merge(sum, summary_one(mm, gp));
-            ++n_verified;
+            ++ctr.verified;
           }
         }
         fold_region(best, sum, strand_char);
@@ -144,28 +180,78 @@ __global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t*
         const uint32_t o_l = bcast(reg.l, owner), o_size = bcast(size, owner), o_len = bcast(lr.len, owner);
         uint32_t nv = 0;
         RegionSummary s = coop_region<NW>(sv, si, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv);
-        n_verified += nv;
+        ctr.verified += nv;
         if ((int)lane == owner) {
           fold_region(best, s, strand_char);
-          ++n_big;
+          ++ctr.big;
         }
       }
     }
   }
-  if (valid) out[r] = best;
-
-  // batch statistics: too_short is counted once per strand pass (mapping.cpp:230-233)
-  uint32_t shortv = (valid && lr.len < kMinReadLen) ? 2u : 0u;
-  shortv = wave_sum_u32(shortv);
-  n_probe = wave_sum_u32(n_probe);
-  n_verified = wave_sum_u32(n_verified);
-  n_big = wave_sum_u32(n_big);
-  if (lane == 0) {
-    if (shortv) atomicAdd(&stats[0], (unsigned long long)shortv);
-    if (n_probe) atomicAdd(&stats[1], (unsigned long long)n_probe);
-    if (n_verified) atomicAdd(&stats[2], (unsigned long long)n_verified);
-    if (n_big) atomicAdd(&stats[3], (unsigned long long)n_big);
+  if (!LITERAL && deferred) {
+    defer_list[atomicAdd(defer_count, 1u)] = r;
+  } else if (valid) {
+    out[r] = best;
   }
+}
+
+__device__ __forceinline__ void flush_counters(const MapCounters& ctr, uint32_t shortv,
+                                               unsigned long long* __restrict__ stats) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t s0 = wave_sum_u32(shortv), s1 = wave_sum_u32(ctr.probes), s2 = wave_sum_u32(ctr.verified),
+           s3 = wave_sum_u32(ctr.big);
+  if (lane == 0) {
+    if (s0) atomicAdd(&stats[0], (unsigned long long)s0);
+    if (s1) atomicAdd(&stats[1], (unsigned long long)s1);
+    if (s2) atomicAdd(&stats[2], (unsigned long long)s2);
+    if (s3) atomicAdd(&stats[3], (unsigned long long)s3);
+  }
+}
+
+// pass 1: every read of the batch, one per lane
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
+                                                    uint64_t stride, uint32_t n, uint32_t strand_base,
+                                                    uint32_t max_mm, uint32_t b,
+                                                    const uint32_t* __restrict__ mask_table,
+                                                    BestMatch* __restrict__ out,
+                                                    unsigned long long* __restrict__ stats,
+                                                    uint32_t* __restrict__ defer_count,
+                                                    uint32_t* __restrict__ defer_list) {
+  __shared__ BlockShared sh;
+  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = r < n;
+  MapCounters ctr = {0, 0, 0};
+  uint32_t len;
+  se_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, defer_count, defer_list,
+                        ctr, len);
+  // too_short is counted once per strand pass (mapping.cpp:230-233)
+  flush_counters(ctr, (valid && len < kMinReadLen) ? 2u : 0u, stats);
+}
+
+// pass 2: the deferred reads (grid-stride over the list; count is on the device)
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ packed,
+                                                            uint64_t stride, uint32_t strand_base, uint32_t max_mm,
+                                                            uint32_t b, const uint32_t* __restrict__ mask_table,
+                                                            BestMatch* __restrict__ out,
+                                                            unsigned long long* __restrict__ stats,
+                                                            const uint32_t* __restrict__ defer_count,
+                                                            const uint32_t* __restrict__ defer_list) {
+  __shared__ BlockShared sh;
+  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t count = *defer_count;
+  MapCounters ctr = {0, 0, 0};
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < count;
+    const uint32_t r = valid ? defer_list[i] : 0;
+    uint32_t len;
+    se_process<NW, true>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, nullptr, nullptr, ctr,
+                         len);
+  }
+  flush_counters(ctr, 0, stats);
 }
 
 // ---------------------------------------------------------------------------
@@ -175,12 +261,18 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 
+constexpr unsigned kLiteralGrid = 1024;  // blocks of the deferred-read pass (grid-stride)
+
 template <int NW>
 static void launch_map_se(const walt_index* idx, const uint32_t* packed, uint64_t stride, uint32_t n,
                           uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
-                          unsigned long long* stats, hipStream_t stream) {
+                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
+                          hipStream_t stream) {
   hipLaunchKernelGGL(k_map_se<NW>, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats);
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list);
+  unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride,
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list);
 }
 
 int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n, uint32_t max_read_len,
@@ -195,8 +287,11 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
   WALT_HIP(hipSetDevice(idx->device));
   const uint64_t stride = se_stride(n);
+  // workspace: [64 words: pack errors, deferred count] [packed reads] [deferred read list]
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   uint32_t* packed = err + 64;
+  uint32_t* defer_count = err + 2;
+  uint32_t* defer_list = packed + (uint64_t)packed_fields((uint32_t)nw) * stride;
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t), stream));
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
   launch_pack_reads(reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
@@ -206,10 +301,10 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   unsigned long long* stats = reinterpret_cast<unsigned long long*>(d_stats);
   const uint32_t sb = ag ? 2u : 0u;
   switch (nw) {
-    case 8: launch_map_se<8>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
-    case 16: launch_map_se<16>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
-    case 32: launch_map_se<32>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
-    default: launch_map_se<64>(idx, packed, stride, n, sb, max_mm, b, out, stats, stream); break;
+    case 8: launch_map_se<8>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
+    case 16: launch_map_se<16>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
+    case 32: launch_map_se<32>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
+    default: launch_map_se<64>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
   }
   if (idx->profile) {
     WALT_HIP(hipEventRecord(idx->ev[2], stream));
@@ -259,7 +354,7 @@ int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms) {
 size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
-  return 64 * sizeof(uint32_t) + (size_t)packed_fields((uint32_t)nw) * se_stride(n) * sizeof(uint32_t);
+  return 64 * sizeof(uint32_t) + ((size_t)packed_fields((uint32_t)nw) + 1) * se_stride(n) * sizeof(uint32_t);
 }
 
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
