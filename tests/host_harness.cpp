@@ -223,6 +223,18 @@ void hh_pe_merge(void* hp, const Candidate* r1, const uint32_t* n1, const Candid
                h->view.n_chrom, frag_range, max_mm, out[j]);
 }
 
+// the packed read records (SoA, stride words between fields) as index_core.h
+// pack_read() defines them -- the specification of the device packing kernel
+int hh_pack(const char* bases, const uint64_t* offsets, uint32_t n, int ga, uint32_t D, uint32_t nw, uint32_t* out,
+            uint64_t stride) {
+  int bad = 0;
+  for (uint32_t r = 0; r < n; ++r)
+    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], (uint32_t)(offsets[r + 1] - offsets[r]),
+                   ga ? 1 : 0, D, nw, out + r, stride))
+      ++bad;
+  return bad;
+}
+
 // expose the literal tables for tests/test_seedtab.py
 void hh_get_nocare(uint32_t* out3x150) {
   for (int s = 0; s < 3; ++s) memcpy(out3x150 + 150 * s, nocare_row(s), 150 * sizeof(uint32_t));

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Summarise tools/prof_pmc.sh output: per-kernel average duration and the last
+launch's PMC values for the walt kernels."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+out = sys.argv[1]
+print("# rocprofv3 summary: %s\n" % out)
+st = glob.glob(os.path.join(out, "stats", "*kernel_stats.csv"))
+if st:
+    print("| kernel | calls | avg ms | min ms | max ms |\n|---|---|---|---|---|")
+    for r in csv.DictReader(open(st[0])):
+        if "walt::" in r["Name"]:
+            nm = r["Name"].split("(")[0].replace("void ", "")
+            print("| %s | %s | %.3f | %.3f | %.3f |" % (nm, r["Calls"], float(r["AverageNs"]) / 1e6,
+                                                      float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
+print("\nPMC (value of the LAST launch of each kernel in its pass):\n")
+vals = collections.OrderedDict()
+for f in sorted(glob.glob(os.path.join(out, "pmc*", "*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "walt::k_map" not in k and "walt::k_pack" not in k and "walt::k_pe" not in k:
+            continue
+        nm = k.split("(")[0].replace("void ", "")
+        vals.setdefault(nm, collections.OrderedDict())[r["Counter_Name"]] = float(r["Counter_Value"])
+for nm, d in vals.items():
+    print("## %s\n" % nm)
+    for c, v in d.items():
+        print("- %s = %.6g" % (c, v))
+    print()

@@ -147,8 +147,12 @@ WALT_HD uint64_t ent_key(const Ent& e) { return ((uint64_t)e.key_hi << 32) | e.k
 
 // char p (0..49) of an MSB-first care string held in 4 words
 WALT_HD uint32_t care_char(const uint32_t* care, uint32_t p) {
-  uint32_t w = p >> 4;
-  uint32_t v = w == 0 ? care[0] : w == 1 ? care[1] : w == 2 ? care[2] : care[3];
+  const uint32_t c0 = care[0], c1 = care[1], c2 = care[2], c3 = care[3];
+  const uint32_t w = p >> 4;
+  uint32_t v = c3;
+  v = w == 2 ? c2 : v;
+  v = w == 1 ? c1 : v;
+  v = w == 0 ? c0 : v;
   return (v >> (30 - 2 * (p & 15))) & 3u;
 }
 
@@ -160,20 +164,32 @@ struct Region {  // inclusive [l,u]; empty when l > u (the reference's (1,0) mar
 };
 WALT_HD Region empty_region() { Region r; r.l = 1; r.u = 0; return r; }
 
-// LowerBound / UpperBound, mapping.cpp:166-196, literal, reading the genome
-// through ent[mid].pos (used for BAD buckets and for care chars >= 44).
-WALT_HD uint32_t lit_lower(const StrandView& sv, uint32_t low, uint32_t high, int ch, uint32_t cp) {
+// genome.sequence[index[j] + F2CAREDPOSITION[p]] as the reference reads it
+// (mapping.cpp:172,188,207): care chars 12..43 come from the entry's key (one
+// load gives key and pos), later ones from the packed genome; a position at or
+// beyond the end of the genome compares below every base.
+WALT_HD int ent_char(const StrandView& sv, uint32_t j, uint32_t p) {
+  const Ent e = sv.ent[j];
+  const uint64_t q = (uint64_t)e.pos + care_pos(p);
+  if (q >= sv.genome_len) return -1;
+  if (p < kKeyWeight + kKeyChars) return (int)((ent_key(e) >> (2 * (kKeyWeight + kKeyChars - 1 - p))) & 3u);
+  return (int)g2_code(sv.g2, q);
+}
+
+// LowerBound / UpperBound, mapping.cpp:166-196, literal (used for BAD buckets
+// and for care chars >= 44).
+WALT_HD uint32_t lit_lower(const StrandView& sv, uint32_t low, uint32_t high, int ch, uint32_t p) {
   while (low < high) {
     uint32_t mid = low + (high - low) / 2;
-    int c = gchar(sv, (uint64_t)sv.ent[mid].pos + cp);
+    int c = ent_char(sv, mid, p);
     if (c >= ch) high = mid; else low = mid + 1;
   }
   return low;
 }
-WALT_HD uint32_t lit_upper(const StrandView& sv, uint32_t low, uint32_t high, int ch, uint32_t cp) {
+WALT_HD uint32_t lit_upper(const StrandView& sv, uint32_t low, uint32_t high, int ch, uint32_t p) {
   while (low < high) {
     uint32_t mid = low + (high - low + 1) / 2;
-    int c = gchar(sv, (uint64_t)sv.ent[mid].pos + cp);
+    int c = ent_char(sv, mid, p);
     if (c <= ch) low = mid; else high = mid - 1;
   }
   return low;
@@ -182,11 +198,10 @@ WALT_HD uint32_t lit_upper(const StrandView& sv, uint32_t low, uint32_t high, in
 WALT_HD Region lit_region(const StrandView& sv, const uint32_t* care, uint32_t p0, uint32_t seed_len,
                           uint32_t l, uint32_t u) {
   for (uint32_t p = p0; p < seed_len; ++p) {
-    uint32_t cp = care_pos(p);
     int ch = (int)care_char(care, p);
-    l = lit_lower(sv, l, u, ch, cp);
-    u = lit_upper(sv, l, u, ch, cp);
-    if (l == u && ch != gchar(sv, (uint64_t)sv.ent[l].pos + cp)) return empty_region();
+    l = lit_lower(sv, l, u, ch, p);
+    u = lit_upper(sv, l, u, ch, p);
+    if (l == u && ch != ent_char(sv, l, p)) return empty_region();
   }
   if (l > u) return empty_region();
   Region r; r.l = l; r.u = u; return r;
@@ -327,11 +342,17 @@ struct RegionSummary {
 };
 WALT_HD RegionSummary summary_empty() { RegionSummary s; s.min_mm = 0xFFFFFFFFu; s.count = 0; s.first = 0; s.last = 0; return s; }
 WALT_HD RegionSummary summary_one(uint32_t mm, uint32_t pos) { RegionSummary s; s.min_mm = mm; s.count = 1; s.first = pos; s.last = pos; return s; }
-// a precedes b in candidate order
+// a precedes b in candidate order.  Written field by field with selects: a
+// struct-valued `cond ? a : b` makes hipcc spill both operands to scratch.
 WALT_HD RegionSummary summary_merge(const RegionSummary& a, const RegionSummary& b) {
-  if (b.count == 0 || a.min_mm < b.min_mm) return a.count ? a : b;
-  if (a.count == 0 || b.min_mm < a.min_mm) return b;
-  RegionSummary s; s.min_mm = a.min_mm; s.count = a.count + b.count; s.first = a.first; s.last = b.last;
+  const bool has_a = a.count != 0, has_b = b.count != 0;
+  const bool take_a = has_a && (!has_b || a.min_mm <= b.min_mm);   // a contributes its first/min
+  const bool take_b = has_b && (!has_a || b.min_mm <= a.min_mm);   // b contributes its last
+  RegionSummary s;
+  s.min_mm = take_a ? a.min_mm : b.min_mm;
+  s.count = (take_a ? a.count : 0u) + (take_b ? b.count : 0u);
+  s.first = take_a ? a.first : b.first;
+  s.last = take_b ? b.last : a.last;
   return s;
 }
 WALT_HD void fold_region(BestMatch& best, const RegionSummary& s, uint32_t strand_char) {

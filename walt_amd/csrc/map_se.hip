@@ -17,51 +17,147 @@
 
 namespace walt {
 
-// Read packing: a block stages the contiguous ASCII bytes of its 256 reads in
-// LDS with coalesced 16-byte loads, then every thread packs its own read from
-// LDS (index_core.h pack_read); the SoA output is coalesced across threads.
-// Blocks whose reads span more than kPackLdsBytes read HBM directly.
-constexpr uint32_t kPackLdsBytes = 40 * 1024;
+// Read packing (the same record index_core.h pack_read() builds, which stays the
+// specification and is what the CPU harness uses):
+//   phase 1  the block reads the contiguous ASCII bytes of its 256 reads with
+//            coalesced 16-byte loads and turns them into a dense 2-bit array in
+//            LDS (16 bytes -> one word) plus a per-word "not ACGT" mask;
+//   phase 2  each thread cuts its own read out of the 2-bit array with funnel
+//            shifts, applies the C->T / G->A conversion as a bit trick, extracts
+//            the three care strings with compile-time offsets and writes the SoA
+//            record (coalesced across the block).
+// Blocks whose reads span more than kPackLdsBytes, or an unaligned input
+// buffer, take the plain per-thread path.
+constexpr uint32_t kPackLdsBytes = 48 * 1024;  // widest byte window a block stages (as 2-bit codes: 1/8 of it)
 
-static __global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict__ bases,
-                                                               const uint64_t* __restrict__ offsets, uint32_t n,
-                                                               uint32_t ga, uint32_t D, uint32_t nw,
-                                                               uint32_t* __restrict__ packed, uint64_t stride,
-                                                               uint32_t* __restrict__ err) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kPackLdsBytes];
+__device__ __forceinline__ uint32_t convert_word(uint32_t x, uint32_t ga) {
+  const uint32_t lo = x & 0x55555555u;
+  // C->T: 01 -> 11 (hi |= lo).  G->A: 10 -> 00 (hi &= lo).
+  return ga ? (x & (0x55555555u | (lo << 1))) : (x | (lo << 1));
+}
+
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict__ bases,
+                                                        const uint64_t* __restrict__ offsets, uint32_t n,
+                                                        uint32_t ga, uint32_t D, uint32_t* __restrict__ packed,
+                                                        uint64_t stride, uint32_t* __restrict__ err) {
+  __shared__ uint32_t codes[kPackLdsBytes / 16 + 4];
+  __shared__ uint32_t inval[kPackLdsBytes / 16 + 4];
   const uint32_t r0 = blockIdx.x * blockDim.x;
   const uint32_t cnt = n - r0 < blockDim.x ? n - r0 : blockDim.x;
   const uint64_t o0 = offsets[r0], o1 = offsets[r0 + cnt];
-  // 16-byte aligned window [a0, o1) of the input that covers this block's reads
-  const uint64_t a0 = o0 - ((reinterpret_cast<uintptr_t>(bases) + o0) & 15);
-  const uint64_t span = o1 - a0;
-  const bool use_lds = span <= kPackLdsBytes;
-  if (use_lds) {
-    for (uint64_t i = (uint64_t)threadIdx.x * 16; i < span; i += (uint64_t)blockDim.x * 16) {
-      if (i + 16 <= span) {
-        *reinterpret_cast<uint4*>(lds + i) = *reinterpret_cast<const uint4*>(bases + a0 + i);
-      } else {
-        for (uint64_t k = i; k < span; ++k) lds[k] = bases[a0 + k];
+  const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(bases) + o0) & 15);
+  const bool use_lds = mis <= o0 && (o1 - (o0 - mis)) <= kPackLdsBytes;
+  const uint64_t a0 = o0 - mis;
+  const uint32_t r = r0 + threadIdx.x;
+  if (!use_lds) {  // rare: generic path straight from HBM
+    if (r >= n) return;
+    const uint64_t o = offsets[r];
+    uint64_t len64 = offsets[r + 1] - o;
+    if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
+    if (!pack_read(bases + o, (uint32_t)len64, ga, D, NW, packed + r, stride)) atomicAdd(err, 1u);
+    return;
+  }
+  const uint32_t span = (uint32_t)(o1 - a0);
+  const uint32_t nwin = (span + 15) / 16;
+  for (uint32_t i = threadIdx.x; i < nwin; i += blockDim.x) {
+    uint4 q;
+    if (16 * i + 16 <= span) {
+      q = *reinterpret_cast<const uint4*>(bases + a0 + 16 * (uint64_t)i);
+    } else {
+      uint32_t t[4] = {0, 0, 0, 0};
+      for (uint32_t k = 16 * i; k < span; ++k) t[(k & 15) >> 2] |= (uint32_t)bases[a0 + k] << (8 * (k & 3));
+      q = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    const uint32_t qs[4] = {q.x, q.y, q.z, q.w};
+    uint32_t c = 0, bad = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t code = base_code((uint8_t)(qs[j] >> (8 * k)));
+        c |= (code & 3u) << (2 * (4 * j + k));
+        bad |= (code > 3 ? 1u : 0u) << (4 * j + k);
       }
     }
-    __syncthreads();
+    codes[i] = c;
+    inval[i] = bad;
   }
-  const uint32_t r = r0 + threadIdx.x;
+  if (threadIdx.x < 4) { codes[nwin + threadIdx.x] = 0; inval[nwin + threadIdx.x] = 0; }
+  __syncthreads();
   if (r >= n) return;
+
   const uint64_t o = offsets[r];
   uint64_t len64 = offsets[r + 1] - o;
-  if (len64 > 16ull * nw) {
-    atomicAdd(err + 1, 1u);
-    len64 = 0;
+  if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
+  const uint32_t len = (uint32_t)len64;
+  const uint32_t off = (uint32_t)(o - a0);
+  const uint32_t wi0 = off >> 4, sh = 2 * (off & 15);
+  uint32_t rd[NW];
+  uint32_t bad = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    uint32_t v = 0, iv = 0;
+    if (16u * w < len) {
+      const uint32_t lo = codes[wi0 + w], hi = codes[wi0 + w + 1];
+      v = funnel_r(lo, hi, sh);
+      iv = (inval[wi0 + w] >> (off & 15)) | (inval[wi0 + w + 1] << (16 - (off & 15)));
+      const uint32_t nb = len - 16u * w;  // bases of this read in the word
+      if (nb < 16) { v &= (1u << (2 * nb)) - 1u; iv &= (1u << nb) - 1u; }
+      iv &= 0xFFFFu;
+    }
+    bad |= iv;
+    rd[w] = convert_word(v, ga);
   }
-  const uint8_t* src = use_lds ? lds + (o - a0) : bases + o;
-  if (!pack_read(src, (uint32_t)len64, ga, D, nw, packed + r, stride)) atomicAdd(err, 1u);
+  if (bad) {
+    atomicAdd(err, 1u);
+    // pack_read() stores code 0 for a non-ACGT char; reproduce that record
+#pragma unroll
+    for (int w = 0; w < NW; ++w) rd[w] = 0;
+    pack_read(bases + o, len, ga, D, NW, packed + r, stride);
+    return;
+  }
+  packed[r] = len;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) packed[(uint64_t)(1 + w) * stride + r] = rd[w];
+
+  const uint32_t seed_len = len >= kMinReadLen ? seed_repeats(len) : 0;
+  const uint32_t nsel = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0;
+  const uint32_t d = D < nsel ? D : nsel;
+  const uint32_t top_w = pow3(kKeyWeight + D - 1);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    uint32_t care[kCareWords] = {0, 0, 0, 0};
+    uint32_t slot = 0, wgt = top_w;
+#pragma unroll
+    for (int i = 0; i < (int)kMaxRepeats; ++i) {
+      const int q = s + 1 + 3 * i;  // compile-time read offset of care char i
+      if ((q >> 4) < NW) {
+        uint32_t c = (rd[q >> 4] >> (2 * (q & 15))) & 3u;
+        c = (uint32_t)i < seed_len ? c : 0u;
+        care[i >> 4] |= c << (30 - 2 * (i & 15));
+        if (i < (int)(kKeyWeight + kMaxDirDigits)) {
+          if ((uint32_t)i < kKeyWeight + d && seed_len) slot += digit3(c, ga) * wgt;
+          wgt /= 3;
+        }
+      }
+    }
+    const uint64_t base = 1 + NW + s * kPerSeedWords;
+#pragma unroll
+    for (uint32_t w = 0; w < kCareWords; ++w) packed[(base + w) * stride + r] = care[w];
+    packed[(base + kCareWords) * stride + r] = slot;
+  }
 }
 
 void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t D,
                        uint32_t nw, uint32_t* d_packed, uint64_t stride, uint32_t* d_err, hipStream_t stream) {
-  hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(n)), dim3(kBlock), 0, stream, d_bases, d_offsets, n, ga, D, nw,
-                     d_packed, stride, d_err);
+  const dim3 g(grid_for(n)), b(kBlock);
+  switch (nw) {
+    case 8: hipLaunchKernelGGL(k_pack_reads<8>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
+    case 16: hipLaunchKernelGGL(k_pack_reads<16>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
+    case 32: hipLaunchKernelGGL(k_pack_reads<32>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
+    default: hipLaunchKernelGGL(k_pack_reads<64>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
+  }
 }
 
 // ---------------------------------------------------------------------------
