@@ -30,10 +30,11 @@ struct HIndex {
 };
 
 template <int NW>
-static void verify_region(const IndexView& iv, const StrandView& sv, const Region& reg, uint32_t seed_i,
+static void verify_region(const IndexView& iv, const StrandView& sv, const Lookup& lk, uint32_t seed_i,
                           uint32_t len, const uint32_t* rd, const uint32_t* mk, RegionSummary& sum) {
+  const Region& reg = lk.reg;
   for (uint32_t j = reg.l; j <= reg.u; ++j) {
-    uint32_t pos = sv.ent[j].pos;
+    uint32_t pos = (j - reg.l) < lk.npos ? lk.pos[j - reg.l] : sv.ent[j].pos;
     uint32_t chr = chrom_id(iv.start_index, iv.n_chrom, pos);
     if (pos - iv.start_index[chr] < seed_i) continue;
     uint32_t gp = pos - seed_i;
@@ -137,13 +138,15 @@ int hh_map_se(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, 
           if (best.mismatch == 0 && seed_i) break;
           if (best.mismatch == 1 && seed_i >= 2) break;
           const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
-          Region reg = seed_lookup(iv, sv, care, care[kCareWords], repeats);
+          Lookup lk;
+          seed_lookup_ex(iv, sv, care, care[kCareWords], repeats, lk);
+          const Region reg = lk.reg;
           uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
           if (size == 0 || size > b) continue;
           uint32_t mk[NW];
           for (int w = 0; w < NW; ++w) mk[w] = compare_mask_word(mt.data(), seed_i, repeats, len, (uint32_t)w);
           RegionSummary sum = summary_empty();
-          verify_region<NW>(iv, sv, reg, seed_i, len, rd, mk, sum);
+          verify_region<NW>(iv, sv, lk, seed_i, len, rd, mk, sum);
           fold_region(best, sum, fi == 0 ? '+' : '-');
         }
       }

@@ -218,55 +218,123 @@ WALT_HD bool bucket_is_bad(const StrandView& sv, uint32_t h) { return (sv.bad[h 
 
 // Full seed lookup for one (read, strand, seed shift): the region
 // SingleEndMapping gets from counter[] + IndexRegion (mapping.cpp:265-274).
-// care/slot come from the packed read.  Returns empty_region() when the bucket
-// is empty or nothing matches.
-WALT_HD Region seed_lookup(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
-                           uint32_t seed_len) {
+// care/slot come from the packed read.  The region is empty when the bucket is
+// empty or nothing matches.
+//
+// Memory behaviour matters more than instruction count here: every dependent
+// load of a binary search is a separate trip to HBM (the per-XCD L2 turns over
+// in a few microseconds under this kernel's random traffic, so even re-touching
+// a line misses).  A directory slot holds only a handful of entries, so slots of
+// up to kScan entries are fetched with INDEPENDENT loads (they land in one or two
+// 128-byte lines, in flight together) and searched in registers; the positions
+// of the first kSmallRegion candidates come back with them.  Longer slots fall
+// back to a binary search.
+constexpr uint32_t kScan = 6;
+constexpr uint32_t kLookupPos = 4;  // == kSmallRegion of the kernels
+
+struct Lookup {
+  Region reg;
+  uint32_t npos;              // pos[0..npos) are the genome positions of slots reg.l, reg.l+1, ...
+  uint32_t pos[kLookupPos];
+};
+
+WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
+                            uint32_t seed_len, Lookup& out) {
+  out.npos = 0;
+  out.reg = empty_region();
   uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
   uint32_t n = seed_len - kKeyWeight;
   if (bucket_is_bad(sv, h)) {
     uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
-    if (first == second) return empty_region();          // mapping.cpp:271-272
-    return lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);
+    if (first == second) return;                         // mapping.cpp:271-272
+    out.reg = lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);
+    return;
   }
   uint32_t D = iv.dir_digits;
   uint32_t d = D < n ? D : n;
   uint32_t lo = sv.dir[slot];
   uint32_t hi = sv.dir[slot + pow3(D - d)];
-  if (lo == hi) return empty_region();
-  Region r;
+  if (lo == hi) return;
   if (n == d) {
-    r.l = lo; r.u = hi - 1;
-    return r;
+    out.reg.l = lo; out.reg.u = hi - 1;
+    return;
   }
   uint32_t nk = n < kKeyChars ? n : kKeyChars;
   uint64_t M = key_mask(nk);
   uint64_t T = target_key(care) & M;
-  // lower bound of T among masked keys in [lo, hi)
-  uint32_t a = lo, b = hi;
-  while (a < b) {
-    uint32_t mid = a + ((b - a) >> 1);
-    if ((ent_key(sv.ent[mid]) & M) < T) a = mid + 1; else b = mid;
-  }
-  if (a == hi || (ent_key(sv.ent[a]) & M) != T) return empty_region();
-  // upper end: short linear probe, then binary search
-  uint32_t u = a;
-  uint32_t probe = 0;
-  while (u + 1 < hi && probe < 4) {
-    if ((ent_key(sv.ent[u + 1]) & M) != T) break;
-    ++u; ++probe;
-  }
-  if (probe == 4 && u + 1 < hi) {
-    uint32_t x = u + 1, y = hi;  // first index in [x,y) with masked key > T
+  uint32_t a, u;
+  const uint32_t ne = hi - lo;
+  if (ne <= kScan) {
+    Ent e[kScan];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t j = 0; j < kScan; ++j) {
+      // clamped index: loads stay independent of ne and inside the slot
+      e[j] = sv.ent[lo + (j < ne ? j : ne - 1)];
+    }
+    uint32_t n_lt = 0, n_eq = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t j = 0; j < kScan; ++j) {
+      const uint64_t k = ent_key(e[j]) & M;
+      n_lt += (j < ne && k < T) ? 1u : 0u;
+      n_eq += (j < ne && k == T) ? 1u : 0u;
+    }
+    if (n_eq == 0) return;
+    a = lo + n_lt;
+    u = a + n_eq - 1;
+    out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < kLookupPos; ++i) {
+      uint32_t p = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (uint32_t j = 0; j < kScan; ++j) p = (n_lt + i == j) ? e[j].pos : p;
+      out.pos[i] = p;
+    }
+  } else {
+    // lower bound of T among masked keys in [lo, hi)
+    uint32_t x = lo, y = hi;
     while (x < y) {
       uint32_t mid = x + ((y - x) >> 1);
-      if ((ent_key(sv.ent[mid]) & M) <= T) x = mid + 1; else y = mid;
+      if ((ent_key(sv.ent[mid]) & M) < T) x = mid + 1; else y = mid;
     }
-    u = x - 1;
+    a = x;
+    if (a == hi || (ent_key(sv.ent[a]) & M) != T) return;
+    // upper end: short linear probe, then binary search
+    u = a;
+    uint32_t probe = 0;
+    while (u + 1 < hi && probe < 4) {
+      if ((ent_key(sv.ent[u + 1]) & M) != T) break;
+      ++u; ++probe;
+    }
+    if (probe == 4 && u + 1 < hi) {
+      x = u + 1; y = hi;  // first index in [x,y) with masked key > T
+      while (x < y) {
+        uint32_t mid = x + ((y - x) >> 1);
+        if ((ent_key(sv.ent[mid]) & M) <= T) x = mid + 1; else y = mid;
+      }
+      u = x - 1;
+    }
   }
-  if (n > kKeyChars) return lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
-  r.l = a; r.u = u;
-  return r;
+  if (n > kKeyChars) {
+    out.npos = 0;
+    out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+    return;
+  }
+  out.reg.l = a; out.reg.u = u;
+}
+
+WALT_HD Region seed_lookup(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
+                           uint32_t seed_len) {
+  Lookup lk;
+  seed_lookup_ex(iv, sv, care, slot, seed_len, lk);
+  return lk.reg;
 }
 
 // ---------------------------------------------------------------------------

@@ -86,6 +86,31 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {  // lane is wa
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// Batch statistics.  Per-wave atomics on the four counters of walt_batch_stats
+// serialise at one L2 line (3 M same-address atomics cost ~8 ms per 50 M reads),
+// so each block reduces its counters in LDS and adds them to one of kStatShards
+// shards (one 128-byte line each) in the workspace; reduce_stats() folds the
+// shards into the caller's walt_batch_stats at the end of the call.
+constexpr uint32_t kStatShards = 256;
+constexpr uint32_t kStatShardWords = 16;  // u64 words per shard = 128 B
+constexpr uint64_t kStatShardBytes = (uint64_t)kStatShards * kStatShardWords * 8;
+
+__device__ __forceinline__ void block_flush_stats(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
+                                                  unsigned long long* __restrict__ shards) {
+  __shared__ uint32_t red[kBlock / 64][4];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  a0 = wave_sum_u32(a0); a1 = wave_sum_u32(a1); a2 = wave_sum_u32(a2); a3 = wave_sum_u32(a3);
+  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a3; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    uint32_t t = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; ++w) t += red[w][threadIdx.x];
+    if (t) atomicAdd(&shards[(uint64_t)(blockIdx.x % kStatShards) * kStatShardWords + threadIdx.x], (unsigned long long)t);
+  }
+}
+
+void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream);
+
 // Packing: ASCII reads -> packed records (index_core.h pack_read).  Defined in
 // map_se.hip; err[0] counts reads with a non-ACGT base, err[1] reads longer
 // than 16*nw.

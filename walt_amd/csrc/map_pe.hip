@@ -54,7 +54,9 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
       const bool full = hsize >= top_k;
       const uint32_t top_mm = hsize ? heap_mm(heap[0]) : 0xFFFFFFFFu;
       bool act = mappable && !(full && top_mm == 0 && seed_i) && !(full && top_mm == 1 && seed_i >= 2);
-      Region reg = empty_region();
+      Lookup lk;
+      lk.npos = 0;
+      lk.reg = empty_region();
       if (act) {
         uint32_t care[kCareWords];
         const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
@@ -65,9 +67,10 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
           deferred = true;
           mappable = false;
         } else {
-          reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk);
         }
       }
+      const Region reg = lk.reg;
       uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
       if (size) ++n_probe;
       if (size > b) size = 0;  // paired.cpp:161-163
@@ -75,13 +78,16 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
       make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
 
       if (size && size <= kSmallRegion) {
-        for (uint32_t k = 0; k < size; ++k) {
-          uint32_t pos = sv.ent[reg.l + k].pos, gp, mm;
-          if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
-            ++n_verified;
-            if (mm <= max_mm) {  // paired.cpp:192-195
-              HeapEnt e; e.pos = gp; e.mms = mm | (fi << 31);
-              topk_push(heap, hsize, top_k, e);
+#pragma unroll
+        for (uint32_t k = 0; k < kSmallRegion; ++k) {  // static k: lk.pos[] stays in registers
+          if (k < size) {
+            uint32_t pos = k < lk.npos ? lk.pos[k] : sv.ent[reg.l + k].pos, gp, mm;
+            if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
+              ++n_verified;
+              if (mm <= max_mm) {  // paired.cpp:192-195
+                HeapEnt e; e.pos = gp; e.mms = mm | (fi << 31);
+                topk_push(heap, hsize, top_k, e);
+              }
             }
           }
         }
@@ -138,17 +144,8 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
 }
 
 __device__ __forceinline__ void pe_flush(uint32_t shortv, uint32_t n_probe, uint32_t n_verified, uint32_t n_big,
-                                         unsigned long long* __restrict__ stats) {
-  shortv = wave_sum_u32(shortv);
-  n_probe = wave_sum_u32(n_probe);
-  n_verified = wave_sum_u32(n_verified);
-  n_big = wave_sum_u32(n_big);
-  if ((threadIdx.x & 63) == 0) {
-    if (shortv) atomicAdd(&stats[0], (unsigned long long)shortv);
-    if (n_probe) atomicAdd(&stats[1], (unsigned long long)n_probe);
-    if (n_verified) atomicAdd(&stats[2], (unsigned long long)n_verified);
-    if (n_big) atomicAdd(&stats[3], (unsigned long long)n_big);
-  }
+                                         unsigned long long* __restrict__ shards) {
+  block_flush_stats(shortv, n_probe, n_verified, n_big, shards);
 }
 
 template <int NW>
@@ -231,6 +228,7 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 struct PeWorkspace {
   uint32_t* err;
+  unsigned long long* shards[2];
   uint32_t* packed[2];
   HeapEnt* heaps[2];
   uint32_t* heap_n[2];
@@ -251,6 +249,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
   };
   w.stride = align_up(chunk ? chunk : 1, 64);
   w.err = reinterpret_cast<uint32_t*>(take(64 * sizeof(uint32_t)));
+  for (int m = 0; m < 2; ++m) w.shards[m] = reinterpret_cast<unsigned long long*>(take(kStatShardBytes));
   for (int m = 0; m < 2; ++m) w.packed[m] = reinterpret_cast<uint32_t*>(take((uint64_t)packed_fields((uint32_t)nw) * w.stride * 4));
   for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
   for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
@@ -285,7 +284,7 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
     launch_pack_reads(bases[m], offs[m], n, (uint32_t)m, idx->view.dir_digits, (uint32_t)nw, w.packed[m], w.stride,
                       w.err, stream);
-    unsigned long long* st = d_stats + 4 * m;
+    unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;
     switch (nw) {
       case 8: launch_pe_topk<8>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
@@ -293,6 +292,7 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
       case 32: launch_pe_topk<32>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
       default: launch_pe_topk<64>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
     }
+    launch_reduce_stats(w.shards[m], d_stats + 4 * m, stream);
     hipLaunchKernelGGL(k_pe_drain, dim3(grid_for(n)), dim3(kBlock), 0, stream, w.heaps[m], w.heap_n[m], n, top_k,
                        w.ranked[m]);
   }
@@ -338,6 +338,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
   const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
   PeWorkspace w = carve_pe(d_workspace, chunk, nw, top_k);
   WALT_HIP(hipMemsetAsync(w.err, 0, 64 * sizeof(uint32_t), stream));
+  for (int m = 0; m < 2; ++m) WALT_HIP(hipMemsetAsync(w.shards[m], 0, kStatShardBytes, stream));
   for (uint32_t start = 0; start < n; start += chunk) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases1), reinterpret_cast<const uint64_t*>(d_offsets1) + start,
@@ -397,6 +398,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
   }
   PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k);
   hipMemset(w.err, 0, 64 * sizeof(uint32_t));
+  for (int m = 0; m < 2; ++m) hipMemset(w.shards[m], 0, kStatShardBytes);
   for (uint32_t start = 0; start < n && !rc; start += chunk) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases[0]), reinterpret_cast<const uint64_t*>(d_off[0]) + start,

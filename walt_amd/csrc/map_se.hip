@@ -11,6 +11,8 @@
 // by the owning lane, regions larger than kSmallRegion verified by the whole
 // wavefront (lane k takes slot l+k, l+64+k, ...) with a ballot/min reduction
 // that reproduces the sequential BestMatch fold (mapping.cpp:306-313).
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "map_common.h"
@@ -210,7 +212,8 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
                                            const uint32_t* __restrict__ packed, uint64_t stride, uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
-                                           uint32_t* __restrict__ defer_list, MapCounters& ctr, uint32_t& len_out) {
+                                           uint32_t* __restrict__ defer_list, MapCounters& ctr, uint32_t& len_out,
+                                           uint32_t ablate = 0) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
   LaneRead<NW> lr;
@@ -230,7 +233,9 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
       // mapping.cpp:250-257 (a `break` there leaves every later seed skipped too,
       // which these per-seed predicates reproduce because best only improves)
       bool act = mappable && !(best.mismatch == 0 && seed_i) && !(best.mismatch == 1 && seed_i >= 2);
-      Region reg = empty_region();
+      Lookup lk;
+      lk.npos = 0;
+      lk.reg = empty_region();
       if (act) {
         uint32_t care[kCareWords];
         const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
@@ -240,24 +245,33 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         if (!LITERAL && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
+        } else if (ablate & 4u) {                       // diagnostic: no lookup at all
+        } else if (ablate & 2u) {                       // diagnostic: directory only
+          uint32_t lo = sv.dir[slot], hi = sv.dir[slot + 1];
+          if (lo > hi) lk.reg.l = 0;
         } else {
-          reg = seed_lookup(iv, sv, care, slot, lr.repeats);
+          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk);
         }
       }
+      const Region reg = lk.reg;
       uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
       if (size) ++ctr.probes;
       if (size > b) size = 0;  // mapping.cpp:275-277
+      if (ablate & 1u) size = 0;                        // diagnostic: no verification
       uint32_t mk[NW];
       make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
 
       // small regions: the owning lane walks its own candidates in order
       if (size && size <= kSmallRegion) {
         RegionSummary sum = summary_empty();
-        for (uint32_t k = 0; k < size; ++k) {
-          uint32_t pos = sv.ent[reg.l + k].pos, gp, mm;
-          if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
-            sum = summary_merge(sum, summary_one(mm, gp));
-            ++ctr.verified;
+#pragma unroll
+        for (uint32_t k = 0; k < kSmallRegion; ++k) {  // static k: lk.pos[] stays in registers
+          if (k < size) {
+            uint32_t pos = k < lk.npos ? lk.pos[k] : sv.ent[reg.l + k].pos, gp, mm;
+            if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
+              sum = summary_merge(sum, summary_one(mm, gp));
+              ++ctr.verified;
+            }
           }
         }
         fold_region(best, sum, strand_char);
@@ -292,16 +306,29 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 }
 
 __device__ __forceinline__ void flush_counters(const MapCounters& ctr, uint32_t shortv,
-                                               unsigned long long* __restrict__ stats) {
-  const uint32_t lane = threadIdx.x & 63;
-  uint32_t s0 = wave_sum_u32(shortv), s1 = wave_sum_u32(ctr.probes), s2 = wave_sum_u32(ctr.verified),
-           s3 = wave_sum_u32(ctr.big);
-  if (lane == 0) {
-    if (s0) atomicAdd(&stats[0], (unsigned long long)s0);
-    if (s1) atomicAdd(&stats[1], (unsigned long long)s1);
-    if (s2) atomicAdd(&stats[2], (unsigned long long)s2);
-    if (s3) atomicAdd(&stats[3], (unsigned long long)s3);
+                                               unsigned long long* __restrict__ shards) {
+  block_flush_stats(shortv, ctr.probes, ctr.verified, ctr.big, shards);
+}
+
+// folds the shards into walt_batch_stats (accumulating) and clears them
+static __global__ void k_reduce_stats(unsigned long long* __restrict__ shards, unsigned long long* __restrict__ stats) {
+  const uint32_t t = threadIdx.x;  // one thread per shard
+  unsigned long long v[4];
+  for (int i = 0; i < 4; ++i) {
+    v[i] = shards[(uint64_t)t * kStatShardWords + i];
+    shards[(uint64_t)t * kStatShardWords + i] = 0;
   }
+  __shared__ unsigned long long red[4][kStatShards];
+  for (int i = 0; i < 4; ++i) red[i][t] = v[i];
+  __syncthreads();
+  if (t < 4) {
+    unsigned long long sum = 0;
+    for (uint32_t k = 0; k < kStatShards; ++k) sum += red[t][k];
+    if (sum) atomicAdd(&stats[t], sum);
+  }
+}
+void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(kStatShards), 0, stream, d_shards, d_stats);
 }
 
 // pass 1: every read of the batch, one per lane
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t*
                                                     BestMatch* __restrict__ out,
                                                     unsigned long long* __restrict__ stats,
                                                     uint32_t* __restrict__ defer_count,
-                                                    uint32_t* __restrict__ defer_list) {
+                                                    uint32_t* __restrict__ defer_list, uint32_t ablate) {
   __shared__ BlockShared sh;
   const uint32_t* si = block_prologue(sh, iv, mask_table);
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t*
   MapCounters ctr = {0, 0, 0};
   uint32_t len;
   se_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, defer_count, defer_list,
-                        ctr, len);
+                        ctr, len, ablate);
   // too_short is counted once per strand pass (mapping.cpp:230-233)
   flush_counters(ctr, (valid && len < kMinReadLen) ? 2u : 0u, stats);
 }
@@ -357,6 +384,10 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 
+// WALT_AMD_ABLATE (diagnostic builds of the measurement only; results are WRONG when
+// it is set): bit 0 skips verification, bit 1 stops after the directory lookup,
+// bit 2 skips the lookup.  Used to attribute HBM requests to the phases.
+static uint32_t g_ablate = 0;
 constexpr unsigned kLiteralGrid = 1024;  // blocks of the deferred-read pass (grid-stride)
 
 template <int NW>
@@ -365,7 +396,7 @@ static void launch_map_se(const walt_index* idx, const uint32_t* packed, uint64_
                           unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
                           hipStream_t stream) {
   hipLaunchKernelGGL(k_map_se<NW>, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list);
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate);
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
   hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list);
@@ -379,22 +410,28 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   if ((idx->strand_mask & need) != need)
     return fail(WALT_EINVAL, ag ? "index opened without the _GA10/_GA11 strands" : "index opened without the _CT00/_CT01 strands");
   if (n == 0) return WALT_OK;
+  {
+    const char* ab = getenv("WALT_AMD_ABLATE");
+    g_ablate = ab ? (uint32_t)atoi(ab) : 0u;
+    if (g_ablate) fprintf(stderr, "[walt_amd] WALT_AMD_ABLATE=%u: DIAGNOSTIC RUN, mapping results are not valid\n", g_ablate);
+  }
   const int nw = nw_for_len(max_read_len);
   if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
   WALT_HIP(hipSetDevice(idx->device));
   const uint64_t stride = se_stride(n);
-  // workspace: [64 words: pack errors, deferred count] [packed reads] [deferred read list]
+  // workspace: [64 words: pack errors, deferred count] [statistic shards] [packed reads] [deferred read list]
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
-  uint32_t* packed = err + 64;
+  unsigned long long* shards = reinterpret_cast<unsigned long long*>(err + 64);
+  uint32_t* packed = err + 64 + kStatShardBytes / 4;
   uint32_t* defer_count = err + 2;
   uint32_t* defer_list = packed + (uint64_t)packed_fields((uint32_t)nw) * stride;
-  WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t), stream));
+  WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
   launch_pack_reads(reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
                     (uint32_t)(ag ? 1 : 0), idx->view.dir_digits, (uint32_t)nw, packed, stride, err, stream);
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[1], stream));
   BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
-  unsigned long long* stats = reinterpret_cast<unsigned long long*>(d_stats);
+  unsigned long long* stats = shards;
   const uint32_t sb = ag ? 2u : 0u;
   switch (nw) {
     case 8: launch_map_se<8>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
@@ -402,6 +439,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
     case 32: launch_map_se<32>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
     default: launch_map_se<64>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
   }
+  launch_reduce_stats(shards, reinterpret_cast<unsigned long long*>(d_stats), stream);
   if (idx->profile) {
     WALT_HIP(hipEventRecord(idx->ev[2], stream));
     idx->ev_valid = true;
@@ -450,7 +488,7 @@ int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms) {
 size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
-  return 64 * sizeof(uint32_t) + ((size_t)packed_fields((uint32_t)nw) + 1) * se_stride(n) * sizeof(uint32_t);
+  return 64 * sizeof(uint32_t) + kStatShardBytes + ((size_t)packed_fields((uint32_t)nw) + 1) * se_stride(n) * sizeof(uint32_t);
 }
 
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
