@@ -94,7 +94,7 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
   s.dir[slots] = index_size;
   s.view.g2 = s.g2.data(); s.view.cnt = s.cnt.data(); s.view.bad = s.bad.data(); s.view.dir = s.dir.data();
   s.view.ent = s.ent.data(); s.view.index_size = index_size; s.view.genome_len = genome_len; s.view.ga = ga;
-  s.view.pad_ = 0;
+  s.view.pad_ = 0; s.view.bloom = nullptr;
   h->view.s[strand] = s.view;
   h->view.start_index = h->start.data();
   h->present[strand] = true;

@@ -68,6 +68,7 @@ struct StrandView {
   uint32_t genome_len;
   uint32_t ga;  // 0: C->T strand (letters A,G,T)  1: G->A strand (letters A,C,T)
   uint32_t pad_;
+  const uint32_t* bloom;  // kBloomBits-bit Bloom filter over the BAD bucket ids (2 hashes)
 };
 
 struct IndexView {
@@ -216,6 +217,19 @@ WALT_HD uint64_t key_mask(uint32_t nk) { return nk >= 32 ? ~0ull : ~(~0ull >> (2
 
 WALT_HD bool bucket_is_bad(const StrandView& sv, uint32_t h) { return (sv.bad[h >> 5] >> (h & 31)) & 1u; }
 
+// The 2 MB BAD bitmap does not stay in the L2 under the mapping kernels' random
+// traffic, so every probe's bitmap read became an HBM-side request.  BAD
+// buckets are rare (a few per chromosome end), so the kernels test a small
+// Bloom filter held in LDS first and read the bitmap only on a filter hit.
+constexpr uint32_t kBloomBits = 1u << 16;
+constexpr uint32_t kBloomWords = kBloomBits / 32;
+WALT_HD uint32_t bloom_h1(uint32_t h) { return (h * 0x9E3779B1u) >> 16; }
+WALT_HD uint32_t bloom_h2(uint32_t h) { return (h * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 16; }
+WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t h) {
+  const uint32_t a = bloom_h1(h), b = bloom_h2(h);
+  return ((bloom[a >> 5] >> (a & 31)) & (bloom[b >> 5] >> (b & 31)) & 1u) != 0;
+}
+
 // Full seed lookup for one (read, strand, seed shift): the region
 // SingleEndMapping gets from counter[] + IndexRegion (mapping.cpp:265-274).
 // care/slot come from the packed read.  The region is empty when the bucket is
@@ -239,12 +253,12 @@ struct Lookup {
 };
 
 WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
-                            uint32_t seed_len, Lookup& out) {
+                            uint32_t seed_len, Lookup& out, bool known_good = false) {
   out.npos = 0;
   out.reg = empty_region();
   uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
   uint32_t n = seed_len - kKeyWeight;
-  if (bucket_is_bad(sv, h)) {
+  if (!known_good && bucket_is_bad(sv, h)) {
     uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
     if (first == second) return;                         // mapping.cpp:271-272
     out.reg = lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);

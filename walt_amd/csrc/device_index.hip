@@ -98,6 +98,21 @@ __global__ void k_build_dir(const uint32_t* __restrict__ cnt, const Ent* __restr
   dir[K] = K == slots ? index_size : dir_entry(cnt, ent, D, ga, K);
 }
 
+// Bloom filter over the BAD bucket ids (one thread per bitmap word)
+__global__ void k_build_bloom(const uint32_t* __restrict__ bad, uint32_t nwords, uint32_t* __restrict__ bloom) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  uint32_t w = bad[i];
+  while (w) {
+    uint32_t bit = __ffs((int)w) - 1;
+    w &= w - 1;
+    uint32_t h = i * 32 + bit;
+    uint32_t a = bloom_h1(h), b = bloom_h2(h);
+    atomicOr(&bloom[a >> 5], 1u << (a & 31));
+    atomicOr(&bloom[b >> 5], 1u << (b & 31));
+  }
+}
+
 __global__ void k_popcount(const uint32_t* __restrict__ words, uint32_t n, unsigned long long* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t c = i < n ? __popc(words[i]) : 0;
@@ -150,9 +165,11 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   const uint32_t D = idx->view.dir_digits;
   const uint32_t slots = idx->view.dir_slots;
   StrandView& sv = idx->view.s[strand];
-  uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr;
+  uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr, *bloom = nullptr;
   Ent* ent = nullptr;
   int rc;
+  if ((rc = dev_alloc(idx, &bloom, kBloomWords))) return rc;
+  WALT_HIP(hipMemsetAsync(bloom, 0, kBloomWords * 4, stream));
   if ((rc = dev_alloc(idx, &cnt, (uint64_t)kNumBuckets + 1))) return rc;
   if ((rc = dev_alloc(idx, &bad, kNumBuckets / 32))) return rc;
   if ((rc = dev_alloc(idx, &dir, (uint64_t)slots + 1))) return rc;
@@ -187,6 +204,8 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   WALT_HIP(hipMemsetAsync(d_cnt64, 0, sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(k_popcount, dim3(grid_for(kNumBuckets / 32)), dim3(kBlock), 0, stream, bad, kNumBuckets / 32,
                      d_cnt64);
+  hipLaunchKernelGGL(k_build_bloom, dim3(grid_for(kNumBuckets / 32)), dim3(kBlock), 0, stream, bad, kNumBuckets / 32,
+                     bloom);
   unsigned long long nbad = 0;
   WALT_HIP(hipMemcpyAsync(&nbad, d_cnt64, sizeof(nbad), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
@@ -199,7 +218,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
                                   " index entries are not in the bucket of their hash");
   idx->bad_buckets[strand] = nbad;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
-  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.pad_ = 0;
+  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.pad_ = 0; sv.bloom = bloom;
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }

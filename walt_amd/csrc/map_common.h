@@ -10,18 +10,25 @@ namespace walt {
 
 constexpr uint32_t kMaskTableWords = 3 * (kMaxRepeats - kMinRepeats + 1) * kMaskWords;  // 1170
 constexpr uint32_t kLdsChroms = 1023;  // start_index entries staged in LDS when they fit
+constexpr unsigned kPersistentGrid = 256 * 8;  // blocks of the persistent mapping kernels (256 CUs x 8)
 constexpr uint32_t kSmallRegion = 4;   // regions up to this size are verified by their own lane
 
 struct BlockShared {
   uint32_t mask_table[kMaskTableWords];
   uint32_t start_index[kLdsChroms + 1];
+  uint32_t bloom[2][kBloomWords];  // BAD-bucket filters of the two strands this launch maps against
 };
 
 // Stage the compare-mask table and the chromosome starts in LDS.  Returns the
 // pointer the lanes use for start_index lookups (LDS when it fits, else HBM).
 __device__ __forceinline__ const uint32_t* block_prologue(BlockShared& sh, const IndexView& iv,
-                                                          const uint32_t* __restrict__ mask_table) {
+                                                          const uint32_t* __restrict__ mask_table,
+                                                          uint32_t strand_base) {
   for (uint32_t i = threadIdx.x; i < kMaskTableWords; i += blockDim.x) sh.mask_table[i] = mask_table[i];
+  for (uint32_t fi = 0; fi < 2; ++fi) {
+    const uint32_t* __restrict__ bl = iv.s[strand_base + fi].bloom;
+    for (uint32_t i = threadIdx.x; i < kBloomWords; i += blockDim.x) sh.bloom[fi][i] = bl[i];
+  }
   const bool fits = iv.n_chrom <= kLdsChroms;
   if (fits)
     for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) sh.start_index[i] = iv.start_index[i];

@@ -63,11 +63,11 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
 #pragma unroll
         for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
         uint32_t slot = packed[(fbase + kCareWords) * stride + r];
-        if (!LITERAL && bucket_is_bad(sv, care[0] >> 8)) {
+        if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
         } else {
-          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk);
+          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk, !LITERAL);
         }
       }
       const Region reg = lk.reg;
@@ -158,14 +158,19 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
                                                      uint32_t* __restrict__ defer_count,
                                                      uint32_t* __restrict__ defer_list) {
   __shared__ BlockShared sh;
-  const uint32_t* si = block_prologue(sh, iv, mask_table);
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = r < n;
-  uint32_t n_probe = 0, n_verified = 0, n_big = 0, len;
-  pe_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, top_k, heaps, heap_n,
-                        defer_count, defer_list, n_probe, n_verified, n_big, len);
-  // paired.cpp:112-115: too_short once per strand pass
-  pe_flush((valid && len < kMinReadLen) ? 2u : 0u, n_probe, n_verified, n_big, stats);
+  const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
+  uint32_t n_probe = 0, n_verified = 0, n_big = 0, shortv = 0;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r64 = base + threadIdx.x;
+    const bool valid = r64 < n;
+    const uint32_t r = valid ? (uint32_t)r64 : 0;
+    uint32_t len;
+    pe_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, top_k, heaps, heap_n,
+                          defer_count, defer_list, n_probe, n_verified, n_big, len);
+    // paired.cpp:112-115: too_short once per strand pass
+    shortv += (valid && len < kMinReadLen) ? 2u : 0u;
+  }
+  pe_flush(shortv, n_probe, n_verified, n_big, stats);
 }
 
 template <int NW>
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const 
                                                              const uint32_t* __restrict__ defer_count,
                                                              const uint32_t* __restrict__ defer_list) {
   __shared__ BlockShared sh;
-  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   const uint32_t count = *defer_count;
   uint32_t n_probe = 0, n_verified = 0, n_big = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
@@ -264,7 +269,8 @@ static void launch_pe_topk(const walt_index* idx, const uint32_t* packed, uint64
                            uint32_t max_mm, uint32_t b, uint32_t top_k, HeapEnt* heaps, uint32_t* heap_n,
                            unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, packed, stride, n, sb,
+  const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
+  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, packed, stride, n, sb,
                      max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
   unsigned g2 = grid_for(n) < 1024u ? grid_for(n) : 1024u;
   hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride, sb, max_mm,

@@ -242,7 +242,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 #pragma unroll
         for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
         uint32_t slot = packed[(fbase + kCareWords) * stride + r];
-        if (!LITERAL && bucket_is_bad(sv, care[0] >> 8)) {
+        if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
         } else if (ablate & 4u) {                       // diagnostic: no lookup at all
@@ -250,7 +250,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
           uint32_t lo = sv.dir[slot], hi = sv.dir[slot + 1];
           if (lo > hi) lk.reg.l = 0;
         } else {
-          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk);
+          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk, !LITERAL);
         }
       }
       const Region reg = lk.reg;
@@ -333,7 +333,7 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 
 // pass 1: every read of the batch, one per lane
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 5 : 1)) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
                                                     uint64_t stride, uint32_t n, uint32_t strand_base,
                                                     uint32_t max_mm, uint32_t b,
                                                     const uint32_t* __restrict__ mask_table,
@@ -342,15 +342,22 @@ __global__ __launch_bounds__(kBlock) void k_map_se(IndexView iv, const uint32_t*
                                                     uint32_t* __restrict__ defer_count,
                                                     uint32_t* __restrict__ defer_list, uint32_t ablate) {
   __shared__ BlockShared sh;
-  const uint32_t* si = block_prologue(sh, iv, mask_table);
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = r < n;
+  const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
+  // persistent blocks: the LDS prologue (mask table, chromosome starts, Bloom
+  // filters: ~25 KB) is paid once per block, not once per 256 reads
   MapCounters ctr = {0, 0, 0};
-  uint32_t len;
-  se_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, defer_count, defer_list,
-                        ctr, len, ablate);
-  // too_short is counted once per strand pass (mapping.cpp:230-233)
-  flush_counters(ctr, (valid && len < kMinReadLen) ? 2u : 0u, stats);
+  uint32_t shortv = 0;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r64 = base + threadIdx.x;
+    const bool valid = r64 < n;
+    const uint32_t r = valid ? (uint32_t)r64 : 0;
+    uint32_t len;
+    se_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, defer_count,
+                          defer_list, ctr, len, ablate);
+    // too_short is counted once per strand pass (mapping.cpp:230-233)
+    shortv += (valid && len < kMinReadLen) ? 2u : 0u;
+  }
+  flush_counters(ctr, shortv, stats);
 }
 
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
                                                             const uint32_t* __restrict__ defer_count,
                                                             const uint32_t* __restrict__ defer_list) {
   __shared__ BlockShared sh;
-  const uint32_t* si = block_prologue(sh, iv, mask_table);
+  const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   const uint32_t count = *defer_count;
   MapCounters ctr = {0, 0, 0};
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
@@ -395,7 +402,8 @@ static void launch_map_se(const walt_index* idx, const uint32_t* packed, uint64_
                           uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                           unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
                           hipStream_t stream) {
-  hipLaunchKernelGGL(k_map_se<NW>, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
+  const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
+  hipLaunchKernelGGL(k_map_se<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate);
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
   hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride,
