@@ -138,10 +138,13 @@ static int dev_alloc(walt_index* idx, T** p, uint64_t count) {
 
 int choose_dir_digits(uint64_t max_index_size, int requested) {
   if (requested >= 0) return requested > (int)kMaxDirDigits ? (int)kMaxDirDigits : requested;
-  // smallest D with index_size / 3^(12+D) <= 8 entries per directory slot
+  // smallest D with index_size / 3^(12+D) <= 3 entries per directory slot: slots
+  // of up to kScan entries are searched with independent loads (core.h), and the
+  // slots a read actually probes are several times fuller than the mean because
+  // a converted strand is half one letter (T or A)
   int D = 0;
   uint64_t slots = 531441;  // 3^12
-  while (D < (int)kMaxDirDigits && max_index_size > 8 * slots) {
+  while (D < (int)kMaxDirDigits && max_index_size > 3 * slots) {
     slots *= 3;
     ++D;
   }

@@ -116,6 +116,14 @@ __device__ __forceinline__ void block_flush_stats(uint32_t a0, uint32_t a1, uint
   }
 }
 
+// Deferred reads are tagged with the (strand, seed) iteration of their first BAD
+// probe and grouped by it before the literal pass, so that the lanes of a
+// literal-pass wave run their long searches in the same iteration instead of
+// one after another.  Entry = read | iteration << kDeferShift.
+constexpr uint32_t kDeferShift = 28;
+constexpr uint32_t kDeferMask = (1u << kDeferShift) - 1;
+void launch_bin_deferred(const uint32_t* d_count, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream);
+
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream);
 
 // Packing: ASCII reads -> packed records (index_core.h pack_read).  Defined in

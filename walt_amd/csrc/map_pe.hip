@@ -41,6 +41,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
+  uint32_t defer_iter = 0;
   HeapEnt* heap = heaps + (uint64_t)(valid ? r : 0) * top_k;
   uint32_t hsize = 0;
 
@@ -66,6 +67,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
+          defer_iter = fi * 3 + seed_i;
         } else {
           seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk, !LITERAL);
         }
@@ -137,7 +139,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
     }
   }
   if (!LITERAL && deferred) {
-    defer_list[atomicAdd(defer_count, 1u)] = r;
+    defer_list[atomicAdd(defer_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
   } else if (valid) {
     heap_n[r] = hsize;
   }
@@ -258,7 +260,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
   for (int m = 0; m < 2; ++m) w.packed[m] = reinterpret_cast<uint32_t*>(take((uint64_t)packed_fields((uint32_t)nw) * w.stride * 4));
   for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
   for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
-  for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
+  for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take(2 * w.stride * 4 + 64));
   for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
   w.total_bytes = off;
   return w;
@@ -272,9 +274,11 @@ static void launch_pe_topk(const walt_index* idx, const uint32_t* packed, uint64
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
   hipLaunchKernelGGL(k_pe_topk<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, packed, stride, n, sb,
                      max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
+  uint32_t* defer_sorted = defer_list + stride;  // second half of the list area
+  launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   unsigned g2 = grid_for(n) < 1024u ? grid_for(n) : 1024u;
   hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride, sb, max_mm,
-                     b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
+                     b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_sorted);
 }
 
 // one chunk (n <= chunk capacity of the workspace)

@@ -221,6 +221,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
+  uint32_t defer_iter = 0;
 
   BestMatch best;  // mapping.cpp:486
   best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
@@ -245,6 +246,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
+          defer_iter = fi * 3 + seed_i;
         } else if (ablate & 4u) {                       // diagnostic: no lookup at all
         } else if (ablate & 2u) {                       // diagnostic: directory only
           uint32_t lo = sv.dir[slot], hi = sv.dir[slot + 1];
@@ -299,7 +301,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
     }
   }
   if (!LITERAL && deferred) {
-    defer_list[atomicAdd(defer_count, 1u)] = r;
+    defer_list[atomicAdd(defer_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
   } else if (valid) {
     out[r] = best;
   }
@@ -327,6 +329,29 @@ static __global__ void k_reduce_stats(unsigned long long* __restrict__ shards, u
     if (sum) atomicAdd(&stats[t], sum);
   }
 }
+// counting sort of the deferred list by iteration tag (6 bins), one block
+static __global__ void k_bin_deferred(const uint32_t* __restrict__ count_p, const uint32_t* __restrict__ list,
+                                      uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t bins[8], base[8];
+  const uint32_t count = *count_p;
+  if (threadIdx.x < 8) bins[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) atomicAdd(&bins[list[i] >> kDeferShift], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int k = 0; k < 8; ++k) { base[k] = run; run += bins[k]; }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+    const uint32_t e = list[i];
+    sorted[atomicAdd(&base[e >> kDeferShift], 1u)] = e & kDeferMask;
+  }
+}
+void launch_bin_deferred(const uint32_t* d_count, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream) {
+  hipLaunchKernelGGL(k_bin_deferred, dim3(1), dim3(1024), 0, stream, d_count, d_list, d_sorted);
+}
+
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream) {
   hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(kStatShards), 0, stream, d_shards, d_stats);
 }
@@ -405,9 +430,12 @@ static void launch_map_se(const walt_index* idx, const uint32_t* packed, uint64_
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
   hipLaunchKernelGGL(k_map_se<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate);
+  uint32_t* defer_sorted = defer_list + stride;
+  if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
+  else defer_sorted = defer_list;
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
   hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list);
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted);
 }
 
 int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n, uint32_t max_read_len,
@@ -496,7 +524,7 @@ int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms) {
 size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
-  return 64 * sizeof(uint32_t) + kStatShardBytes + ((size_t)packed_fields((uint32_t)nw) + 1) * se_stride(n) * sizeof(uint32_t);
+  return 64 * sizeof(uint32_t) + kStatShardBytes + ((size_t)packed_fields((uint32_t)nw) + 2) * se_stride(n) * sizeof(uint32_t);
 }
 
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
