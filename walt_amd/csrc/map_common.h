@@ -122,7 +122,8 @@ __device__ __forceinline__ void block_flush_stats(uint32_t a0, uint32_t a1, uint
 // one after another.  Entry = read | iteration << kDeferShift.
 constexpr uint32_t kDeferShift = 28;
 constexpr uint32_t kDeferMask = (1u << kDeferShift) - 1;
-void launch_bin_deferred(const uint32_t* d_count, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream);
+void launch_bin_deferred(uint32_t* d_ctl /*32 zeroed words: [0] = count*/, const uint32_t* d_list, uint32_t* d_sorted,
+                         hipStream_t stream);
 
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream);
 

@@ -255,7 +255,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
     return q;
   };
   w.stride = align_up(chunk ? chunk : 1, 64);
-  w.err = reinterpret_cast<uint32_t*>(take(64 * sizeof(uint32_t)));
+  w.err = reinterpret_cast<uint32_t*>(take(128 * sizeof(uint32_t)));  // [0..1] pack errors, [64 + 32 m ...] deferral control of mate m
   for (int m = 0; m < 2; ++m) w.shards[m] = reinterpret_cast<unsigned long long*>(take(kStatShardBytes));
   for (int m = 0; m < 2; ++m) w.packed[m] = reinterpret_cast<uint32_t*>(take((uint64_t)packed_fields((uint32_t)nw) * w.stride * 4));
   for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
@@ -288,8 +288,8 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
                     hipStream_t stream) {
   const uint8_t* bases[2] = {d_bases1, d_bases2};
   const uint64_t* offs[2] = {d_off1, d_off2};
-  // err words: [0..1] pack errors (kept across chunks), [8 + m] deferred-read count of mate m (per chunk)
-  WALT_HIP(hipMemsetAsync(w.err + 8, 0, 2 * sizeof(uint32_t), stream));
+  // err words: [0..1] pack errors (kept across chunks), [64 + 32 m ..] deferral control block of mate m (per chunk)
+  WALT_HIP(hipMemsetAsync(w.err + 64, 0, 64 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) {
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
     launch_pack_reads(bases[m], offs[m], n, (uint32_t)m, idx->view.dir_digits, (uint32_t)nw, w.packed[m], w.stride,
@@ -297,10 +297,10 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;
     switch (nw) {
-      case 8: launch_pe_topk<8>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
-      case 16: launch_pe_topk<16>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
-      case 32: launch_pe_topk<32>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
-      default: launch_pe_topk<64>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 8 + m, w.defer_list[m], stream); break;
+      case 8: launch_pe_topk<8>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
+      case 16: launch_pe_topk<16>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
+      case 32: launch_pe_topk<32>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
+      default: launch_pe_topk<64>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
     }
     launch_reduce_stats(w.shards[m], d_stats + 4 * m, stream);
     hipLaunchKernelGGL(k_pe_drain, dim3(grid_for(n)), dim3(kBlock), 0, stream, w.heaps[m], w.heap_n[m], n, top_k,
@@ -347,7 +347,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
   WALT_HIP(hipSetDevice(idx->device));
   const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
   PeWorkspace w = carve_pe(d_workspace, chunk, nw, top_k);
-  WALT_HIP(hipMemsetAsync(w.err, 0, 64 * sizeof(uint32_t), stream));
+  WALT_HIP(hipMemsetAsync(w.err, 0, 128 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) WALT_HIP(hipMemsetAsync(w.shards[m], 0, kStatShardBytes, stream));
   for (uint32_t start = 0; start < n; start += chunk) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;
@@ -407,7 +407,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
   }
   PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k);
-  hipMemset(w.err, 0, 64 * sizeof(uint32_t));
+  hipMemset(w.err, 0, 128 * sizeof(uint32_t));
   for (int m = 0; m < 2; ++m) hipMemset(w.shards[m], 0, kStatShardBytes);
   for (uint32_t start = 0; start < n && !rc; start += chunk) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;

@@ -329,27 +329,46 @@ static __global__ void k_reduce_stats(unsigned long long* __restrict__ shards, u
     if (sum) atomicAdd(&stats[t], sum);
   }
 }
-// counting sort of the deferred list by iteration tag (6 bins), one block
-static __global__ void k_bin_deferred(const uint32_t* __restrict__ count_p, const uint32_t* __restrict__ list,
-                                      uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t bins[8], base[8];
-  const uint32_t count = *count_p;
-  if (threadIdx.x < 8) bins[threadIdx.x] = 0;
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) atomicAdd(&bins[list[i] >> kDeferShift], 1u);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int k = 0; k < 8; ++k) { base[k] = run; run += bins[k]; }
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-    const uint32_t e = list[i];
-    sorted[atomicAdd(&base[e >> kDeferShift], 1u)] = e & kDeferMask;
+// Counting sort of the deferred list by iteration tag (8 bins), wave-aggregated:
+// k_bin_count fills bins[0..7] (scratch words behind the deferred count),
+// k_bin_scatter turns them into cursors and scatters.  ctl[0] = count,
+// ctl[8..15] = bin counts, ctl[16..23] = cursors (all zeroed with the workspace head).
+static __global__ void k_bin_count(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list) {
+  const uint32_t count = ctl[0];
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t bin = i < count ? (list[i] >> kDeferShift) & 7u : 8u;
+    for (uint32_t k = 0; k < 8; ++k) {
+      const unsigned long long m = __ballot(bin == k);
+      if (lane == 0 && m) atomicAdd(&ctl[8 + k], (uint32_t)__popcll(m));
+    }
   }
 }
-void launch_bin_deferred(const uint32_t* d_count, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream) {
-  hipLaunchKernelGGL(k_bin_deferred, dim3(1), dim3(1024), 0, stream, d_count, d_list, d_sorted);
+static __global__ void k_bin_scatter(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list,
+                                     uint32_t* __restrict__ sorted) {
+  const uint32_t count = ctl[0];
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t start[8];
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < 8; ++k) { start[k] = run; run += ctl[8 + k]; }
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t e = i < count ? list[i] : 0u;
+    const uint32_t bin = i < count ? (e >> kDeferShift) & 7u : 8u;
+    for (uint32_t k = 0; k < 8; ++k) {
+      const unsigned long long m = __ballot(bin == k);
+      if (!m) continue;
+      uint32_t off = 0;
+      if (lane == 0) off = atomicAdd(&ctl[16 + k], (uint32_t)__popcll(m));
+      off = bcast(off, 0);
+      if (bin == k) sorted[start[k] + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = e & kDeferMask;
+    }
+  }
+}
+void launch_bin_deferred(uint32_t* d_ctl, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream) {
+  hipLaunchKernelGGL(k_bin_count, dim3(64), dim3(kBlock), 0, stream, d_ctl, d_list);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(64), dim3(kBlock), 0, stream, d_ctl, d_list, d_sorted);
 }
 
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream) {
@@ -459,7 +478,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   unsigned long long* shards = reinterpret_cast<unsigned long long*>(err + 64);
   uint32_t* packed = err + 64 + kStatShardBytes / 4;
-  uint32_t* defer_count = err + 2;
+  uint32_t* defer_count = err + 32;  // control block: [0] count, [8..15] bin counts, [16..23] bin cursors
   uint32_t* defer_list = packed + (uint64_t)packed_fields((uint32_t)nw) * stride;
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
