@@ -226,19 +226,15 @@ def main():
         map_ms.append(m_ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from walt_amd import dist as wdist
+    elapsed = wdist.allreduce_max(elapsed, device=dev)  # MAX over ranks
 
     # mapping statistics of the last step; the ONLY data-path collective is this
     # final sum over ranks (RCCL), mirroring StatSingleReads (mapping.hpp:94-100)
-    res = d_out.view(torch.int32).view(n, 4)
-    times = res[:, 1]
-    st = torch.stack([torch.tensor(n, device=dev), (times == 1).sum(), (times >= 2).sum(), (times == 0).sum()]).to(torch.int64)
-    if world > 1:
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-    total, uniq, amb, unm = [int(v) for v in st.tolist()]
+    times = d_out.view(torch.int32).view(n, 4)[:, 1]
+    too_short = int(d_stats[0].item()) // (args.warmup + args.steps)
+    st = wdist.allreduce_stats(wdist.se_stats_vector(times, too_short))
+    total, uniq, amb, unm, short = [int(v) for v in st.tolist()]
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * n * args.steps / elapsed
@@ -255,7 +251,7 @@ def main():
                        "max_mismatches": args.max_mismatches, "bucket_cap": args.bucket,
                        "index_dir_digits": idx.dir_digits, "index_hbm_gb": round(idx.device_bytes / 1e9, 2),
                        "index_build_s": round(t_index, 1), "parallelism": "replica-per-gpu x%d" % world},
-            "mapping": {"total": total, "unique": uniq, "ambiguous": amb, "unmapped": unm},
+            "mapping": {"total": total, "unique": uniq, "ambiguous": amb, "unmapped": unm, "too_short": short},
             "kernel_ms": {"pack_reads": float(np.mean(pack_ms)), "map_se": float(np.mean(map_ms))},
         }
         if not args.no_cpu_baseline:

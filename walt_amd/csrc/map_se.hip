@@ -329,46 +329,75 @@ static __global__ void k_reduce_stats(unsigned long long* __restrict__ shards, u
     if (sum) atomicAdd(&stats[t], sum);
   }
 }
-// Counting sort of the deferred list by iteration tag (8 bins), wave-aggregated:
-// k_bin_count fills bins[0..7] (scratch words behind the deferred count),
-// k_bin_scatter turns them into cursors and scatters.  ctl[0] = count,
-// ctl[8..15] = bin counts, ctl[16..23] = cursors (all zeroed with the workspace head).
+// Counting sort of the deferred list by iteration tag (8 bins).  Each block owns
+// a contiguous slice of the list and aggregates in LDS, so the global control
+// words see 8 atomics per block.  ctl[0] = count, ctl[8..15] = bin totals
+// (k_bin_count), ctl[16..23] = bin cursors (k_bin_scatter); zeroed per call.
+constexpr unsigned kBinBlocks = 64;
+
+__device__ __forceinline__ void bin_slice(uint32_t count, uint32_t& lo, uint32_t& hi) {
+  const uint32_t per = (count + kBinBlocks - 1) / kBinBlocks;
+  lo = blockIdx.x * per < count ? blockIdx.x * per : count;
+  hi = lo + per < count ? lo + per : count;
+}
 static __global__ void k_bin_count(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list) {
-  const uint32_t count = ctl[0];
+  __shared__ uint32_t bins[8];
+  if (threadIdx.x < 8) bins[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t lo, hi;
+  bin_slice(ctl[0], lo, hi);
   const uint32_t lane = threadIdx.x & 63;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+  for (uint32_t base = lo; base < hi; base += blockDim.x) {
     const uint32_t i = base + threadIdx.x;
-    const uint32_t bin = i < count ? (list[i] >> kDeferShift) & 7u : 8u;
+    const uint32_t bin = i < hi ? (list[i] >> kDeferShift) & 7u : 8u;
     for (uint32_t k = 0; k < 8; ++k) {
       const unsigned long long m = __ballot(bin == k);
-      if (lane == 0 && m) atomicAdd(&ctl[8 + k], (uint32_t)__popcll(m));
+      if (lane == 0 && m) atomicAdd(&bins[k], (uint32_t)__popcll(m));
     }
   }
+  __syncthreads();
+  if (threadIdx.x < 8 && bins[threadIdx.x]) atomicAdd(&ctl[8 + threadIdx.x], bins[threadIdx.x]);
 }
 static __global__ void k_bin_scatter(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list,
                                      uint32_t* __restrict__ sorted) {
-  const uint32_t count = ctl[0];
+  __shared__ uint32_t bins[8], cursor[8];
+  if (threadIdx.x < 8) bins[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t lo, hi;
+  bin_slice(ctl[0], lo, hi);
   const uint32_t lane = threadIdx.x & 63;
-  uint32_t start[8];
-  uint32_t run = 0;
-  for (uint32_t k = 0; k < 8; ++k) { start[k] = run; run += ctl[8 + k]; }
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+  for (uint32_t base = lo; base < hi; base += blockDim.x) {  // this block's bin counts
     const uint32_t i = base + threadIdx.x;
-    const uint32_t e = i < count ? list[i] : 0u;
-    const uint32_t bin = i < count ? (e >> kDeferShift) & 7u : 8u;
+    const uint32_t bin = i < hi ? (list[i] >> kDeferShift) & 7u : 8u;
+    for (uint32_t k = 0; k < 8; ++k) {
+      const unsigned long long m = __ballot(bin == k);
+      if (lane == 0 && m) atomicAdd(&bins[k], (uint32_t)__popcll(m));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {  // reserve this block's range inside every bin
+    uint32_t start = 0;
+    for (uint32_t k = 0; k < threadIdx.x; ++k) start += ctl[8 + k];
+    cursor[threadIdx.x] = start + (bins[threadIdx.x] ? atomicAdd(&ctl[16 + threadIdx.x], bins[threadIdx.x]) : 0u);
+  }
+  __syncthreads();
+  for (uint32_t base = lo; base < hi; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t e = i < hi ? list[i] : 0u;
+    const uint32_t bin = i < hi ? (e >> kDeferShift) & 7u : 8u;
     for (uint32_t k = 0; k < 8; ++k) {
       const unsigned long long m = __ballot(bin == k);
       if (!m) continue;
       uint32_t off = 0;
-      if (lane == 0) off = atomicAdd(&ctl[16 + k], (uint32_t)__popcll(m));
+      if (lane == 0) off = atomicAdd(&cursor[k], (uint32_t)__popcll(m));
       off = bcast(off, 0);
-      if (bin == k) sorted[start[k] + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = e & kDeferMask;
+      if (bin == k) sorted[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = e & kDeferMask;
     }
   }
 }
 void launch_bin_deferred(uint32_t* d_ctl, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream) {
-  hipLaunchKernelGGL(k_bin_count, dim3(64), dim3(kBlock), 0, stream, d_ctl, d_list);
-  hipLaunchKernelGGL(k_bin_scatter, dim3(64), dim3(kBlock), 0, stream, d_ctl, d_list, d_sorted);
+  hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBlock), 0, stream, d_ctl, d_list);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBlock), 0, stream, d_ctl, d_list, d_sorted);
 }
 
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream) {
