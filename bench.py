@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400_000)
     ap.add_argument("--max-mismatches", type=int, default=6)
     ap.add_argument("--bucket", type=int, default=5000)
-    ap.add_argument("--dir-digits", type=int, default=-1)
+    ap.add_argument("--dir-bits", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -181,10 +181,10 @@ def main():
     torch.cuda.empty_cache()  # hand the generator's cached blocks back: the library allocates with hipMalloc
     t0 = time.perf_counter()
     idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, HG19_NAMES, device=local,
-                                      strands=walt_amd.STRANDS_CT, dir_digits=args.dir_digits)
+                                      strands=walt_amd.STRANDS_CT, dir_bits=args.dir_bits)
     t_index = time.perf_counter() - t0
-    log("index: CT00 %d + CT01 %d entries, dir_digits %d, %.1f GB in HBM, bad buckets %d/%d (%.1f s)" % (
-        idx.index_size(0), idx.index_size(1), idx.dir_digits, idx.device_bytes / 1e9, idx.bad_buckets(0),
+    log("index: CT00 %d + CT01 %d entries, dir_bits %d, %.1f GB in HBM, bad buckets %d/%d (%.1f s)" % (
+        idx.index_size(0), idx.index_size(1), idx.dir_bits, idx.device_bytes / 1e9, idx.bad_buckets(0),
         idx.bad_buckets(1), t_index))
 
     n = args.reads
@@ -249,7 +249,7 @@ def main():
                                        sum(lens), n, args.read_len, args.max_mismatches, args.bucket),
                        "genome_bp": int(sum(lens)), "reads_per_gpu": n, "read_len": args.read_len,
                        "max_mismatches": args.max_mismatches, "bucket_cap": args.bucket,
-                       "index_dir_digits": idx.dir_digits, "index_hbm_gb": round(idx.device_bytes / 1e9, 2),
+                       "index_dir_bits": idx.dir_bits, "index_hbm_gb": round(idx.device_bytes / 1e9, 2),
                        "index_build_s": round(t_index, 1), "parallelism": "replica-per-gpu x%d" % world},
             "mapping": {"total": total, "unique": uniq, "ambiguous": amb, "unmapped": unm, "too_short": short},
             "kernel_ms": {"pack_reads": float(np.mean(pack_ms)), "map_se": float(np.mean(map_ms))},
@@ -265,8 +265,19 @@ def main():
             bytes_per_read = args.read_len + 16 + 8 * P + S * 4.25 + C * (4 + args.read_len / 4.0)
             kern_s = float(np.mean(map_ms)) / 1e3
             achieved = bytes_per_read * n / kern_s
+            # HBM bytes per launch from the PMC passes of tools/prof_pmc.sh on this same command
+            # (TCC_EA0_RDREQ x 128 B + WRITE_SIZE; profiles/traffic.json), null when not collected
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tj):
+                try:
+                    t = json.load(open(tj))
+                    if t.get("reads_per_launch") == n and t.get("genome_bp") == int(sum(lens)):
+                        traffic = t["hbm_bytes_per_launch"]
+                except (ValueError, KeyError):
+                    pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "k_map_se<8>",
+                               "frac": achieved / HBM_PEAK, "traffic": traffic, "kernel": "k_map_se<8> (+ literal pass)",
                                "algorithmic_bytes_per_read": bytes_per_read,
                                "per_read": {"probes": P, "search_steps": S, "candidates": C}}
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",
@@ -274,6 +285,8 @@ def main():
                                              "restatement with OpenMP; index in host memory" % ns,
                                    "bit_exact_vs_gpu": bool(same)}
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()  # ranks > 0 wait for rank 0's CPU baseline before tearing the group down
     idx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -86,9 +86,9 @@ int walt_device_count(void);
  * 324-351; call sites mapping.cpp:437,492 and paired.cpp:583,661): reads
  * <path> and the selected <path>_CT00/_CT01/_GA10/_GA11 files once, uploads
  * them to `device` and builds the derived HBM structures (2-bit genome, entry
- * keys, directory).  dir_digits < 0 picks the directory depth from the index
- * size. */
-int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_digits,
+ * keys, directory).  dir_bits = directory prefix length in bits (24..31); < 0
+ * picks it from the index size. */
+int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_bits,
                     walt_index** out);
 
 /* Same from host arrays laid out exactly like the .dbindex strand files
@@ -97,7 +97,7 @@ int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, 
 int walt_index_from_host(uint32_t n_chrom, const uint32_t* chrom_len, const char* const* chrom_names,
                          const uint8_t* const genome[4], const uint32_t* const counter[4],
                          const uint32_t* const index[4], const uint32_t index_size[4], int device,
-                         int dir_digits, walt_index** out);
+                         int dir_bits, walt_index** out);
 
 void walt_index_close(walt_index* idx);
 
@@ -107,7 +107,7 @@ uint32_t walt_index_chrom_len(const walt_index* idx, uint32_t i);
 const char* walt_index_chrom_name(const walt_index* idx, uint32_t i);
 uint64_t walt_index_genome_len(const walt_index* idx);
 uint64_t walt_index_device_bytes(const walt_index* idx);
-int walt_index_dir_digits(const walt_index* idx);
+int walt_index_dir_bits(const walt_index* idx);
 /* number of 4^12 buckets that take the literal search (diagnostic), per strand */
 uint64_t walt_index_bad_buckets(const walt_index* idx, int strand);
 
@@ -164,7 +164,7 @@ int walt_makedb(const char* fasta_path, const char* out_dbindex_path, int thread
  * (std::sort leaves those in an unspecified order, reference.cpp:296-298). */
 int walt_index_build_device(const void* d_genome_ascii, uint32_t n_chrom, const uint32_t* chrom_len,
                             const char* const* chrom_names, int device, unsigned strand_mask,
-                            int dir_digits, walt_index** out);
+                            int dir_bits, walt_index** out);
 
 /* HashTable::index_size of a resident strand (reference.hpp:84). */
 uint32_t walt_index_size(const walt_index* idx, int strand);

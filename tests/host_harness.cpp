@@ -46,14 +46,14 @@ static void verify_region(const IndexView& iv, const StrandView& sv, const Looku
 
 extern "C" {
 
-void* hh_index_new(uint32_t n_chrom, const uint32_t* chrom_len, int dir_digits) {
+void* hh_index_new(uint32_t n_chrom, const uint32_t* chrom_len, int dir_bits) {
   HIndex* h = new HIndex();
   h->start.assign(n_chrom + 1, 0);
   for (uint32_t i = 0; i < n_chrom; ++i) h->start[i + 1] = h->start[i] + chrom_len[i];
   memset(&h->view, 0, sizeof(h->view));
   h->view.n_chrom = n_chrom;
-  h->view.dir_digits = (uint32_t)dir_digits;
-  h->view.dir_slots = pow3(kKeyWeight + dir_digits);
+  h->view.dir_bits = (uint32_t)dir_bits;
+  h->view.dir_slots = 1u << dir_bits;
   for (int i = 0; i < 4; ++i) h->present[i] = false;
   return h;
 }
@@ -88,10 +88,15 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
       if (ha == hb) s.bad[ha >> 5] |= 1u << (ha & 31);
     }
   }
-  const uint32_t D = h->view.dir_digits, slots = h->view.dir_slots;
-  s.dir.resize((size_t)slots + 1);
-  for (uint32_t K = 0; K < slots; ++K) s.dir[K] = dir_entry(s.cnt.data(), s.ent.data(), D, ga, K);
-  s.dir[slots] = index_size;
+  const uint32_t Bd = h->view.dir_bits, slots = h->view.dir_slots;
+  s.dir.assign((size_t)slots + 1, index_size);
+  for (uint32_t j = 0; j < index_size; ++j) {
+    uint32_t v = ent_prefix(s.g2.data(), s.ent[j], ga, Bd);
+    uint32_t& d = s.dir[slots - v];
+    if (j < d) d = j;
+  }
+  for (size_t k = 1; k <= slots; ++k)
+    if (s.dir[k - 1] < s.dir[k]) s.dir[k] = s.dir[k - 1];
   s.view.g2 = s.g2.data(); s.view.cnt = s.cnt.data(); s.view.bad = s.bad.data(); s.view.dir = s.dir.data();
   s.view.ent = s.ent.data(); s.view.index_size = index_size; s.view.genome_len = genome_len; s.view.ga = ga;
   s.view.pad_ = 0; s.view.bloom = nullptr;
@@ -123,7 +128,7 @@ int hh_map_se(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, 
   for (uint32_t r = 0; r < n; ++r) {
     uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
     if (len > 1024) return -1;
-    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_digits, NW,
+    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_bits, NW,
                    rec.data(), 1))
       return -2;
     BestMatch best; best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
@@ -139,7 +144,7 @@ int hh_map_se(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, 
           if (best.mismatch == 1 && seed_i >= 2) break;
           const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
           Lookup lk;
-          seed_lookup_ex(iv, sv, care, care[kCareWords], repeats, lk);
+          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], repeats, lk);
           const Region reg = lk.reg;
           uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
           if (size == 0 || size > b) continue;
@@ -170,7 +175,7 @@ int hh_pe_topk(void* hp, const char* bases, const uint64_t* offsets, uint32_t n,
   for (uint32_t r = 0; r < n; ++r) {
     uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
     if (len > 1024) return -1;
-    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_digits, NW,
+    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_bits, NW,
                    rec.data(), 1))
       return -2;
     const uint32_t* rd = &rec[1];
@@ -186,7 +191,7 @@ int hh_pe_topk(void* hp, const char* bases, const uint64_t* offsets, uint32_t n,
           if (full && heap_mm(heap[0]) == 0 && seed_i) break;        // paired.cpp:133-135
           if (full && heap_mm(heap[0]) == 1 && seed_i >= 2) break;   // paired.cpp:139-141
           const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
-          Region reg = seed_lookup(iv, sv, care, care[kCareWords], repeats);
+          Region reg = seed_lookup(iv, sv, care, care[kCareWords], care[kCareWords + 1], repeats);
           uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
           if (size == 0 || size > b) continue;
           uint32_t mk[NW];

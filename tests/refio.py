@@ -227,10 +227,10 @@ def oracle_pe(db, seqs1, seqs2, max_mm=6, b=5000, top_k=50, frag_range=1000, thr
 # CPU harness drivers (per-lane kernel logic compiled with g++)
 # ---------------------------------------------------------------------------
 class HarnessIndex:
-    def __init__(self, db, dir_digits, strands=(0, 1, 2, 3)):
+    def __init__(self, db, dir_bits, strands=(0, 1, 2, 3)):
         H = harness()
         self.db = db
-        self.h = H.hh_index_new(db.n_chrom, db.lengths.ctypes.data, dir_digits)
+        self.h = H.hh_index_new(db.n_chrom, db.lengths.ctypes.data, dir_bits)
         self.bad = {}
         for s in strands:
             if db.genome[s] is None:

@@ -26,7 +26,7 @@ def wa():
 def g1_dev(wa, scratch):
     path = os.path.join(scratch, "g1_prod.dbindex")
     wa.makedb(os.path.join(refio.GOLDEN, "g1.fa"), path, threads=4)
-    idx = {D: wa.Index.open(path, device=0, strands=wa.STRANDS_ALL, dir_digits=D) for D in (-1, 2)}
+    idx = {D: wa.Index.open(path, device=0, strands=wa.STRANDS_ALL, dir_bits=D) for D in (-1, 27)}
     yield idx
     for i in idx.values():
         i.close()
@@ -41,7 +41,7 @@ def dev_se_mapper(idx):
     return mapper
 
 
-@pytest.mark.parametrize("D", [-1, 2])
+@pytest.mark.parametrize("D", [-1, 27])
 @pytest.mark.parametrize("case", SE_CASES)
 def test_gpu_se_reproduces_reference_files(g1_db, g1_dev, case, D):
     check_against_golden(case, run_se_case(g1_db, case, dev_se_mapper(g1_dev[D])))
@@ -49,7 +49,7 @@ def test_gpu_se_reproduces_reference_files(g1_db, g1_dev, case, D):
 
 @pytest.mark.parametrize("case", PE_CASES)
 def test_gpu_pe_reproduces_reference_files(wa, g1_db, g1_dev, case):
-    idx = g1_dev[2]
+    idx = g1_dev[27]
 
     def mapper(s1, s2, m, b, k, L):
         b1, o1 = wa.pack_reads(s1)
@@ -66,7 +66,7 @@ def test_gpu_se_records_equal_oracle_exact_times(wa, g1_db, g1_dev):
         _, seqs, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, fq), 10 ** 7))
         for m, b in ((6, 5000), (10, 5000), (3, 7), (0, 5000)):
             want, work = refio.oracle_se(g1_db, seqs, ag=ag, max_mm=m, b=b)
-            for D in (-1, 2):
+            for D in (-1, 27):
                 bases, offsets = wa.pack_reads(seqs)
                 got, stats = g1_dev[D].map_se_batch(bases, offsets, ag_wildcard=ag, max_mismatches=m, b=b)
                 assert_best_equal(got, want, "%s m=%d b=%d D=%d" % (fq, m, b, D))
@@ -105,15 +105,15 @@ def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
     bct, oct_ = wa.pack_reads(reads_ct)
     bga, oga = wa.pack_reads(reads_ga)
     any_bad = 0
-    for D in (0, 1, 3):
-        idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_digits=D)
+    for D in (24, 26, 31):
+        idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_bits=D)
         any_bad += sum(idx.bad_buckets(s) for s in range(4))
         got, st = idx.map_se_batch(bct, oct_, ag_wildcard=False, max_mismatches=6, b=5000)
         assert_best_equal(got, want_ct, "CT D=%d" % D)
         assert int(st["too_short"]) == int(wct["too_short"])
         got, _ = idx.map_se_batch(bga, oga, ag_wildcard=True, max_mismatches=4, b=50)
         assert_best_equal(got, want_ga, "GA D=%d" % D)
-        if D == 1:
+        if D == 26:
             for k in (2, 50):
                 # any reads can serve as "mate 2": it is mapped with G->A on the _GA1x strands
                 res, _, (g1, gn1, g2, gn2) = idx.map_pe_batch(bct, oct_, bct, oct_, max_mismatches=6, top_k=k,
@@ -199,7 +199,7 @@ def test_gpu_packed_records_equal_specification(wa, g1_dev):
     defines (checked for both conversions and all word widths)."""
     import random
     import torch
-    idx = g1_dev[2]
+    idx = g1_dev[27]
     rng = random.Random(3)
     dev = torch.device("cuda:0")
     for max_len in (100, 128, 150, 256, 400, 1000):
@@ -209,7 +209,7 @@ def test_gpu_packed_records_equal_specification(wa, g1_dev):
         bases, offsets = wa.pack_reads(reads)
         n = len(reads)
         nw = 8 if max_len <= 128 else 16 if max_len <= 256 else 32 if max_len <= 512 else 64
-        fields = 1 + nw + 15
+        fields = 1 + nw + 18
         stride = (n + 63) // 64 * 64
         for ag in (False, True):
             d_bases = torch.from_numpy(bases).to(dev)
@@ -223,7 +223,7 @@ def test_gpu_packed_records_equal_specification(wa, g1_dev):
             got = d_ws.cpu().numpy().view(np.uint32)[64 + 8192:64 + 8192 + fields * stride].reshape(fields, stride)[:, :n]
             want = np.zeros((fields, stride), dtype=np.uint32)
             hb = np.concatenate([bases, np.zeros(1, np.uint8)])
-            bad = refio.harness().hh_pack(hb.ctypes.data, offsets.ctypes.data, n, int(ag), idx.dir_digits, nw,
+            bad = refio.harness().hh_pack(hb.ctypes.data, offsets.ctypes.data, n, int(ag), idx.dir_bits, nw,
                                           want.ctypes.data, stride)
             assert bad == 0
             assert np.array_equal(got, want[:, :n]), (max_len, ag)

@@ -31,3 +31,17 @@ for nm, d in vals.items():
     for c, v in d.items():
         print("- %s = %.6g" % (c, v))
     print()
+
+# HBM traffic per launch of the mapping kernels (pass 1 + literal pass): every
+# TCC_EA0_RDREQ is a 128-byte request on this kernel (TCC_EA0_RDREQ_128B == RDREQ);
+# WRITE_SIZE is in KB.  Written for bench.py's roofline.traffic.
+import json
+rd = sum(d.get("TCC_EA0_RDREQ_sum", 0) for nm, d in vals.items() if "k_map_se" in nm)
+wr = sum(d.get("WRITE_SIZE", 0) for nm, d in vals.items() if "k_map_se" in nm)
+if rd:
+    meta = {"hbm_bytes_per_launch": rd * 128 + wr * 1024, "read_requests_128B": rd, "write_kb": wr,
+            "kernels": [nm for nm in vals if "k_map_se" in nm], "reads_per_launch": 50000000, "genome_bp": 3095677412,
+            "source": out}
+    with open(os.path.join(out, "traffic.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("traffic.json:", json.dumps(meta))

@@ -98,8 +98,8 @@ def lib():
     L.walt_index_genome_len.restype = u64
     L.walt_index_device_bytes.argtypes = [vp]
     L.walt_index_device_bytes.restype = u64
-    L.walt_index_dir_digits.argtypes = [vp]
-    L.walt_index_dir_digits.restype = ci
+    L.walt_index_dir_bits.argtypes = [vp]
+    L.walt_index_dir_bits.restype = ci
     L.walt_index_bad_buckets.argtypes = [vp, ci]
     L.walt_index_bad_buckets.restype = u64
     L.walt_map_se_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, vp, vp]
@@ -157,14 +157,14 @@ class Index:
         self._h = handle
 
     @classmethod
-    def open(cls, dbindex_path, device=0, strands=STRANDS_ALL, dir_digits=-1):
+    def open(cls, dbindex_path, device=0, strands=STRANDS_ALL, dir_bits=-1):
         h = ctypes.c_void_p()
-        _check(lib().walt_index_open(os.fsencode(dbindex_path), int(device), int(strands), int(dir_digits),
+        _check(lib().walt_index_open(os.fsencode(dbindex_path), int(device), int(strands), int(dir_bits),
                                      ctypes.byref(h)))
         return cls(h)
 
     @classmethod
-    def from_host(cls, chrom_len, genome, counter, index, chrom_names=None, device=0, dir_digits=-1):
+    def from_host(cls, chrom_len, genome, counter, index, chrom_names=None, device=0, dir_bits=-1):
         """genome/counter/index: 4-lists (CT00, CT01, GA10, GA11) of numpy arrays or None."""
         n = len(chrom_len)
         cl = np.ascontiguousarray(chrom_len, dtype=np.uint32)
@@ -189,13 +189,13 @@ class Index:
         h = ctypes.c_void_p()
         _check(lib().walt_index_from_host(n, cl.ctypes.data, names, ctypes.cast(g, ctypes.c_void_p),
                                           ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(ix, ctypes.c_void_p),
-                                          ctypes.cast(sz, ctypes.c_void_p), int(device), int(dir_digits),
+                                          ctypes.cast(sz, ctypes.c_void_p), int(device), int(dir_bits),
                                           ctypes.byref(h)))
         return cls(h)
 
     @classmethod
     def build_device(cls, d_genome_ascii, chrom_len, chrom_names=None, device=0, strands=STRANDS_ALL,
-                     dir_digits=-1):
+                     dir_bits=-1):
         """GPU makedb: d_genome_ascii is an HBM address of the ACGT genome (makedb.cpp:46-85)."""
         n = len(chrom_len)
         cl = np.ascontiguousarray(chrom_len, dtype=np.uint32)
@@ -205,7 +205,7 @@ class Index:
             names = ctypes.cast(arr, ctypes.c_void_p)
         h = ctypes.c_void_p()
         _check(lib().walt_index_build_device(d_genome_ascii, n, cl.ctypes.data, names, int(device), int(strands),
-                                             int(dir_digits), ctypes.byref(h)))
+                                             int(dir_bits), ctypes.byref(h)))
         return cls(h)
 
     def index_size(self, strand):
@@ -266,8 +266,8 @@ class Index:
         return lib().walt_index_device_bytes(self._h)
 
     @property
-    def dir_digits(self):
-        return lib().walt_index_dir_digits(self._h)
+    def dir_bits(self):
+        return lib().walt_index_dir_bits(self._h)
 
     def bad_buckets(self, strand):
         return lib().walt_index_bad_buckets(self._h, strand)

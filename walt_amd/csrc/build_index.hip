@@ -241,7 +241,7 @@ using namespace walt;
 extern "C" {
 
 int walt_index_build_device(const void* d_genome_ascii, uint32_t n_chrom, const uint32_t* chrom_len,
-                            const char* const* chrom_names, int device, unsigned strand_mask, int dir_digits,
+                            const char* const* chrom_names, int device, unsigned strand_mask, int dir_bits,
                             walt_index** out) {
   if (!d_genome_ascii || !out || !chrom_len || !n_chrom || !(strand_mask & 15u))
     return fail(WALT_EINVAL, "walt_index_build_device: bad argument");
@@ -257,7 +257,7 @@ int walt_index_build_device(const void* d_genome_ascii, uint32_t n_chrom, const 
   head.genome_len = (uint32_t)total;
   head.max_index_size = head.genome_len;  // upper bound, used to pick the directory depth
   walt_index* idx = nullptr;
-  int rc = new_index(device, head, dir_digits, &idx);
+  int rc = new_index(device, head, dir_bits, &idx);
   if (rc) return rc;
   std::vector<uint32_t> start(n_chrom + 1, 0);
   for (uint32_t i = 0; i < n_chrom; ++i) start[i + 1] = start[i] + chrom_len[i];

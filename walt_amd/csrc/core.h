@@ -22,10 +22,17 @@
 //          reference.cpp:258-288 but are READ as real bytes) or touch the end of
 //          the genome.  Such buckets take the literal search; all others take
 //          the key search, which returns the same [l,u].
-//   dir  : DERIVED directory over the first 12+D care chars in base 3 (a
-//          converted strand has a 3-letter alphabet): dir[K] = first slot whose
-//          (12+D)-char prefix is >= K.  Replaces the first D rounds of the
-//          per-character LowerBound/UpperBound narrowing by one lookup.
+//   dir  : DERIVED directory over the first Bd BITS of an order-preserving
+//          prefix code of the care characters.  A converted strand has three
+//          letters, one of them half of all bases (T after C->T, A after G->A),
+//          so the code gives that letter one bit and the others two
+//          (C->T: A=00 G=01 T=1;  G->A: A=0 C=10 T=11): code bits of an iid genome
+//          are uniform, slots are evenly filled, and bit-string order equals
+//          the index's lexicographic order.  dir is stored REVERSED:
+//          dir[S - v] = first index slot whose code prefix is >= v (S = 2^Bd),
+//          so that it is the running minimum of a forward scan when built.
+//          Replaces the per-character LowerBound/UpperBound narrowing of the
+//          first ~20 care characters by one lookup.
 #ifndef WALT_AMD_CORE_H_
 #define WALT_AMD_CORE_H_
 
@@ -49,7 +56,8 @@ constexpr uint32_t kMinRepeats = 12;    // (38 - 2) / 3
 constexpr uint32_t kKeyChars = 32;      // care chars 12..43 held in Ent::key
 constexpr uint32_t kMaskWords = 10;     // 160 bases of table-driven compare mask
 constexpr uint32_t kNumBuckets = 1u << 24;
-constexpr uint32_t kMaxDirDigits = 8;   // 3^(12+8) < 2^32
+constexpr uint32_t kMinDirBits = 24;    // directory prefixes always cover the 12 hash characters
+constexpr uint32_t kMaxDirBits = 31;
 constexpr uint32_t kEraseBucket = 500000;  // reference.cpp:211
 
 WALT_HD uint32_t care_pos(uint32_t i) { return 1 + 3 * i; }  // F2CAREDPOSITION[i]
@@ -75,8 +83,8 @@ struct IndexView {
   StrandView s[4];               // CT00, CT01, GA10, GA11
   const uint32_t* start_index;   // n_chrom + 1 (Genome::start_index, reference.hpp:55)
   uint32_t n_chrom;
-  uint32_t dir_digits;           // D
-  uint32_t dir_slots;            // 3^(12+D)
+  uint32_t dir_bits;             // Bd: directory prefix length in code bits
+  uint32_t dir_slots;            // S = 2^Bd
   uint32_t pad_;
 };
 
@@ -92,12 +100,13 @@ struct BestMatch {
 //   words[NW]      converted read, 2 bits/base, 16 bases per word
 //   care[s][4]     for seed shift s: the chars at read offsets s+1+3i, i<50,
 //                  MSB first (char 0 in bits 31..30 of care[s][0])
-//   slot[s]        first directory slot of the (12+d)-char prefix, d=min(D,n)
+//   slot[s], span[s]  the entries whose care characters start like this seed's
+//                  are dir[slot[s]] .. dir[slot[s] - span[s]] (reversed directory)
 // kept in SoA form in HBM: field f of read r at base[f * stride + r].
 constexpr uint32_t kCareWords = 4;
-constexpr uint32_t kPerSeedWords = kCareWords + 1;
+constexpr uint32_t kPerSeedWords = kCareWords + 2;
 WALT_HD uint32_t packed_fields(uint32_t nw) { return 1 + nw + 3 * kPerSeedWords; }
-// field 0: length; 1..nw: words; then per seed: care[4], slot
+// field 0: length; 1..nw: words; then per seed: care[4], slot, span
 
 // ---------------------------------------------------------------------------
 // small helpers
@@ -122,9 +131,11 @@ WALT_HD uint32_t base_code(uint8_t c) {
 WALT_HD uint32_t convert_code(uint32_t code, uint32_t ga) {
   return ga ? (code == 2 ? 0u : code) : (code == 1 ? 3u : code);
 }
-// base-3 digit of a converted code on a strand (C->T: A,G,T -> 0,1,2; G->A: A,C,T -> 0,1,2)
-WALT_HD uint32_t digit3(uint32_t code, uint32_t ga) { return ga ? code - (code >> 1) : (code + 1) >> 1; }
-WALT_HD uint32_t code_of_digit3(uint32_t d, uint32_t ga) { return ga ? (d == 2 ? 3u : d) : (d == 0 ? 0u : d + 1); }
+// order-preserving prefix code of a converted base (see the dir comment above)
+WALT_HD uint32_t pcode_len(uint32_t c, uint32_t ga) { return ga ? (c == 0 ? 1u : 2u) : (c == 3 ? 1u : 2u); }
+WALT_HD uint32_t pcode_bits(uint32_t c, uint32_t ga) {
+  return ga ? (c == 0 ? 0u : (c == 1 ? 2u : 3u)) : (c == 0 ? 0u : 1u);  // C->T: A 00, G 01, T 1
+}
 
 WALT_HD uint32_t g2_code(const uint32_t* g2, uint64_t pos) {
   return (g2[pos >> 4] >> (2 * (uint32_t)(pos & 15))) & 3u;
@@ -155,6 +166,27 @@ WALT_HD uint32_t care_char(const uint32_t* care, uint32_t p) {
   v = w == 1 ? c1 : v;
   v = w == 0 ? c0 : v;
   return (v >> (30 - 2 * (p & 15))) & 3u;
+}
+
+// Directory range of a care string of nchars characters: code prefixes
+// [v_lo, v_lo + span) (span is a power of two; 1 when the string has >= Bd bits).
+WALT_HD void dir_range(const uint32_t* care, uint32_t nchars, uint32_t ga, uint32_t Bd, uint32_t& v_lo,
+                       uint32_t& span) {
+  uint64_t acc = 0;
+  uint32_t nb = 0;
+  for (uint32_t i = 0; i < 32 && i < nchars && nb < Bd; ++i) {
+    const uint32_t c = care_char(care, i);
+    const uint32_t l = pcode_len(c, ga);
+    acc = (acc << l) | pcode_bits(c, ga);
+    nb += l;
+  }
+  if (nb >= Bd) {
+    v_lo = (uint32_t)(acc >> (nb - Bd));
+    span = 1;
+  } else {
+    v_lo = (uint32_t)(acc << (Bd - nb));
+    span = 1u << (Bd - nb);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -253,7 +285,7 @@ struct Lookup {
 };
 
 WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
-                            uint32_t seed_len, Lookup& out, bool known_good = false) {
+                            uint32_t span, uint32_t seed_len, Lookup& out, bool known_good = false) {
   out.npos = 0;
   out.reg = empty_region();
   uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
@@ -264,15 +296,10 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     out.reg = lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);
     return;
   }
-  uint32_t D = iv.dir_digits;
-  uint32_t d = D < n ? D : n;
+  (void)iv;
   uint32_t lo = sv.dir[slot];
-  uint32_t hi = sv.dir[slot + pow3(D - d)];
-  if (lo == hi) return;
-  if (n == d) {
-    out.reg.l = lo; out.reg.u = hi - 1;
-    return;
-  }
+  uint32_t hi = sv.dir[slot - span];
+  if (lo >= hi) return;
   uint32_t nk = n < kKeyChars ? n : kKeyChars;
   uint64_t M = key_mask(nk);
   uint64_t T = target_key(care) & M;
@@ -345,9 +372,9 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
 }
 
 WALT_HD Region seed_lookup(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
-                           uint32_t seed_len) {
+                           uint32_t span, uint32_t seed_len) {
   Lookup lk;
-  seed_lookup_ex(iv, sv, care, slot, seed_len, lk);
+  seed_lookup_ex(iv, sv, care, slot, span, seed_len, lk);
   return lk.reg;
 }
 

@@ -7,6 +7,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
 #include "device_common.h"
 
 namespace walt {
@@ -91,11 +96,19 @@ __global__ void k_check_buckets(const uint32_t* __restrict__ g2, const Ent* __re
   if (!(cnt[h] <= j && j < cnt[h + 1])) atomicAdd(err + 2, 1u);
 }
 
-__global__ void k_build_dir(const uint32_t* __restrict__ cnt, const Ent* __restrict__ ent, uint32_t D,
-                            uint32_t ga, uint32_t slots, uint32_t index_size, uint32_t* __restrict__ dir) {
-  uint32_t K = blockIdx.x * blockDim.x + threadIdx.x;
-  if (K > slots) return;
-  dir[K] = K == slots ? index_size : dir_entry(cnt, ent, D, ga, K);
+// Reversed directory, step 1: dir[S - v] = smallest index slot whose code prefix
+// is v (only run starts need to write; atomicMin because BAD buckets are not
+// monotone).  Step 2 (host driver): inclusive running minimum over dir[0..S].
+__global__ void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_dir_scatter(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t n, uint32_t ga,
+                              uint32_t Bd, uint32_t* __restrict__ dir) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t v = ent_prefix(g2, ent[j], ga, Bd);
+  if (j == 0 || ent_prefix(g2, ent[j - 1], ga, Bd) != v) atomicMin(&dir[(1u << Bd) - v], j);
 }
 
 // Bloom filter over the BAD bucket ids (one thread per bitmap word)
@@ -136,19 +149,13 @@ static int dev_alloc(walt_index* idx, T** p, uint64_t count) {
   return WALT_OK;
 }
 
-int choose_dir_digits(uint64_t max_index_size, int requested) {
-  if (requested >= 0) return requested > (int)kMaxDirDigits ? (int)kMaxDirDigits : requested;
-  // smallest D with index_size / 3^(12+D) <= 3 entries per directory slot: slots
-  // of up to kScan entries are searched with independent loads (core.h), and the
-  // slots a read actually probes are several times fuller than the mean because
-  // a converted strand is half one letter (T or A)
-  int D = 0;
-  uint64_t slots = 531441;  // 3^12
-  while (D < (int)kMaxDirDigits && max_index_size > 3 * slots) {
-    slots *= 3;
-    ++D;
-  }
-  return D;
+int choose_dir_bits(uint64_t max_index_size, int requested) {
+  if (requested >= 0) return requested > (int)kMaxDirBits ? (int)kMaxDirBits : requested < (int)kMinDirBits ? (int)kMinDirBits : requested;
+  // smallest Bd with index_size / 2^Bd <= 2 entries per directory slot (slots of
+  // up to kScan entries are searched with independent loads, core.h)
+  int B = (int)kMinDirBits;
+  while (B < (int)kMaxDirBits && max_index_size > (2ull << B)) ++B;
+  return B;
 }
 
 int alloc_strand_g2(walt_index* idx, uint32_t** g2_out, hipStream_t stream) {
@@ -165,7 +172,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
                          const uint32_t* d_index, uint32_t index_size, hipStream_t stream) {
   const uint32_t genome_len = idx->head.genome_len;
   const uint32_t ga = strand >= 2 ? 1u : 0u;
-  const uint32_t D = idx->view.dir_digits;
+  const uint32_t Bd = idx->view.dir_bits;
   const uint32_t slots = idx->view.dir_slots;
   StrandView& sv = idx->view.s[strand];
   uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr, *bloom = nullptr;
@@ -200,8 +207,25 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       hipLaunchKernelGGL(k_mark_unsorted, dim3(grid_for(index_size - 1)), dim3(kBlock), 0, stream, g2, ent,
                          index_size, bad);
   }
-  hipLaunchKernelGGL(k_build_dir, dim3(grid_for((uint64_t)slots + 1)), dim3(kBlock), 0, stream, cnt, ent, D, ga,
-                     slots, index_size, dir);
+  // reversed directory: fill with "past the end", scatter run starts, running minimum
+  hipLaunchKernelGGL(k_fill_u32, dim3(grid_for((uint64_t)slots + 1)), dim3(kBlock), 0, stream, dir,
+                     (uint64_t)slots + 1, index_size);
+  if (index_size)
+    hipLaunchKernelGGL(k_dir_scatter, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, ent, index_size, ga,
+                       Bd, dir);
+  {
+    size_t tmp_bytes = 0;
+    WALT_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, dir, dir, (size_t)slots + 1, rocprim::minimum<uint32_t>(),
+                                     stream));
+    void* tmp = nullptr;
+    WALT_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    hipError_t se = rocprim::inclusive_scan(tmp, tmp_bytes, dir, dir, (size_t)slots + 1,
+                                            rocprim::minimum<uint32_t>(), stream);
+    hipError_t sy = hipStreamSynchronize(stream);
+    hipFree(tmp);
+    WALT_HIP(se);
+    WALT_HIP(sy);
+  }
   unsigned long long* d_cnt64 = nullptr;
   WALT_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt64), sizeof(unsigned long long)));
   WALT_HIP(hipMemsetAsync(d_cnt64, 0, sizeof(unsigned long long), stream));
@@ -265,7 +289,7 @@ int finish_index_device(walt_index* idx) {
   return WALT_OK;
 }
 
-int new_index(int device, const IndexHead& head, int dir_digits, walt_index** out) {
+int new_index(int device, const IndexHead& head, int dir_bits, walt_index** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(WALT_EHIP, "no HIP device available (the walt_amd hot path has no CPU fallback)");
@@ -275,8 +299,8 @@ int new_index(int device, const IndexHead& head, int dir_digits, walt_index** ou
   idx->device = device;
   idx->head = head;
   memset(&idx->view, 0, sizeof(idx->view));
-  idx->view.dir_digits = (uint32_t)choose_dir_digits(head.max_index_size, dir_digits);
-  idx->view.dir_slots = pow3(kKeyWeight + idx->view.dir_digits);
+  idx->view.dir_bits = (uint32_t)choose_dir_bits(head.max_index_size, dir_bits);
+  idx->view.dir_slots = 1u << idx->view.dir_bits;
   *out = idx;
   return WALT_OK;
 }
@@ -331,14 +355,14 @@ int walt_device_count(void) {
   return n;
 }
 
-int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_digits, walt_index** out) {
+int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_bits, walt_index** out) {
   if (!dbindex_path || !out || !(strand_mask & 15u)) return fail(WALT_EINVAL, "walt_index_open: bad argument");
   *out = nullptr;
   IndexHead head;
   int rc = read_index_head(dbindex_path, head);
   if (rc) return rc;
   walt_index* idx = nullptr;
-  if ((rc = new_index(device, head, dir_digits, &idx))) return rc;
+  if ((rc = new_index(device, head, dir_bits, &idx))) return rc;
   static const char* sfx[4] = {"_CT00", "_CT01", "_GA10", "_GA11"};
   for (int s = 0; s < 4 && !rc; ++s) {
     if (!(strand_mask & (1u << s))) continue;
@@ -360,7 +384,7 @@ int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, 
 
 int walt_index_from_host(uint32_t n_chrom, const uint32_t* chrom_len, const char* const* chrom_names,
                          const uint8_t* const genome[4], const uint32_t* const counter[4],
-                         const uint32_t* const index[4], const uint32_t index_size[4], int device, int dir_digits,
+                         const uint32_t* const index[4], const uint32_t index_size[4], int device, int dir_bits,
                          walt_index** out) {
   if (!out || !chrom_len || !n_chrom) return fail(WALT_EINVAL, "walt_index_from_host: bad argument");
   *out = nullptr;
@@ -376,7 +400,7 @@ int walt_index_from_host(uint32_t n_chrom, const uint32_t* chrom_len, const char
   for (int s = 0; s < 4; ++s)
     if (genome[s] && index_size[s] > head.max_index_size) head.max_index_size = index_size[s];
   walt_index* idx = nullptr;
-  int rc = new_index(device, head, dir_digits, &idx);
+  int rc = new_index(device, head, dir_bits, &idx);
   if (rc) return rc;
   for (int s = 0; s < 4 && !rc; ++s) {
     if (!genome[s]) continue;
@@ -412,7 +436,7 @@ const char* walt_index_chrom_name(const walt_index* idx, uint32_t i) {
 }
 uint64_t walt_index_genome_len(const walt_index* idx) { return idx ? idx->head.genome_len : 0; }
 uint64_t walt_index_device_bytes(const walt_index* idx) { return idx ? idx->device_bytes : 0; }
-int walt_index_dir_digits(const walt_index* idx) { return idx ? (int)idx->view.dir_digits : -1; }
+int walt_index_dir_bits(const walt_index* idx) { return idx ? (int)idx->view.dir_bits : -1; }
 uint64_t walt_index_bad_buckets(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->bad_buckets[strand] : 0;
 }

@@ -37,39 +37,20 @@ WALT_HD Ent make_ent(const uint32_t* g2, uint32_t genome_len, uint32_t pos, bool
   return e;
 }
 
-// Directory entry for base-3 key K over 12+D digits: lower bound, inside the
-// 4^12 bucket of its first 12 digits, of the D-digit sub-prefix among the Ent
-// keys.  (For BAD buckets the value is only ever used as the end of the
-// preceding bucket; sub-prefix 0 gives the bucket start there.)
-WALT_HD uint32_t dir_entry(const uint32_t* cnt, const Ent* ent, uint32_t D, uint32_t ga, uint32_t K) {
-  uint32_t sub = K % pow3(D);
-  uint32_t top = K / pow3(D);
-  // 12 base-3 digits -> base-4 bucket
-  uint32_t h = 0;
-  uint32_t div = pow3(kKeyWeight - 1);
-  for (uint32_t i = 0; i < kKeyWeight; ++i) {
-    uint32_t dgt = top / div;
-    top -= dgt * div;
-    div /= 3;
-    h = (h << 2) | code_of_digit3(dgt, ga);
+// Code prefix (first Bd bits, zero padded) of the care characters behind an index
+// entry: characters 0..11 from the genome, 12..43 from the entry key.
+WALT_HD uint32_t ent_prefix(const uint32_t* g2, const Ent& e, uint32_t ga, uint32_t Bd) {
+  uint64_t acc = 0;
+  uint32_t nb = 0;
+  const uint64_t key = ent_key(e);
+  for (uint32_t i = 0; i < kKeyWeight + kKeyChars && nb < Bd; ++i) {
+    const uint32_t c = i < kKeyWeight ? g2_code(g2, (uint64_t)e.pos + care_pos(i))
+                                      : (uint32_t)((key >> (2 * (kKeyWeight + kKeyChars - 1 - i))) & 3u);
+    const uint32_t l = pcode_len(c, ga);
+    acc = (acc << l) | pcode_bits(c, ga);
+    nb += l;
   }
-  uint32_t lo = cnt[h], hi = cnt[h + 1];
-  if (D == 0 || sub == 0) return lo;
-  uint64_t T = 0;
-  uint32_t sdiv = pow3(D - 1);
-  for (uint32_t i = 0; i < D; ++i) {
-    uint32_t dgt = sub / sdiv;
-    sub -= dgt * sdiv;
-    sdiv /= 3;
-    T = (T << 2) | code_of_digit3(dgt, ga);
-  }
-  T <<= (64 - 2 * D);
-  uint64_t M = key_mask(D);
-  while (lo < hi) {
-    uint32_t mid = lo + ((hi - lo) >> 1);
-    if ((ent_key(ent[mid]) & M) < T) lo = mid + 1; else hi = mid;
-  }
-  return lo;
+  return (uint32_t)(acc >> (nb - Bd));  // 44 characters carry >= 44 > Bd bits
 }
 
 // ---------------------------------------------------------------------------
@@ -77,7 +58,7 @@ WALT_HD uint32_t dir_entry(const uint32_t* cnt, const Ent* ent, uint32_t D, uint
 // loader leaves them (mapping.cpp:101-103).  Returns false on a non-ACGT char.
 // out has packed_fields(nw) words with stride `stride` (SoA over reads).
 // ---------------------------------------------------------------------------
-WALT_HD bool pack_read(const uint8_t* bases, uint32_t len, uint32_t ga, uint32_t D, uint32_t nw,
+WALT_HD bool pack_read(const uint8_t* bases, uint32_t len, uint32_t ga, uint32_t Bd, uint32_t nw,
                        uint32_t* out, uint64_t stride) {
   bool ok = true;
   out[0] = len;
@@ -96,20 +77,19 @@ WALT_HD bool pack_read(const uint8_t* bases, uint32_t len, uint32_t ga, uint32_t
   uint32_t seed_len = len >= kMinReadLen ? seed_repeats(len) : 0;
   for (uint32_t s = 0; s < 3; ++s) {
     uint32_t care[kCareWords] = {0, 0, 0, 0};
-    uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0;
-    uint32_t d = D < n ? D : n;
-    uint32_t K = 0;
     for (uint32_t p = 0; p < seed_len; ++p) {
       uint32_t i = s + care_pos(p);  // < len, see DESIGN.md
       uint32_t c = base_code(bases[i]);
       if (c > 3) c = 0;
       c = convert_code(c, ga);
       care[p >> 4] |= c << (30 - 2 * (p & 15));
-      if (p < kKeyWeight + d) K = K * 3 + digit3(c, ga);
     }
+    uint32_t v_lo = 0, span = 0;
+    if (seed_len) dir_range(care, seed_len, ga, Bd, v_lo, span);
     uint32_t base = 1 + nw + s * kPerSeedWords;
     for (uint32_t w = 0; w < kCareWords; ++w) out[(base + w) * stride] = care[w];
-    out[(base + kCareWords) * stride] = K * pow3(D - d);
+    out[(base + kCareWords) * stride] = seed_len ? (1u << Bd) - v_lo : 0u;  // index into the reversed directory
+    out[(base + kCareWords + 1) * stride] = span;
   }
   return ok;
 }

@@ -130,7 +130,7 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 // Packing: ASCII reads -> packed records (index_core.h pack_read).  Defined in
 // map_se.hip; err[0] counts reads with a non-ACGT base, err[1] reads longer
 // than 16*nw.
-void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t D,
+void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t Bd,
                        uint32_t nw, uint32_t* d_packed, uint64_t stride, uint32_t* d_err, hipStream_t stream);
 int check_pack_errors(const void* d_workspace, hipStream_t stream);
 

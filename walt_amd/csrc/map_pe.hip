@@ -63,13 +63,14 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
 #pragma unroll
         for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
-        uint32_t slot = packed[(fbase + kCareWords) * stride + r];
+        const uint32_t slot = packed[(fbase + kCareWords) * stride + r];
+        const uint32_t span = packed[(fbase + kCareWords + 1) * stride + r];
         if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
           defer_iter = fi * 3 + seed_i;
         } else {
-          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk, !LITERAL);
+          seed_lookup_ex(iv, sv, care, slot, span, lr.repeats, lk, !LITERAL);
         }
       }
       const Region reg = lk.reg;
@@ -292,7 +293,7 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   WALT_HIP(hipMemsetAsync(w.err + 64, 0, 64 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) {
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
-    launch_pack_reads(bases[m], offs[m], n, (uint32_t)m, idx->view.dir_digits, (uint32_t)nw, w.packed[m], w.stride,
+    launch_pack_reads(bases[m], offs[m], n, (uint32_t)m, idx->view.dir_bits, (uint32_t)nw, w.packed[m], w.stride,
                       w.err, stream);
     unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;

@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t convert_word(uint32_t x, uint32_t ga) {
 template <int NW>
 __global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict__ bases,
                                                         const uint64_t* __restrict__ offsets, uint32_t n,
-                                                        uint32_t ga, uint32_t D, uint32_t* __restrict__ packed,
+                                                        uint32_t ga, uint32_t Bd, uint32_t* __restrict__ packed,
                                                         uint64_t stride, uint32_t* __restrict__ err) {
   __shared__ uint32_t codes[kPackLdsBytes / 16 + 4];
   __shared__ uint32_t inval[kPackLdsBytes / 16 + 4];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict
     const uint64_t o = offsets[r];
     uint64_t len64 = offsets[r + 1] - o;
     if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
-    if (!pack_read(bases + o, (uint32_t)len64, ga, D, NW, packed + r, stride)) atomicAdd(err, 1u);
+    if (!pack_read(bases + o, (uint32_t)len64, ga, Bd, NW, packed + r, stride)) atomicAdd(err, 1u);
     return;
   }
   const uint32_t span = (uint32_t)(o1 - a0);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict
     // pack_read() stores code 0 for a non-ACGT char; reproduce that record
 #pragma unroll
     for (int w = 0; w < NW; ++w) rd[w] = 0;
-    pack_read(bases + o, len, ga, D, NW, packed + r, stride);
+    pack_read(bases + o, len, ga, Bd, NW, packed + r, stride);
     return;
   }
   packed[r] = len;
@@ -124,41 +124,48 @@ __global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict
   for (int w = 0; w < NW; ++w) packed[(uint64_t)(1 + w) * stride + r] = rd[w];
 
   const uint32_t seed_len = len >= kMinReadLen ? seed_repeats(len) : 0;
-  const uint32_t nsel = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0;
-  const uint32_t d = D < nsel ? D : nsel;
-  const uint32_t top_w = pow3(kKeyWeight + D - 1);
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     uint32_t care[kCareWords] = {0, 0, 0, 0};
-    uint32_t slot = 0, wgt = top_w;
+    uint64_t acc = 0;   // order-preserving prefix code of the care characters (core.h dir_range)
+    uint32_t nb = 0;
 #pragma unroll
     for (int i = 0; i < (int)kMaxRepeats; ++i) {
       const int q = s + 1 + 3 * i;  // compile-time read offset of care char i
       if ((q >> 4) < NW) {
         uint32_t c = (rd[q >> 4] >> (2 * (q & 15))) & 3u;
-        c = (uint32_t)i < seed_len ? c : 0u;
+        const bool in_seed = (uint32_t)i < seed_len;
+        c = in_seed ? c : 0u;
         care[i >> 4] |= c << (30 - 2 * (i & 15));
-        if (i < (int)(kKeyWeight + kMaxDirDigits)) {
-          if ((uint32_t)i < kKeyWeight + d && seed_len) slot += digit3(c, ga) * wgt;
-          wgt /= 3;
+        if (i < 32) {
+          const bool take = in_seed && nb < Bd;
+          const uint32_t l = pcode_len(c, ga);
+          acc = take ? ((acc << l) | pcode_bits(c, ga)) : acc;
+          nb += take ? l : 0u;
         }
       }
+    }
+    uint32_t v_lo = 0, span = 0;
+    if (seed_len) {
+      if (nb >= Bd) { v_lo = (uint32_t)(acc >> (nb - Bd)); span = 1; }
+      else { v_lo = (uint32_t)(acc << (Bd - nb)); span = 1u << (Bd - nb); }
     }
     const uint64_t base = 1 + NW + s * kPerSeedWords;
 #pragma unroll
     for (uint32_t w = 0; w < kCareWords; ++w) packed[(base + w) * stride + r] = care[w];
-    packed[(base + kCareWords) * stride + r] = slot;
+    packed[(base + kCareWords) * stride + r] = seed_len ? (1u << Bd) - v_lo : 0u;
+    packed[(base + kCareWords + 1) * stride + r] = span;
   }
 }
 
-void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t D,
+void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t Bd,
                        uint32_t nw, uint32_t* d_packed, uint64_t stride, uint32_t* d_err, hipStream_t stream) {
   const dim3 g(grid_for(n)), b(kBlock);
   switch (nw) {
-    case 8: hipLaunchKernelGGL(k_pack_reads<8>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
-    case 16: hipLaunchKernelGGL(k_pack_reads<16>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
-    case 32: hipLaunchKernelGGL(k_pack_reads<32>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
-    default: hipLaunchKernelGGL(k_pack_reads<64>, g, b, 0, stream, d_bases, d_offsets, n, ga, D, d_packed, stride, d_err); break;
+    case 8: hipLaunchKernelGGL(k_pack_reads<8>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
+    case 16: hipLaunchKernelGGL(k_pack_reads<16>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
+    case 32: hipLaunchKernelGGL(k_pack_reads<32>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
+    default: hipLaunchKernelGGL(k_pack_reads<64>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
   }
 }
 
@@ -242,17 +249,18 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
 #pragma unroll
         for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
-        uint32_t slot = packed[(fbase + kCareWords) * stride + r];
+        const uint32_t slot = packed[(fbase + kCareWords) * stride + r];
+        const uint32_t span = packed[(fbase + kCareWords + 1) * stride + r];
         if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
           defer_iter = fi * 3 + seed_i;
         } else if (ablate & 4u) {                       // diagnostic: no lookup at all
         } else if (ablate & 2u) {                       // diagnostic: directory only
-          uint32_t lo = sv.dir[slot], hi = sv.dir[slot + 1];
+          uint32_t lo = sv.dir[slot], hi = sv.dir[slot - span];
           if (lo > hi) lk.reg.l = 0;
         } else {
-          seed_lookup_ex(iv, sv, care, slot, lr.repeats, lk, !LITERAL);
+          seed_lookup_ex(iv, sv, care, slot, span, lr.repeats, lk, !LITERAL);
         }
       }
       const Region reg = lk.reg;
@@ -512,7 +520,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
   launch_pack_reads(reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
-                    (uint32_t)(ag ? 1 : 0), idx->view.dir_digits, (uint32_t)nw, packed, stride, err, stream);
+                    (uint32_t)(ag ? 1 : 0), idx->view.dir_bits, (uint32_t)nw, packed, stride, err, stream);
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[1], stream));
   BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
   unsigned long long* stats = shards;
