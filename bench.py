@@ -236,6 +236,14 @@ def main():
     st = wdist.allreduce_stats(wdist.se_stats_vector(times, too_short))
     total, uniq, amb, unm, short = [int(v) for v in st.tolist()]
 
+    if os.environ.get("WALT_AMD_STAMPS"):
+        buf = (ctypes.c_ulonglong * 16)()
+        if walt_amd.lib().walt_profile_stamps(buf) == 0:
+            tot = float(buf[8]) or 1.0
+            names = ["read record", "care loads", "bloom/bad", "lookup", "masks", "own-lane verify", "coop regions",
+                     "store", "total"]
+            log("phase shares (s_memtime, drained at boundaries): " +
+                ", ".join("%s %.1f%%" % (nm, 100.0 * buf[i] / tot) for i, nm in enumerate(names[:8])))
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * n * args.steps / elapsed
     if rank == 0:

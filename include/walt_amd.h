@@ -186,6 +186,9 @@ int walt_index_write(const walt_index* idx, const char* dbindex_path);
  * the last call's events and returns the two durations in milliseconds. */
 int walt_profile_enable(walt_index* idx, int on);
 int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms);
+/* Diagnostic (environment WALT_AMD_STAMPS=1): in-kernel s_memtime sums per phase of
+ * the single-end mapping kernel, cycles summed over waves; reading clears them. */
+int walt_profile_stamps(unsigned long long* out16);
 
 #ifdef __cplusplus
 }

@@ -278,6 +278,34 @@ WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t h) {
 constexpr uint32_t kScan = 6;
 constexpr uint32_t kLookupPos = 4;  // == kSmallRegion of the kernels
 
+// equal range [a,u] of masked key T among the sorted entries [lo,hi) by binary
+// search (slots longer than kScan); false when T is not present
+WALT_HD bool slot_binary_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a,
+                                uint32_t& u) {
+  uint32_t x = lo, y = hi;
+  while (x < y) {  // lower bound
+    uint32_t mid = x + ((y - x) >> 1);
+    if ((ent_key(sv.ent[mid]) & M) < T) x = mid + 1; else y = mid;
+  }
+  a = x;
+  if (a == hi || (ent_key(sv.ent[a]) & M) != T) return false;
+  u = a;
+  uint32_t probe = 0;  // upper end: short linear probe, then binary search
+  while (u + 1 < hi && probe < 4) {
+    if ((ent_key(sv.ent[u + 1]) & M) != T) break;
+    ++u; ++probe;
+  }
+  if (probe == 4 && u + 1 < hi) {
+    x = u + 1; y = hi;  // first index in [x,y) with masked key > T
+    while (x < y) {
+      uint32_t mid = x + ((y - x) >> 1);
+      if ((ent_key(sv.ent[mid]) & M) <= T) x = mid + 1; else y = mid;
+    }
+    u = x - 1;
+  }
+  return true;
+}
+
 struct Lookup {
   Region reg;
   uint32_t npos;              // pos[0..npos) are the genome positions of slots reg.l, reg.l+1, ...
@@ -339,29 +367,7 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
       out.pos[i] = p;
     }
   } else {
-    // lower bound of T among masked keys in [lo, hi)
-    uint32_t x = lo, y = hi;
-    while (x < y) {
-      uint32_t mid = x + ((y - x) >> 1);
-      if ((ent_key(sv.ent[mid]) & M) < T) x = mid + 1; else y = mid;
-    }
-    a = x;
-    if (a == hi || (ent_key(sv.ent[a]) & M) != T) return;
-    // upper end: short linear probe, then binary search
-    u = a;
-    uint32_t probe = 0;
-    while (u + 1 < hi && probe < 4) {
-      if ((ent_key(sv.ent[u + 1]) & M) != T) break;
-      ++u; ++probe;
-    }
-    if (probe == 4 && u + 1 < hi) {
-      x = u + 1; y = hi;  // first index in [x,y) with masked key > T
-      while (x < y) {
-        uint32_t mid = x + ((y - x) >> 1);
-        if ((ent_key(sv.ent[mid]) & M) <= T) x = mid + 1; else y = mid;
-      }
-      u = x - 1;
-    }
+    if (!slot_binary_search(sv, lo, hi, T, M, a, u)) return;
   }
   if (n > kKeyChars) {
     out.npos = 0;

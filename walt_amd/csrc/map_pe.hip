@@ -163,8 +163,14 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
   __shared__ BlockShared sh;
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   uint32_t n_probe = 0, n_verified = 0, n_big = 0, shortv = 0;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t r64 = base + threadIdx.x;
+  // each block walks its own contiguous slice of the batch (consecutive 256-read
+  // chunks share pages: a strided assignment made every load a TLB miss)
+  const uint64_t chunks = ((uint64_t)n + blockDim.x - 1) / blockDim.x;
+  const uint64_t per_block = (chunks + gridDim.x - 1) / gridDim.x;
+  const uint64_t c_lo = (uint64_t)blockIdx.x * per_block;
+  const uint64_t c_hi = c_lo + per_block < chunks ? c_lo + per_block : chunks;
+  for (uint64_t c = c_lo; c < c_hi; ++c) {
+    const uint64_t r64 = c * blockDim.x + threadIdx.x;
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;

@@ -205,6 +205,41 @@ __device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const
   return acc;
 }
 
+// In-kernel phase timing (diagnostic, WALT_AMD_STAMPS=1): s_memtime at phase
+// boundaries with every outstanding memory operation drained first, summed per
+// wave and added to a device buffer.  The stamped run is slower (no overlap across
+// phases); read its SHARES, not its length.  Phases: 0 read record, 1 care/slot
+// loads, 2 bloom/bad test, 3 lookup (dir + entries), 4 masks, 5 own-lane verify,
+// 6 wave-cooperative regions, 7 store, 8 total.
+constexpr int kStampPhases = 9;
+struct Stamps {
+  unsigned long long* buf;  // nullptr = disabled
+  unsigned long long last;
+  unsigned long long acc[kStampPhases];
+};
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+__device__ __forceinline__ void stamp_begin(Stamps& st, unsigned long long* buf) {
+  st.buf = buf;
+  for (int i = 0; i < kStampPhases; ++i) st.acc[i] = 0;
+  st.last = buf ? stamp_now() : 0;
+}
+__device__ __forceinline__ void stamp(Stamps& st, int phase) {
+  if (st.buf) {
+    const unsigned long long t = stamp_now();
+    st.acc[phase] += t - st.last;
+    st.acc[8] += t - st.last;
+    st.last = t;
+  }
+}
+__device__ __forceinline__ void stamp_end(Stamps& st) {
+  if (st.buf && (threadIdx.x & 63) == 0)
+    for (int i = 0; i < kStampPhases; ++i) atomicAdd(&st.buf[i], st.acc[i]);
+}
+
 // Work for one read per lane.  LITERAL = false (pass 1): a lane whose probe
 // lands in a BAD bucket (literal LowerBound/UpperBound search, ~100x the
 // dependent loads of the key search) stops and appends its read to the deferred
@@ -220,7 +255,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
                                            uint32_t* __restrict__ defer_list, MapCounters& ctr, uint32_t& len_out,
-                                           uint32_t ablate = 0) {
+                                           uint32_t ablate, Stamps& st) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
   LaneRead<NW> lr;
@@ -229,6 +264,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
   uint32_t defer_iter = 0;
+  stamp(st, 0);
 
   BestMatch best;  // mapping.cpp:486
   best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
@@ -244,24 +280,34 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
       Lookup lk;
       lk.npos = 0;
       lk.reg = empty_region();
-      if (act) {
-        uint32_t care[kCareWords];
-        const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
+      {
+        uint32_t care[kCareWords] = {0, 0, 0, 0};
+        uint32_t slot = 0, span = 0;
+        if (act) {
+          const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
 #pragma unroll
-        for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
-        const uint32_t slot = packed[(fbase + kCareWords) * stride + r];
-        const uint32_t span = packed[(fbase + kCareWords + 1) * stride + r];
-        if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
-          deferred = true;
-          mappable = false;
-          defer_iter = fi * 3 + seed_i;
-        } else if (ablate & 4u) {                       // diagnostic: no lookup at all
-        } else if (ablate & 2u) {                       // diagnostic: directory only
-          uint32_t lo = sv.dir[slot], hi = sv.dir[slot - span];
-          if (lo > hi) lk.reg.l = 0;
-        } else {
-          seed_lookup_ex(iv, sv, care, slot, span, lr.repeats, lk, !LITERAL);
+          for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
+          slot = packed[(fbase + kCareWords) * stride + r];
+          span = packed[(fbase + kCareWords + 1) * stride + r];
         }
+        stamp(st, 1);
+        bool is_bad = false;
+        if (act && !LITERAL) is_bad = bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8);
+        stamp(st, 2);
+        if (act) {
+          if (is_bad) {
+            deferred = true;
+            mappable = false;
+            defer_iter = fi * 3 + seed_i;
+          } else if (ablate & 4u) {                       // diagnostic: no lookup at all
+          } else if (ablate & 2u) {                       // diagnostic: directory only
+            uint32_t lo = sv.dir[slot], hi = sv.dir[slot - span];
+            if (lo > hi) lk.reg.l = 0;
+          } else {
+            seed_lookup_ex(iv, sv, care, slot, span, lr.repeats, lk, !LITERAL);
+          }
+        }
+        stamp(st, 3);
       }
       const Region reg = lk.reg;
       uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
@@ -270,6 +316,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
       if (ablate & 1u) size = 0;                        // diagnostic: no verification
       uint32_t mk[NW];
       make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
+      stamp(st, 4);
 
       // small regions: the owning lane walks its own candidates in order
       if (size && size <= kSmallRegion) {
@@ -286,6 +333,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         }
         fold_region(best, sum, strand_char);
       }
+      stamp(st, 5);
       // large regions: the whole wave verifies one owner's region at a time
       unsigned long long big = __ballot(size > kSmallRegion);
       while (big) {
@@ -306,6 +354,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
           ++ctr.big;
         }
       }
+      stamp(st, 6);
     }
   }
   if (!LITERAL && deferred) {
@@ -313,6 +362,242 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
   } else if (valid) {
     out[r] = best;
   }
+  stamp(st, 7);
+}
+
+// ---------------------------------------------------------------------------
+// Pass 1, seed-major: for each seed shift the '+' and '-' strand probes of a read
+// are issued TOGETHER (directory loads of both strands, then both slots' entries,
+// then both genome windows), because the kernel is bound by dependent round trips
+// (Little's law: ~330 k lanes in flight / ~19 dependent trips per read), not by
+// instruction issue.  The reference order is strand-major (+s0 +s1 +s2 -s0 -s1 -s2,
+// mapping.cpp:491-499, 248-263) and its early exits depend on the running best, so:
+//   * '+' summaries are folded immediately (their need is known exactly);
+//   * a '-' probe is computed when it MIGHT be needed (best so far, including the
+//     '-' summaries already seen, has not reached the exit value) -- a superset of
+//     the reference's probes -- and its RegionSummary is kept;
+//   * after seed 2 the '-' summaries are folded in order under the exact exit
+//     conditions.  A RegionSummary does not depend on the running best (the
+//     reference's mismatch-loop cut-off only truncates counts that lose anyway),
+//     so the result is identical; unused speculative probes are only extra work.
+// A lane whose probe lands in a BAD bucket is deferred to the literal pass.
+// ---------------------------------------------------------------------------
+struct SlotProbe {
+  uint32_t lo, ne;      // slot range [lo, lo+ne) of the directory lookup (ne == 0: nothing)
+  Ent e[kScan];         // its first entries (clamped indices, independent loads)
+};
+
+__device__ __forceinline__ void probe_issue(const StrandView& sv, bool need, uint32_t slot, uint32_t span,
+                                            uint32_t& lo, uint32_t& hi) {
+  const uint32_t s0 = need ? slot : 0u, sp = need ? span : 0u;
+  lo = sv.dir[s0];
+  hi = sv.dir[s0 - sp];
+}
+__device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p) {
+#pragma unroll
+  for (uint32_t j = 0; j < kScan; ++j) {
+    const uint32_t k = p.ne ? p.lo + (j < p.ne ? j : p.ne - 1) : 0u;  // ent[] has index_size + 1 slots
+    p.e[j] = sv.ent[k];
+  }
+}
+// region + leading candidate positions from a probed slot (core.h seed_lookup_ex, scan branch)
+__device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotProbe& p, const uint32_t* care,
+                                              uint32_t seed_len, Lookup& out) {
+  out.npos = 0;
+  out.reg = empty_region();
+  if (p.ne == 0) return;
+  const uint32_t n = seed_len - kKeyWeight;
+  const uint32_t nk = n < kKeyChars ? n : kKeyChars;
+  const uint64_t M = key_mask(nk);
+  const uint64_t T = target_key(care) & M;
+  uint32_t a, u;
+  if (p.ne <= kScan) {
+    uint32_t n_lt = 0, n_eq = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScan; ++j) {
+      const uint64_t k = ent_key(p.e[j]) & M;
+      n_lt += (j < p.ne && k < T) ? 1u : 0u;
+      n_eq += (j < p.ne && k == T) ? 1u : 0u;
+    }
+    if (n_eq == 0) return;
+    a = p.lo + n_lt;
+    u = a + n_eq - 1;
+    out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
+#pragma unroll
+    for (uint32_t i = 0; i < kLookupPos; ++i) {
+      uint32_t q = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < kScan; ++j) q = (n_lt + i == j) ? p.e[j].pos : q;
+      out.pos[i] = q;
+    }
+  } else {
+    if (!slot_binary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
+  }
+  if (n > kKeyChars) {
+    out.npos = 0;
+    out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+    return;
+  }
+  out.reg.l = a; out.reg.u = u;
+}
+
+// branch-free candidate check: the genome window is always loaded (from position
+// 0 when the edge filters of mapping.cpp:280-286 reject the candidate)
+template <int NW>
+__device__ __forceinline__ void verify_nobranch(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
+                                                bool active, uint32_t slot_pos, uint32_t seed_i, uint32_t len,
+                                                const uint32_t* rd, const uint32_t* mk, bool& ok, uint32_t& gp,
+                                                uint32_t& mm) {
+  const uint32_t chr = chrom_id(si, n_chrom, slot_pos);
+  const uint32_t g = slot_pos - seed_i;
+  ok = active && (slot_pos - si[chr] >= seed_i) && (g + len < si[chr + 1]);
+  gp = ok ? g : 0u;
+  mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
+}
+
+template <int NW>
+__device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si,
+                                                const uint32_t* __restrict__ packed, uint64_t stride, uint32_t r,
+                                                bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
+                                                BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
+                                                uint32_t* __restrict__ defer_list, MapCounters& ctr,
+                                                uint32_t& len_out, uint32_t ablate, Stamps& st) {
+  const uint32_t n_chrom = iv.n_chrom;
+  const uint32_t lane = threadIdx.x & 63;
+  const StrandView& svp = iv.s[strand_base];
+  const StrandView& svm = iv.s[strand_base + 1];
+  LaneRead<NW> lr;
+  load_lane_read<NW>(lr, packed, stride, r, valid);
+  len_out = lr.len;
+  bool mappable = valid && lr.len >= kMinReadLen;
+  bool deferred = false;
+  uint32_t defer_iter = 0;
+  stamp(st, 0);
+
+  BestMatch best;  // mapping.cpp:486
+  best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
+  RegionSummary m0 = summary_empty(), m1 = summary_empty(), m2 = summary_empty();  // '-' strand, per seed
+  uint32_t minus_lb = 0xFFFFFFFFu;  // smallest mismatch count any kept '-' summary holds
+
+#pragma unroll 1
+  for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+    // '+': exact (mapping.cpp:250-257 with the state after the '+' folds so far)
+    bool need_p = mappable && (seed_i == 0 || (seed_i == 1 ? best.mismatch != 0 : best.mismatch > 1));
+    // '-': superset of the reference's decision (see header comment)
+    const uint32_t lb = best.mismatch < minus_lb ? best.mismatch : minus_lb;
+    bool need_m = mappable && (seed_i == 0 || (seed_i == 1 ? lb != 0 : lb > 1));
+    if (ablate & 4u) need_p = need_m = false;
+
+    uint32_t care[kCareWords] = {0, 0, 0, 0};
+    uint32_t slot = 0, span = 0;
+    if (need_p || need_m) {
+      const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
+#pragma unroll
+      for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
+      slot = packed[(fbase + kCareWords) * stride + r];
+      span = packed[(fbase + kCareWords + 1) * stride + r];
+    }
+    stamp(st, 1);
+    const uint32_t h = care[0] >> 8;
+    const bool bad_p = need_p && bloom_maybe(sh.bloom[0], h) && bucket_is_bad(svp, h);
+    const bool bad_m = need_m && bloom_maybe(sh.bloom[1], h) && bucket_is_bad(svm, h);
+    if (bad_p || bad_m) {
+      deferred = true;
+      mappable = false;
+      need_p = need_m = false;
+      defer_iter = seed_i + (bad_p ? 0u : 3u);
+    }
+    stamp(st, 2);
+
+    // directory pairs of both strands, then both slots' entries: independent loads
+    SlotProbe pp, pm;
+    uint32_t hi_p, hi_m;
+    probe_issue(svp, need_p, slot, span, pp.lo, hi_p);
+    probe_issue(svm, need_m, slot, span, pm.lo, hi_m);
+    pp.ne = (need_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
+    pm.ne = (need_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
+    if (ablate & 2u) pp.ne = pm.ne = 0;
+    probe_entries(svp, pp);
+    probe_entries(svm, pm);
+    Lookup lp, lm;
+    probe_resolve(svp, pp, care, lr.repeats, lp);
+    probe_resolve(svm, pm, care, lr.repeats, lm);
+    stamp(st, 3);
+
+    uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
+    uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
+    ctr.probes += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
+    if (size_p > b) size_p = 0;  // mapping.cpp:275-277
+    if (size_m > b) size_m = 0;
+    if (ablate & 1u) size_p = size_m = 0;
+    uint32_t mk[NW];
+    make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
+    stamp(st, 4);
+
+    // small regions: candidate k of both strands checked side by side
+    RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
+    const bool small_p = size_p && size_p <= kSmallRegion, small_m = size_m && size_m <= kSmallRegion;
+    if (small_p || small_m) {
+#pragma unroll
+      for (uint32_t k = 0; k < kSmallRegion; ++k) {
+        const bool act_p = small_p && k < size_p, act_m = small_m && k < size_m;
+        if (act_p || act_m) {
+          uint32_t pos_p = 0, pos_m = 0;
+          if (act_p) pos_p = k < lp.npos ? lp.pos[k] : svp.ent[lp.reg.l + k].pos;
+          if (act_m) pos_m = k < lm.npos ? lm.pos[k] : svm.ent[lm.reg.l + k].pos;
+          bool ok_p, ok_m;
+          uint32_t gp_p, gp_m, mm_p, mm_m;
+          verify_nobranch<NW>(svp, si, n_chrom, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+          verify_nobranch<NW>(svm, si, n_chrom, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+          if (ok_p) { sum_p = summary_merge(sum_p, summary_one(mm_p, gp_p)); ++ctr.verified; }
+          if (ok_m) { sum_m = summary_merge(sum_m, summary_one(mm_m, gp_m)); ++ctr.verified; }
+        }
+      }
+    }
+    stamp(st, 5);
+    // large regions: the whole wave verifies one owner's region at a time ('+' then '-')
+#pragma unroll 1
+    for (uint32_t fi = 0; fi < 2; ++fi) {
+      const StrandView& sv = fi ? svm : svp;
+      const uint32_t my_size = fi ? size_m : size_p;
+      const uint32_t my_l = fi ? lm.reg.l : lp.reg.l;
+      unsigned long long big = __ballot(my_size > kSmallRegion);
+      while (big) {
+        const int owner = (int)__ffsll((long long)big) - 1;
+        big &= big - 1;
+        uint32_t o_rd[NW], o_mk[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          o_rd[w] = bcast(lr.rd[w], owner);
+          o_mk[w] = bcast(mk[w], owner);
+        }
+        const uint32_t o_l = bcast(my_l, owner), o_size = bcast(my_size, owner), o_len = bcast(lr.len, owner);
+        uint32_t nv = 0;
+        RegionSummary s = coop_region<NW>(sv, si, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv);
+        ctr.verified += nv;
+        if ((int)lane == owner) {
+          if (fi) sum_m = s; else sum_p = s;
+          ++ctr.big;
+        }
+      }
+    }
+    stamp(st, 6);
+    fold_region(best, sum_p, '+');  // empty when the '+' probe was not needed
+    if (seed_i == 0) m0 = sum_m; else if (seed_i == 1) m1 = sum_m; else m2 = sum_m;
+    if (sum_m.count && sum_m.min_mm < minus_lb) minus_lb = sum_m.min_mm;
+  }
+  // '-' strand folds in reference order under the exact exit conditions
+  fold_region(best, m0, '-');
+  if (best.mismatch != 0) {
+    fold_region(best, m1, '-');
+    if (best.mismatch > 1) fold_region(best, m2, '-');
+  }
+  if (deferred) {
+    defer_list[atomicAdd(defer_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
+  } else if (valid) {
+    out[r] = best;
+  }
+  stamp(st, 7);
 }
 
 __device__ __forceinline__ void flush_counters(const MapCounters& ctr, uint32_t shortv,
@@ -414,30 +699,40 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 
 // pass 1: every read of the batch, one per lane
 template <int NW>
-__global__ __launch_bounds__(kBlock, (NW <= 8 ? 5 : 1)) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
                                                     uint64_t stride, uint32_t n, uint32_t strand_base,
                                                     uint32_t max_mm, uint32_t b,
                                                     const uint32_t* __restrict__ mask_table,
                                                     BestMatch* __restrict__ out,
                                                     unsigned long long* __restrict__ stats,
                                                     uint32_t* __restrict__ defer_count,
-                                                    uint32_t* __restrict__ defer_list, uint32_t ablate) {
+                                                    uint32_t* __restrict__ defer_list, uint32_t ablate,
+                                                    unsigned long long* __restrict__ stamps) {
   __shared__ BlockShared sh;
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   // persistent blocks: the LDS prologue (mask table, chromosome starts, Bloom
   // filters: ~25 KB) is paid once per block, not once per 256 reads
   MapCounters ctr = {0, 0, 0};
   uint32_t shortv = 0;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t r64 = base + threadIdx.x;
+  Stamps st;
+  stamp_begin(st, stamps);
+  // each block walks its own contiguous slice of the batch (consecutive 256-read
+  // chunks share pages: a strided assignment made every load a TLB miss)
+  const uint64_t chunks = ((uint64_t)n + blockDim.x - 1) / blockDim.x;
+  const uint64_t per_block = (chunks + gridDim.x - 1) / gridDim.x;
+  const uint64_t c_lo = (uint64_t)blockIdx.x * per_block;
+  const uint64_t c_hi = c_lo + per_block < chunks ? c_lo + per_block : chunks;
+  for (uint64_t c = c_lo; c < c_hi; ++c) {
+    const uint64_t r64 = c * blockDim.x + threadIdx.x;
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    se_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, defer_count,
-                          defer_list, ctr, len, ablate);
+    se_process_dual<NW>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, defer_count,
+                        defer_list, ctr, len, ablate, st);
     // too_short is counted once per strand pass (mapping.cpp:230-233)
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
+  stamp_end(st);
   flush_counters(ctr, shortv, stats);
 }
 
@@ -459,8 +754,10 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
     const bool valid = i < count;
     const uint32_t r = valid ? defer_list[i] : 0;
     uint32_t len;
+    Stamps st;
+    st.buf = nullptr;
     se_process<NW, true>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, nullptr, nullptr, ctr,
-                         len);
+                         len, 0u, st);
   }
   flush_counters(ctr, 0, stats);
 }
@@ -476,6 +773,7 @@ uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 // it is set): bit 0 skips verification, bit 1 stops after the directory lookup,
 // bit 2 skips the lookup.  Used to attribute HBM requests to the phases.
 static uint32_t g_ablate = 0;
+static unsigned long long* g_stamps = nullptr;  // WALT_AMD_STAMPS=1: device buffer of kStampPhases sums (diagnostic)
 constexpr unsigned kLiteralGrid = 1024;  // blocks of the deferred-read pass (grid-stride)
 
 template <int NW>
@@ -483,9 +781,11 @@ static void launch_map_se(const walt_index* idx, const uint32_t* packed, uint64_
                           uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                           unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
                           hipStream_t stream) {
-  const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
+  unsigned pg = kPersistentGrid;
+  if (const char* e = getenv("WALT_AMD_GRID")) pg = atoi(e) > 0 ? (unsigned)atoi(e) : grid_for(n);  // diagnostic knob
+  const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
   hipLaunchKernelGGL(k_map_se<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate);
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate, g_stamps);
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
@@ -506,6 +806,10 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
     const char* ab = getenv("WALT_AMD_ABLATE");
     g_ablate = ab ? (uint32_t)atoi(ab) : 0u;
     if (g_ablate) fprintf(stderr, "[walt_amd] WALT_AMD_ABLATE=%u: DIAGNOSTIC RUN, mapping results are not valid\n", g_ablate);
+    if (getenv("WALT_AMD_STAMPS") && !g_stamps) {
+      hipMalloc(reinterpret_cast<void**>(&g_stamps), 16 * sizeof(unsigned long long));
+      hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long));
+    }
   }
   const int nw = nw_for_len(max_read_len);
   if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
@@ -563,6 +867,15 @@ int walt_profile_enable(walt_index* idx, int on) {
     for (int i = 0; i < 3; ++i) WALT_HIP(hipEventCreate(&idx->ev[i]));
   idx->profile = on != 0;
   idx->ev_valid = false;
+  return WALT_OK;
+}
+
+// diagnostic: read and clear the WALT_AMD_STAMPS phase sums (cycles summed over waves)
+int walt_profile_stamps(unsigned long long* out16) {
+  if (!g_stamps) return fail(WALT_EINVAL, "WALT_AMD_STAMPS is not enabled");
+  WALT_HIP(hipDeviceSynchronize());
+  WALT_HIP(hipMemcpy(out16, g_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  WALT_HIP(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
   return WALT_OK;
 }
 
