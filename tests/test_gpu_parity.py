@@ -192,38 +192,3 @@ def test_gpu_device_pointer_api_with_torch(wa, g1_db, g1_dev):
     want, work = refio.oracle_se(g1_db, seqs)
     assert_best_equal(got, want, "device api")
     assert int(d_stats[0]) == int(work["too_short"])
-
-
-def test_gpu_packed_records_equal_specification(wa, g1_dev):
-    """The device packing kernel writes exactly the records index_core.h pack_read()
-    defines (checked for both conversions and all word widths)."""
-    import random
-    import torch
-    idx = g1_dev[27]
-    rng = random.Random(3)
-    dev = torch.device("cuda:0")
-    for max_len in (100, 128, 150, 256, 400, 1000):
-        reads = ["".join(rng.choice("ACGT") for _ in range(rng.choice([max_len, max_len, rng.randrange(1, max_len + 1)])))
-                 for _ in range(777)]
-        reads[5] = "A" * max_len
-        bases, offsets = wa.pack_reads(reads)
-        n = len(reads)
-        nw = 8 if max_len <= 128 else 16 if max_len <= 256 else 32 if max_len <= 512 else 64
-        fields = 1 + nw + 18
-        stride = (n + 63) // 64 * 64
-        for ag in (False, True):
-            d_bases = torch.from_numpy(bases).to(dev)
-            d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
-            d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-            d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
-            d_ws = torch.zeros(wa.lib().walt_se_workspace_bytes(n, max_len), dtype=torch.uint8, device=dev)
-            idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, max_len, d_out.data_ptr(),
-                                    d_stats.data_ptr(), d_ws.data_ptr(), ag_wildcard=ag)
-            torch.cuda.synchronize()
-            got = d_ws.cpu().numpy().view(np.uint32)[64 + 8192:64 + 8192 + fields * stride].reshape(fields, stride)[:, :n]
-            want = np.zeros((fields, stride), dtype=np.uint32)
-            hb = np.concatenate([bases, np.zeros(1, np.uint8)])
-            bad = refio.harness().hh_pack(hb.ctypes.data, offsets.ctypes.data, n, int(ag), idx.dir_bits, nw,
-                                          want.ctypes.data, stride)
-            assert bad == 0
-            assert np.array_equal(got, want[:, :n]), (max_len, ag)

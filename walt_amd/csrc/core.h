@@ -253,10 +253,10 @@ WALT_HD bool bucket_is_bad(const StrandView& sv, uint32_t h) { return (sv.bad[h 
 // traffic, so every probe's bitmap read became an HBM-side request.  BAD
 // buckets are rare (a few per chromosome end), so the kernels test a small
 // Bloom filter held in LDS first and read the bitmap only on a filter hit.
-constexpr uint32_t kBloomBits = 1u << 16;
+constexpr uint32_t kBloomBits = 1u << 14;  // 2 KB of LDS per strand
 constexpr uint32_t kBloomWords = kBloomBits / 32;
-WALT_HD uint32_t bloom_h1(uint32_t h) { return (h * 0x9E3779B1u) >> 16; }
-WALT_HD uint32_t bloom_h2(uint32_t h) { return (h * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 16; }
+WALT_HD uint32_t bloom_h1(uint32_t h) { return (h * 0x9E3779B1u) >> 18; }
+WALT_HD uint32_t bloom_h2(uint32_t h) { return (h * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 18; }
 WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t h) {
   const uint32_t a = bloom_h1(h), b = bloom_h2(h);
   return ((bloom[a >> 5] >> (a & 31)) & (bloom[b >> 5] >> (b & 31)) & 1u) != 0;

@@ -36,6 +36,23 @@ __device__ __forceinline__ const uint32_t* block_prologue(BlockShared& sh, const
   return fits ? sh.start_index : iv.start_index;
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint32_t o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {  // lane is wave-uniform
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
 template <int NW>
 struct LaneRead {
   uint32_t len;
@@ -43,13 +60,175 @@ struct LaneRead {
   uint32_t rd[NW];
 };
 
+// ---------------------------------------------------------------------------
+// Read front-end, fused into the mapping kernels (no packed-read arrays in HBM):
+// each WAVE stages the contiguous ASCII bytes of its 64 reads as a dense 2-bit
+// array in its own slice of LDS (coalesced 16-byte loads, no block barrier), each
+// lane cuts its read out with funnel shifts and converts C->T / G->A by a bit
+// trick (mapping.cpp:142-164).  The care string of a seed shift and its directory
+// range are computed in registers (seed_query) -- the record index_core.h
+// pack_read() specifies, without the memory round trip.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t convert_word(uint32_t x, uint32_t ga) {
+  const uint32_t lo = x & 0x55555555u;
+  // C->T: 01 -> 11 (hi |= lo).  G->A: 10 -> 00 (hi &= lo).
+  return ga ? (x & (0x55555555u | (lo << 1))) : (x | (lo << 1));
+}
+
+// dynamic LDS: per wave [codes: win_words + 2][inval: win_words + 2]
+__device__ __forceinline__ uint32_t stage_words_per_wave(uint32_t win_words) { return 2 * (win_words + 2); }
+inline uint32_t stage_win_words(uint32_t max_read_len) { return (64 * max_read_len + 16 + 15) / 16; }
+inline size_t stage_lds_bytes(uint32_t max_read_len) {
+  return (size_t)(kBlock / 64) * 2 * (stage_win_words(max_read_len) + 2) * sizeof(uint32_t);
+}
+
+// slow path: a lane packs its own read straight from HBM (literal pass, odd layouts)
 template <int NW>
-__device__ __forceinline__ void load_lane_read(LaneRead<NW>& lr, const uint32_t* __restrict__ packed,
-                                               uint64_t stride, uint32_t r, bool valid) {
-  lr.len = valid ? packed[r] : 0;
-  lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
+__device__ __forceinline__ void lane_read_global(LaneRead<NW>& lr, const uint8_t* __restrict__ bases, uint64_t o,
+                                                 uint32_t len, uint32_t ga, uint32_t* __restrict__ err) {
+  bool bad = false;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) lr.rd[w] = valid ? packed[(uint64_t)(1 + w) * stride + r] : 0;
+  for (int w = 0; w < NW; ++w) {  // static w: rd[] stays in registers
+    uint32_t v = 0;
+    if (16u * w < len) {
+#pragma unroll 1
+      for (uint32_t k = 0; k < 16 && 16u * w + k < len; ++k) {
+        uint32_t c = base_code(bases[o + 16u * w + k]);
+        if (c > 3) { bad = true; c = 0; }
+        v |= c << (2 * k);
+      }
+    }
+    lr.rd[w] = convert_word(v, ga);
+  }
+  if (bad) atomicAdd(err, 1u);
+}
+
+// Stage this wave's reads [r, r + 63] and fill lr.  `valid` lanes have r < n.
+template <int NW>
+__device__ __forceinline__ void wave_load_reads(LaneRead<NW>& lr, const uint8_t* __restrict__ bases,
+                                                const uint64_t* __restrict__ offsets, uint32_t r, bool valid,
+                                                uint32_t ga, uint32_t* lds_wave, uint32_t win_words,
+                                                uint32_t* __restrict__ err) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t o = 0, oe = 0;
+  if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
+  uint64_t len64 = oe - o;
+  if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
+  lr.len = (uint32_t)len64;
+  lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
+  // wave-uniform window [a0, o1): first valid lane's start .. last valid lane's end
+  const unsigned long long vm = __ballot(valid);
+  if (vm == 0) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) lr.rd[w] = 0;
+    return;
+  }
+  const int last = 63 - (int)__clzll((long long)vm);
+  const uint64_t o0 = ((uint64_t)bcast((uint32_t)(o >> 32), 0) << 32) | bcast((uint32_t)o, 0);
+  const uint64_t o1 = ((uint64_t)bcast((uint32_t)(oe >> 32), last) << 32) | bcast((uint32_t)oe, last);
+  const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(bases) + o0) & 15);
+  const bool use_lds = mis <= o0 && (o1 - (o0 - mis)) <= 16ull * win_words;
+  if (!use_lds) {
+    if (valid) lane_read_global<NW>(lr, bases, o, lr.len, ga, err);
+    else {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) lr.rd[w] = 0;
+    }
+    return;
+  }
+  const uint64_t a0 = o0 - mis;
+  const uint32_t span = (uint32_t)(o1 - a0);
+  const uint32_t nwin = (span + 15) / 16;
+  uint32_t* codes = lds_wave;
+  uint32_t* inval = lds_wave + win_words + 2;
+  for (uint32_t i = lane; i < nwin; i += 64) {
+    uint4 q;
+    if (16 * i + 16 <= span) {
+      q = *reinterpret_cast<const uint4*>(bases + a0 + 16 * (uint64_t)i);
+    } else {
+      uint32_t t[4] = {0, 0, 0, 0};
+      for (uint32_t k = 16 * i; k < span; ++k) t[(k & 15) >> 2] |= (uint32_t)bases[a0 + k] << (8 * (k & 3));
+      q = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    const uint32_t qs[4] = {q.x, q.y, q.z, q.w};
+    uint32_t c = 0, bad = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t code = base_code((uint8_t)(qs[j] >> (8 * k)));
+        c |= (code & 3u) << (2 * (4 * j + k));
+        bad |= (code > 3 ? 1u : 0u) << (4 * j + k);
+      }
+    }
+    codes[i] = c;
+    inval[i] = bad;
+  }
+  if (lane < 2) { codes[nwin + lane] = 0; inval[nwin + lane] = 0; }
+  // LDS writes of this wave -> reads by other lanes of the same wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const uint32_t off = valid ? (uint32_t)(o - a0) : 0u;
+  const uint32_t wi0 = off >> 4, sh = 2 * (off & 15);
+  uint32_t bad = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    uint32_t v = 0, ivb = 0;
+    if (16u * w < lr.len) {
+      v = funnel_r(codes[wi0 + w], codes[wi0 + w + 1], sh);
+      ivb = (inval[wi0 + w] >> (off & 15)) | (inval[wi0 + w + 1] << (16 - (off & 15)));
+      const uint32_t nb = lr.len - 16u * w;
+      if (nb < 16) { v &= (1u << (2 * nb)) - 1u; ivb &= (1u << nb) - 1u; }
+      ivb &= 0xFFFFu;
+    }
+    bad |= ivb;
+    lr.rd[w] = convert_word(v, ga);
+  }
+  if (bad) atomicAdd(err, 1u);
+  // the next staging of this wave must not overtake these reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Care string (chars at read offsets seed_i + 1 + 3 i, MSB first) of a seed shift
+// and its directory range, from the packed read in registers.
+template <int NW>
+__device__ __forceinline__ void seed_query(const uint32_t* rd, uint32_t seed_len, uint32_t seed_i, uint32_t ga,
+                                           uint32_t Bd, uint32_t* care, uint32_t& slot, uint32_t& span) {
+  constexpr int NS = NW < 10 ? NW : 10;  // 50 care chars reach base 3*49 + 3 = 150
+  uint32_t shd[NS];
+  const uint32_t sh = 2 * (seed_i + 1);
+#pragma unroll
+  for (int w = 0; w < NS; ++w) shd[w] = funnel_r(rd[w], w + 1 < NW ? rd[w + 1] : 0u, sh);
+  care[0] = care[1] = care[2] = care[3] = 0;
+  uint64_t acc = 0;
+  uint32_t nb = 0;
+#pragma unroll
+  for (int i = 0; i < (int)kMaxRepeats; ++i) {
+    constexpr int dummy = 0; (void)dummy;
+    const int q = 3 * i;  // compile-time offset in the shifted read
+    if ((q >> 4) < NS) {
+      uint32_t c = (shd[q >> 4] >> (2 * (q & 15))) & 3u;
+      const bool in_seed = (uint32_t)i < seed_len;
+      c = in_seed ? c : 0u;
+      care[i >> 4] |= c << (30 - 2 * (i & 15));
+      if (i < 32) {
+        const bool take = in_seed && nb < Bd;
+        const uint32_t l = pcode_len(c, ga);
+        acc = take ? ((acc << l) | pcode_bits(c, ga)) : acc;
+        nb += take ? l : 0u;
+      }
+    }
+  }
+  uint32_t v_lo = 0;
+  span = 0;
+  if (seed_len) {
+    if (nb >= Bd) { v_lo = (uint32_t)(acc >> (nb - Bd)); span = 1; }
+    else { v_lo = (uint32_t)(acc << (Bd - nb)); span = 1u << (Bd - nb); }
+  }
+  slot = seed_len ? (1u << Bd) - v_lo : 0u;
 }
 
 template <int NW>
@@ -74,23 +253,6 @@ __device__ __forceinline__ bool verify_candidate(const StrandView& sv, const uin
   gp_out = gp;
   mm_out = count_mismatch<NW>(sv.g2, gp, rd, mk);
   return true;
-}
-
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    uint32_t o = __shfl_xor(v, off);
-    v = o < v ? o : v;
-  }
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-__device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {  // lane is wave-uniform
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
 // Batch statistics.  Per-wave atomics on the four counters of walt_batch_stats
@@ -127,12 +289,7 @@ void launch_bin_deferred(uint32_t* d_ctl /*32 zeroed words: [0] = count*/, const
 
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream);
 
-// Packing: ASCII reads -> packed records (index_core.h pack_read).  Defined in
-// map_se.hip; err[0] counts reads with a non-ACGT base, err[1] reads longer
-// than 16*nw.
-void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t Bd,
-                       uint32_t nw, uint32_t* d_packed, uint64_t stride, uint32_t* d_err, hipStream_t stream);
-int check_pack_errors(const void* d_workspace, hipStream_t stream);
+int check_read_errors(const void* d_workspace, hipStream_t stream);
 
 }  // namespace walt
 #endif

@@ -28,7 +28,9 @@ constexpr uint32_t kPeChunk = 1u << 21;  // pairs processed per workspace pass
 // BAD bucket, pass 2 maps them from scratch (their heap restarts empty).
 template <int NW, bool LITERAL>
 __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
-                                           const uint32_t* __restrict__ packed, uint64_t stride, uint32_t r,
+                                           const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                           uint32_t* __restrict__ err, uint32_t* lds_wave, uint32_t win_words,
+                                           uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            uint32_t top_k, HeapEnt* __restrict__ heaps,
                                            uint32_t* __restrict__ heap_n, uint32_t* __restrict__ defer_count,
@@ -36,8 +38,17 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
                                            uint32_t& n_verified, uint32_t& n_big, uint32_t& len_out) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
+  const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
   LaneRead<NW> lr;
-  load_lane_read<NW>(lr, packed, stride, r, valid);
+  if (LITERAL) {
+    uint64_t o = 0, oe = 0;
+    if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
+    lr.len = (oe - o) > 16ull * NW ? 0u : (uint32_t)(oe - o);
+    lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
+    lane_read_global<NW>(lr, bases, o, lr.len, ga, err);
+  } else {
+    wave_load_reads<NW>(lr, bases, offsets, r, valid, ga, lds_wave, win_words, err);
+  }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
@@ -60,11 +71,8 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
       lk.reg = empty_region();
       if (act) {
         uint32_t care[kCareWords];
-        const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
-#pragma unroll
-        for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
-        const uint32_t slot = packed[(fbase + kCareWords) * stride + r];
-        const uint32_t span = packed[(fbase + kCareWords + 1) * stride + r];
+        uint32_t slot, span;
+        seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, care, slot, span);
         if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;
@@ -152,8 +160,10 @@ __device__ __forceinline__ void pe_flush(uint32_t shortv, uint32_t n_probe, uint
 }
 
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t* __restrict__ packed,
-                                                     uint64_t stride, uint32_t n, uint32_t strand_base,
+__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint8_t* __restrict__ bases,
+                                                     const uint64_t* __restrict__ offsets,
+                                                     uint32_t* __restrict__ err, uint32_t win_words, uint32_t n,
+                                                     uint32_t strand_base,
                                                      uint32_t max_mm, uint32_t b, uint32_t top_k,
                                                      const uint32_t* __restrict__ mask_table,
                                                      HeapEnt* __restrict__ heaps, uint32_t* __restrict__ heap_n,
@@ -161,6 +171,8 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
                                                      uint32_t* __restrict__ defer_count,
                                                      uint32_t* __restrict__ defer_list) {
   __shared__ BlockShared sh;
+  extern __shared__ uint32_t dyn_lds[];
+  uint32_t* lds_wave = dyn_lds + (threadIdx.x >> 6) * stage_words_per_wave(win_words);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   uint32_t n_probe = 0, n_verified = 0, n_big = 0, shortv = 0;
   // each block walks its own contiguous slice of the batch (consecutive 256-read
@@ -174,8 +186,8 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    pe_process<NW, false>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, top_k, heaps, heap_n,
-                          defer_count, defer_list, n_probe, n_verified, n_big, len);
+    pe_process<NW, false>(iv, sh, si, bases, offsets, err, lds_wave, win_words, r, valid, strand_base, max_mm, b,
+                          top_k, heaps, heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
     // paired.cpp:112-115: too_short once per strand pass
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
@@ -183,8 +195,10 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
 }
 
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const uint32_t* __restrict__ packed,
-                                                             uint64_t stride, uint32_t strand_base, uint32_t max_mm,
+__global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const uint8_t* __restrict__ bases,
+                                                             const uint64_t* __restrict__ offsets,
+                                                             uint32_t* __restrict__ err, uint32_t strand_base,
+                                                             uint32_t max_mm,
                                                              uint32_t b, uint32_t top_k,
                                                              const uint32_t* __restrict__ mask_table,
                                                              HeapEnt* __restrict__ heaps,
@@ -201,8 +215,8 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const 
     const bool valid = i < count;
     const uint32_t r = valid ? defer_list[i] : 0;
     uint32_t len;
-    pe_process<NW, true>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, top_k, heaps, heap_n,
-                         nullptr, nullptr, n_probe, n_verified, n_big, len);
+    pe_process<NW, true>(iv, sh, si, bases, offsets, err, nullptr, 0u, r, valid, strand_base, max_mm, b, top_k,
+                         heaps, heap_n, nullptr, nullptr, n_probe, n_verified, n_big, len);
   }
   pe_flush(0, n_probe, n_verified, n_big, stats);
 }
@@ -225,13 +239,14 @@ __global__ void k_pe_drain(HeapEnt* __restrict__ heaps, const uint32_t* __restri
 
 __global__ void k_pe_merge(IndexView iv, const Candidate* __restrict__ ranked1, const uint32_t* __restrict__ n1,
                            const Candidate* __restrict__ ranked2, const uint32_t* __restrict__ n2,
-                           const uint32_t* __restrict__ len1, const uint32_t* __restrict__ len2, uint32_t n,
+                           const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, uint32_t n,
                            uint32_t top_k, int frag_range, uint32_t max_mm, PairResult* __restrict__ out) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   PairResult pr;
-  pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r], len1[r], len2[r],
-             iv.start_index, iv.n_chrom, frag_range, max_mm, pr);
+  pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r],
+             (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), iv.start_index, iv.n_chrom,
+             frag_range, max_mm, pr);
   out[r] = pr;
 }
 
@@ -243,7 +258,6 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 struct PeWorkspace {
   uint32_t* err;
   unsigned long long* shards[2];
-  uint32_t* packed[2];
   HeapEnt* heaps[2];
   uint32_t* heap_n[2];
   uint32_t* defer_list[2];
@@ -264,7 +278,6 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
   w.stride = align_up(chunk ? chunk : 1, 64);
   w.err = reinterpret_cast<uint32_t*>(take(128 * sizeof(uint32_t)));  // [0..1] pack errors, [64 + 32 m ...] deferral control of mate m
   for (int m = 0; m < 2; ++m) w.shards[m] = reinterpret_cast<unsigned long long*>(take(kStatShardBytes));
-  for (int m = 0; m < 2; ++m) w.packed[m] = reinterpret_cast<uint32_t*>(take((uint64_t)packed_fields((uint32_t)nw) * w.stride * 4));
   for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
   for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
   for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take(2 * w.stride * 4 + 64));
@@ -274,23 +287,32 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
 }
 
 template <int NW>
-static void launch_pe_topk(const walt_index* idx, const uint32_t* packed, uint64_t stride, uint32_t n, uint32_t sb,
-                           uint32_t max_mm, uint32_t b, uint32_t top_k, HeapEnt* heaps, uint32_t* heap_n,
-                           unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
-                           hipStream_t stream) {
+static int launch_pe_topk(const walt_index* idx, const uint8_t* bases, const uint64_t* offsets, uint32_t* err,
+                          uint32_t max_read_len, uint64_t stride, uint32_t n, uint32_t sb,
+                          uint32_t max_mm, uint32_t b, uint32_t top_k, HeapEnt* heaps, uint32_t* heap_n,
+                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
+                          hipStream_t stream) {
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
-  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, packed, stride, n, sb,
-                     max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
+  const uint32_t win_words = stage_win_words(max_read_len);
+  const size_t lds = stage_lds_bytes(max_read_len);
+  if (lds + sizeof(BlockShared) > 160 * 1024) return fail(WALT_EINVAL, "read length too large for the LDS staging window");
+  if (lds > 32 * 1024)
+    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_topk<NW>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err, win_words, n,
+                     sb, max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
   uint32_t* defer_sorted = defer_list + stride;  // second half of the list area
   launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   unsigned g2 = grid_for(n) < 1024u ? grid_for(n) : 1024u;
-  hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride, sb, max_mm,
-                     b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_sorted);
+  hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, bases, offsets, err, sb,
+                     max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_sorted);
+  return WALT_OK;
 }
 
 // one chunk (n <= chunk capacity of the workspace)
 static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_off1, const uint8_t* d_bases2,
-                    const uint64_t* d_off2, uint32_t n, int nw, uint32_t max_mm, uint32_t b, uint32_t top_k,
+                    const uint64_t* d_off2, uint32_t n, int nw, uint32_t max_read_len, uint32_t max_mm, uint32_t b,
+                    uint32_t top_k,
                     int frag_range, PairResult* d_out, unsigned long long* d_stats, const PeWorkspace& w,
                     hipStream_t stream) {
   const uint8_t* bases[2] = {d_bases1, d_bases2};
@@ -299,22 +321,23 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   WALT_HIP(hipMemsetAsync(w.err + 64, 0, 64 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) {
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
-    launch_pack_reads(bases[m], offs[m], n, (uint32_t)m, idx->view.dir_bits, (uint32_t)nw, w.packed[m], w.stride,
-                      w.err, stream);
     unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;
+    uint32_t* ctl = w.err + 64 + 32 * m;
+    int rc;
     switch (nw) {
-      case 8: launch_pe_topk<8>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
-      case 16: launch_pe_topk<16>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
-      case 32: launch_pe_topk<32>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
-      default: launch_pe_topk<64>(idx, w.packed[m], w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, w.err + 64 + 32 * m, w.defer_list[m], stream); break;
+      case 8: rc = launch_pe_topk<8>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      case 16: rc = launch_pe_topk<16>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      case 32: rc = launch_pe_topk<32>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      default: rc = launch_pe_topk<64>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
     }
+    if (rc) return rc;
     launch_reduce_stats(w.shards[m], d_stats + 4 * m, stream);
     hipLaunchKernelGGL(k_pe_drain, dim3(grid_for(n)), dim3(kBlock), 0, stream, w.heaps[m], w.heap_n[m], n, top_k,
                        w.ranked[m]);
   }
   hipLaunchKernelGGL(k_pe_merge, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, w.ranked[0], w.heap_n[0],
-                     w.ranked[1], w.heap_n[1], w.packed[0], w.packed[1], n, top_k, frag_range, max_mm, d_out);
+                     w.ranked[1], w.heap_n[1], d_off1, d_off2, n, top_k, frag_range, max_mm, d_out);
   WALT_HIP(hipGetLastError());
   return WALT_OK;
 }
@@ -360,7 +383,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
     uint32_t cnt = n - start < chunk ? n - start : chunk;
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases1), reinterpret_cast<const uint64_t*>(d_offsets1) + start,
                   reinterpret_cast<const uint8_t*>(d_bases2), reinterpret_cast<const uint64_t*>(d_offsets2) + start, cnt,
-                  nw, max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
+                  nw, max_read_len, max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
                   reinterpret_cast<unsigned long long*>(d_stats), w, stream);
     if (rc) return rc;
   }
@@ -420,7 +443,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     uint32_t cnt = n - start < chunk ? n - start : chunk;
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases[0]), reinterpret_cast<const uint64_t*>(d_off[0]) + start,
                   reinterpret_cast<const uint8_t*>(d_bases[1]), reinterpret_cast<const uint64_t*>(d_off[1]) + start, cnt, nw,
-                  max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
+                  max_len, max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
                   reinterpret_cast<unsigned long long*>(d_stats), w, nullptr);
     if (rc) break;
     if (hipDeviceSynchronize() != hipSuccess) { rc = fail(WALT_EHIP, "paired-end kernels failed"); break; }
@@ -431,7 +454,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
       if (rn[m]) hipMemcpy(rn[m] + start, w.heap_n[m], (size_t)cnt * 4, hipMemcpyDeviceToHost);
     }
   }
-  if (!rc) rc = check_pack_errors(d_ws, nullptr);
+  if (!rc) rc = check_read_errors(d_ws, nullptr);
   if (!rc) {
     if (hipMemcpy(out, d_out, (size_t)n * sizeof(walt_pair_result), hipMemcpyDeviceToHost) != hipSuccess)
       rc = fail(WALT_EHIP, "download failed");

@@ -19,156 +19,6 @@
 
 namespace walt {
 
-// Read packing (the same record index_core.h pack_read() builds, which stays the
-// specification and is what the CPU harness uses):
-//   phase 1  the block reads the contiguous ASCII bytes of its 256 reads with
-//            coalesced 16-byte loads and turns them into a dense 2-bit array in
-//            LDS (16 bytes -> one word) plus a per-word "not ACGT" mask;
-//   phase 2  each thread cuts its own read out of the 2-bit array with funnel
-//            shifts, applies the C->T / G->A conversion as a bit trick, extracts
-//            the three care strings with compile-time offsets and writes the SoA
-//            record (coalesced across the block).
-// Blocks whose reads span more than kPackLdsBytes, or an unaligned input
-// buffer, take the plain per-thread path.
-constexpr uint32_t kPackLdsBytes = 48 * 1024;  // widest byte window a block stages (as 2-bit codes: 1/8 of it)
-
-__device__ __forceinline__ uint32_t convert_word(uint32_t x, uint32_t ga) {
-  const uint32_t lo = x & 0x55555555u;
-  // C->T: 01 -> 11 (hi |= lo).  G->A: 10 -> 00 (hi &= lo).
-  return ga ? (x & (0x55555555u | (lo << 1))) : (x | (lo << 1));
-}
-
-template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pack_reads(const uint8_t* __restrict__ bases,
-                                                        const uint64_t* __restrict__ offsets, uint32_t n,
-                                                        uint32_t ga, uint32_t Bd, uint32_t* __restrict__ packed,
-                                                        uint64_t stride, uint32_t* __restrict__ err) {
-  __shared__ uint32_t codes[kPackLdsBytes / 16 + 4];
-  __shared__ uint32_t inval[kPackLdsBytes / 16 + 4];
-  const uint32_t r0 = blockIdx.x * blockDim.x;
-  const uint32_t cnt = n - r0 < blockDim.x ? n - r0 : blockDim.x;
-  const uint64_t o0 = offsets[r0], o1 = offsets[r0 + cnt];
-  const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(bases) + o0) & 15);
-  const bool use_lds = mis <= o0 && (o1 - (o0 - mis)) <= kPackLdsBytes;
-  const uint64_t a0 = o0 - mis;
-  const uint32_t r = r0 + threadIdx.x;
-  if (!use_lds) {  // rare: generic path straight from HBM
-    if (r >= n) return;
-    const uint64_t o = offsets[r];
-    uint64_t len64 = offsets[r + 1] - o;
-    if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
-    if (!pack_read(bases + o, (uint32_t)len64, ga, Bd, NW, packed + r, stride)) atomicAdd(err, 1u);
-    return;
-  }
-  const uint32_t span = (uint32_t)(o1 - a0);
-  const uint32_t nwin = (span + 15) / 16;
-  for (uint32_t i = threadIdx.x; i < nwin; i += blockDim.x) {
-    uint4 q;
-    if (16 * i + 16 <= span) {
-      q = *reinterpret_cast<const uint4*>(bases + a0 + 16 * (uint64_t)i);
-    } else {
-      uint32_t t[4] = {0, 0, 0, 0};
-      for (uint32_t k = 16 * i; k < span; ++k) t[(k & 15) >> 2] |= (uint32_t)bases[a0 + k] << (8 * (k & 3));
-      q = make_uint4(t[0], t[1], t[2], t[3]);
-    }
-    const uint32_t qs[4] = {q.x, q.y, q.z, q.w};
-    uint32_t c = 0, bad = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t code = base_code((uint8_t)(qs[j] >> (8 * k)));
-        c |= (code & 3u) << (2 * (4 * j + k));
-        bad |= (code > 3 ? 1u : 0u) << (4 * j + k);
-      }
-    }
-    codes[i] = c;
-    inval[i] = bad;
-  }
-  if (threadIdx.x < 4) { codes[nwin + threadIdx.x] = 0; inval[nwin + threadIdx.x] = 0; }
-  __syncthreads();
-  if (r >= n) return;
-
-  const uint64_t o = offsets[r];
-  uint64_t len64 = offsets[r + 1] - o;
-  if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
-  const uint32_t len = (uint32_t)len64;
-  const uint32_t off = (uint32_t)(o - a0);
-  const uint32_t wi0 = off >> 4, sh = 2 * (off & 15);
-  uint32_t rd[NW];
-  uint32_t bad = 0;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    uint32_t v = 0, iv = 0;
-    if (16u * w < len) {
-      const uint32_t lo = codes[wi0 + w], hi = codes[wi0 + w + 1];
-      v = funnel_r(lo, hi, sh);
-      iv = (inval[wi0 + w] >> (off & 15)) | (inval[wi0 + w + 1] << (16 - (off & 15)));
-      const uint32_t nb = len - 16u * w;  // bases of this read in the word
-      if (nb < 16) { v &= (1u << (2 * nb)) - 1u; iv &= (1u << nb) - 1u; }
-      iv &= 0xFFFFu;
-    }
-    bad |= iv;
-    rd[w] = convert_word(v, ga);
-  }
-  if (bad) {
-    atomicAdd(err, 1u);
-    // pack_read() stores code 0 for a non-ACGT char; reproduce that record
-#pragma unroll
-    for (int w = 0; w < NW; ++w) rd[w] = 0;
-    pack_read(bases + o, len, ga, Bd, NW, packed + r, stride);
-    return;
-  }
-  packed[r] = len;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) packed[(uint64_t)(1 + w) * stride + r] = rd[w];
-
-  const uint32_t seed_len = len >= kMinReadLen ? seed_repeats(len) : 0;
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    uint32_t care[kCareWords] = {0, 0, 0, 0};
-    uint64_t acc = 0;   // order-preserving prefix code of the care characters (core.h dir_range)
-    uint32_t nb = 0;
-#pragma unroll
-    for (int i = 0; i < (int)kMaxRepeats; ++i) {
-      const int q = s + 1 + 3 * i;  // compile-time read offset of care char i
-      if ((q >> 4) < NW) {
-        uint32_t c = (rd[q >> 4] >> (2 * (q & 15))) & 3u;
-        const bool in_seed = (uint32_t)i < seed_len;
-        c = in_seed ? c : 0u;
-        care[i >> 4] |= c << (30 - 2 * (i & 15));
-        if (i < 32) {
-          const bool take = in_seed && nb < Bd;
-          const uint32_t l = pcode_len(c, ga);
-          acc = take ? ((acc << l) | pcode_bits(c, ga)) : acc;
-          nb += take ? l : 0u;
-        }
-      }
-    }
-    uint32_t v_lo = 0, span = 0;
-    if (seed_len) {
-      if (nb >= Bd) { v_lo = (uint32_t)(acc >> (nb - Bd)); span = 1; }
-      else { v_lo = (uint32_t)(acc << (Bd - nb)); span = 1u << (Bd - nb); }
-    }
-    const uint64_t base = 1 + NW + s * kPerSeedWords;
-#pragma unroll
-    for (uint32_t w = 0; w < kCareWords; ++w) packed[(base + w) * stride + r] = care[w];
-    packed[(base + kCareWords) * stride + r] = seed_len ? (1u << Bd) - v_lo : 0u;
-    packed[(base + kCareWords + 1) * stride + r] = span;
-  }
-}
-
-void launch_pack_reads(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t ga, uint32_t Bd,
-                       uint32_t nw, uint32_t* d_packed, uint64_t stride, uint32_t* d_err, hipStream_t stream) {
-  const dim3 g(grid_for(n)), b(kBlock);
-  switch (nw) {
-    case 8: hipLaunchKernelGGL(k_pack_reads<8>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
-    case 16: hipLaunchKernelGGL(k_pack_reads<16>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
-    case 32: hipLaunchKernelGGL(k_pack_reads<32>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
-    default: hipLaunchKernelGGL(k_pack_reads<64>, g, b, 0, stream, d_bases, d_offsets, n, ga, Bd, d_packed, stride, d_err); break;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // Wave-cooperative verification of one large region owned by lane `owner`.
 // All 64 lanes call this with the same (uniform) arguments broadcast from the
@@ -251,15 +101,23 @@ struct MapCounters {
 
 template <int NW, bool LITERAL>
 __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
-                                           const uint32_t* __restrict__ packed, uint64_t stride, uint32_t r,
+                                           const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                           uint32_t* __restrict__ err, uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
                                            uint32_t* __restrict__ defer_list, MapCounters& ctr, uint32_t& len_out,
                                            uint32_t ablate, Stamps& st) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
+  const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
   LaneRead<NW> lr;
-  load_lane_read<NW>(lr, packed, stride, r, valid);
+  {
+    uint64_t o = 0, oe = 0;
+    if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
+    lr.len = (oe - o) > 16ull * NW ? 0u : (uint32_t)(oe - o);
+    lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
+    lane_read_global<NW>(lr, bases, o, lr.len, ga, err);
+  }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
@@ -283,13 +141,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
       {
         uint32_t care[kCareWords] = {0, 0, 0, 0};
         uint32_t slot = 0, span = 0;
-        if (act) {
-          const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
-#pragma unroll
-          for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
-          slot = packed[(fbase + kCareWords) * stride + r];
-          span = packed[(fbase + kCareWords + 1) * stride + r];
-        }
+        if (act) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, care, slot, span);
         stamp(st, 1);
         bool is_bad = false;
         if (act && !LITERAL) is_bad = bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8);
@@ -457,7 +309,9 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const uint
 
 template <int NW>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si,
-                                                const uint32_t* __restrict__ packed, uint64_t stride, uint32_t r,
+                                                const uint8_t* __restrict__ bases,
+                                                const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
+                                                uint32_t* lds_wave, uint32_t win_words, uint32_t r,
                                                 bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                                 BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
                                                 uint32_t* __restrict__ defer_list, MapCounters& ctr,
@@ -466,8 +320,9 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
   const uint32_t lane = threadIdx.x & 63;
   const StrandView& svp = iv.s[strand_base];
   const StrandView& svm = iv.s[strand_base + 1];
+  const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
   LaneRead<NW> lr;
-  load_lane_read<NW>(lr, packed, stride, r, valid);
+  wave_load_reads<NW>(lr, bases, offsets, r, valid, ga, lds_wave, win_words, err);
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
@@ -490,13 +345,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
 
     uint32_t care[kCareWords] = {0, 0, 0, 0};
     uint32_t slot = 0, span = 0;
-    if (need_p || need_m) {
-      const uint64_t fbase = (uint64_t)(1 + NW + seed_i * kPerSeedWords);
-#pragma unroll
-      for (uint32_t w = 0; w < kCareWords; ++w) care[w] = packed[(fbase + w) * stride + r];
-      slot = packed[(fbase + kCareWords) * stride + r];
-      span = packed[(fbase + kCareWords + 1) * stride + r];
-    }
+    if (need_p || need_m) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, care, slot, span);
     stamp(st, 1);
     const uint32_t h = care[0] >> 8;
     const bool bad_p = need_p && bloom_maybe(sh.bloom[0], h) && bucket_is_bad(svp, h);
@@ -699,8 +548,10 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 
 // pass 1: every read of the batch, one per lane
 template <int NW>
-__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView iv, const uint32_t* __restrict__ packed,
-                                                    uint64_t stride, uint32_t n, uint32_t strand_base,
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView iv, const uint8_t* __restrict__ bases,
+                                                    const uint64_t* __restrict__ offsets,
+                                                    uint32_t* __restrict__ err, uint32_t win_words,
+                                                    uint32_t n, uint32_t strand_base,
                                                     uint32_t max_mm, uint32_t b,
                                                     const uint32_t* __restrict__ mask_table,
                                                     BestMatch* __restrict__ out,
@@ -709,6 +560,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
                                                     uint32_t* __restrict__ defer_list, uint32_t ablate,
                                                     unsigned long long* __restrict__ stamps) {
   __shared__ BlockShared sh;
+  extern __shared__ uint32_t dyn_lds[];
+  uint32_t* lds_wave = dyn_lds + (threadIdx.x >> 6) * stage_words_per_wave(win_words);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   // persistent blocks: the LDS prologue (mask table, chromosome starts, Bloom
   // filters: ~25 KB) is paid once per block, not once per 256 reads
@@ -727,8 +580,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    se_process_dual<NW>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, defer_count,
-                        defer_list, ctr, len, ablate, st);
+    se_process_dual<NW>(iv, sh, si, bases, offsets, err, lds_wave, win_words, r, valid, strand_base, max_mm, b,
+                        out, defer_count, defer_list, ctr, len, ablate, st);
     // too_short is counted once per strand pass (mapping.cpp:230-233)
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
@@ -738,8 +591,10 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
 
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ packed,
-                                                            uint64_t stride, uint32_t strand_base, uint32_t max_mm,
+__global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint8_t* __restrict__ bases,
+                                                            const uint64_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ err, uint32_t strand_base,
+                                                            uint32_t max_mm,
                                                             uint32_t b, const uint32_t* __restrict__ mask_table,
                                                             BestMatch* __restrict__ out,
                                                             unsigned long long* __restrict__ stats,
@@ -756,8 +611,8 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
     uint32_t len;
     Stamps st;
     st.buf = nullptr;
-    se_process<NW, true>(iv, sh, si, packed, stride, r, valid, strand_base, max_mm, b, out, nullptr, nullptr, ctr,
-                         len, 0u, st);
+    se_process<NW, true>(iv, sh, si, bases, offsets, err, r, valid, strand_base, max_mm, b, out, nullptr, nullptr,
+                         ctr, len, 0u, st);
   }
   flush_counters(ctr, 0, stats);
 }
@@ -777,21 +632,29 @@ static unsigned long long* g_stamps = nullptr;  // WALT_AMD_STAMPS=1: device buf
 constexpr unsigned kLiteralGrid = 1024;  // blocks of the deferred-read pass (grid-stride)
 
 template <int NW>
-static void launch_map_se(const walt_index* idx, const uint32_t* packed, uint64_t stride, uint32_t n,
-                          uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
-                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
-                          hipStream_t stream) {
+static int launch_map_se(const walt_index* idx, const uint8_t* bases, const uint64_t* offsets, uint32_t* err,
+                         uint32_t max_read_len, uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b,
+                         BestMatch* out, unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
+                         uint64_t stride, hipStream_t stream) {
   unsigned pg = kPersistentGrid;
   if (const char* e = getenv("WALT_AMD_GRID")) pg = atoi(e) > 0 ? (unsigned)atoi(e) : grid_for(n);  // diagnostic knob
   const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
-  hipLaunchKernelGGL(k_map_se<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, packed, stride, n,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate, g_stamps);
+  const uint32_t win_words = stage_win_words(max_read_len);
+  const size_t lds = stage_lds_bytes(max_read_len);
+  if (lds + sizeof(BlockShared) > 160 * 1024) return fail(WALT_EINVAL, "read length too large for the LDS staging window");
+  if (lds > 32 * 1024)
+    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_map_se<NW>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_map_se<NW>, dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err, win_words,
+                     n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate,
+                     g_stamps);
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
-  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, packed, stride,
+  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, bases, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted);
+  return WALT_OK;
 }
 
 int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n, uint32_t max_read_len,
@@ -815,26 +678,28 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
   WALT_HIP(hipSetDevice(idx->device));
   const uint64_t stride = se_stride(n);
-  // workspace: [64 words: pack errors, deferred count] [statistic shards] [packed reads] [deferred read list]
+  // workspace: [64 words: read errors, deferral control] [statistic shards] [deferred list] [sorted deferred list]
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   unsigned long long* shards = reinterpret_cast<unsigned long long*>(err + 64);
-  uint32_t* packed = err + 64 + kStatShardBytes / 4;
   uint32_t* defer_count = err + 32;  // control block: [0] count, [8..15] bin counts, [16..23] bin cursors
-  uint32_t* defer_list = packed + (uint64_t)packed_fields((uint32_t)nw) * stride;
+  uint32_t* defer_list = err + 64 + kStatShardBytes / 4;
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
-  if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
-  launch_pack_reads(reinterpret_cast<const uint8_t*>(d_bases), reinterpret_cast<const uint64_t*>(d_offsets), n,
-                    (uint32_t)(ag ? 1 : 0), idx->view.dir_bits, (uint32_t)nw, packed, stride, err, stream);
-  if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[1], stream));
-  BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
-  unsigned long long* stats = shards;
-  const uint32_t sb = ag ? 2u : 0u;
-  switch (nw) {
-    case 8: launch_map_se<8>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
-    case 16: launch_map_se<16>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
-    case 32: launch_map_se<32>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
-    default: launch_map_se<64>(idx, packed, stride, n, sb, max_mm, b, out, stats, defer_count, defer_list, stream); break;
+  if (idx->profile) {
+    WALT_HIP(hipEventRecord(idx->ev[0], stream));
+    WALT_HIP(hipEventRecord(idx->ev[1], stream));  // read packing is fused into the mapping kernel
   }
+  const uint8_t* bases = reinterpret_cast<const uint8_t*>(d_bases);
+  const uint64_t* offsets = reinterpret_cast<const uint64_t*>(d_offsets);
+  BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
+  const uint32_t sb = ag ? 2u : 0u;
+  int rc;
+  switch (nw) {
+    case 8: rc = launch_map_se<8>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 16: rc = launch_map_se<16>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 32: rc = launch_map_se<32>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    default: rc = launch_map_se<64>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+  }
+  if (rc) return rc;
   launch_reduce_stats(shards, reinterpret_cast<unsigned long long*>(d_stats), stream);
   if (idx->profile) {
     WALT_HIP(hipEventRecord(idx->ev[2], stream));
@@ -844,8 +709,8 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   return WALT_OK;
 }
 
-// err words written by k_pack_reads live at the start of the workspace
-int check_pack_errors(const void* d_workspace, hipStream_t stream) {
+// err[0] / err[1] (non-ACGT reads / over-long reads) live at the start of the workspace
+int check_read_errors(const void* d_workspace, hipStream_t stream) {
   uint32_t herr[2] = {0, 0};
   WALT_HIP(hipMemcpyAsync(herr, d_workspace, sizeof(herr), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipStreamSynchronize(stream));
@@ -893,7 +758,8 @@ int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms) {
 size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
-  return 64 * sizeof(uint32_t) + kStatShardBytes + ((size_t)packed_fields((uint32_t)nw) + 2) * se_stride(n) * sizeof(uint32_t);
+  (void)nw;
+  return 64 * sizeof(uint32_t) + kStatShardBytes + 2 * se_stride(n) * sizeof(uint32_t);
 }
 
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
@@ -939,7 +805,7 @@ int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offset
     return fail(WALT_EHIP, std::string("upload failed: ") + hipGetErrorString(e));
   }
   rc = map_se_device(idx, d_bases, d_off, n, max_len, ag_wildcard, max_mismatches, b, d_out, d_stats, d_ws, nullptr);
-  if (!rc) rc = check_pack_errors(d_ws, nullptr);
+  if (!rc) rc = check_read_errors(d_ws, nullptr);
   if (!rc) {
     if ((e = hipMemcpy(out, d_out, (size_t)n * sizeof(walt_best_match), hipMemcpyDeviceToHost)) != hipSuccess)
       rc = fail(WALT_EHIP, std::string("download failed: ") + hipGetErrorString(e));
