@@ -17,6 +17,7 @@ struct BlockShared {
   uint32_t mask_table[kMaskTableWords];
   uint32_t start_index[kLdsChroms + 1];
   uint32_t bloom[2][kBloomWords];  // BAD-bucket filters of the two strands this launch maps against
+  uint16_t pcode4[256];            // prefix code of 4 care chars: bits | len << 8 (core.h pcode_*)
 };
 
 // Stage the compare-mask table and the chromosome starts in LDS.  Returns the
@@ -28,6 +29,15 @@ __device__ __forceinline__ const uint32_t* block_prologue(BlockShared& sh, const
   for (uint32_t fi = 0; fi < 2; ++fi) {
     const uint32_t* __restrict__ bl = iv.s[strand_base + fi].bloom;
     for (uint32_t i = threadIdx.x; i < kBloomWords; i += blockDim.x) sh.bloom[fi][i] = bl[i];
+  }
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {  // 4 chars, first char in bits 7..6
+    uint32_t bits = 0, len = 0;
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t c = (i >> (6 - 2 * k)) & 3u, l = pcode_len(c, strand_base >> 1);
+      bits = (bits << l) | pcode_bits(c, strand_base >> 1);
+      len += l;
+    }
+    sh.pcode4[i] = (uint16_t)(bits | (len << 8));
   }
   const bool fits = iv.n_chrom <= kLdsChroms;
   if (fits)
@@ -193,42 +203,72 @@ __device__ __forceinline__ void wave_load_reads(LaneRead<NW>& lr, const uint8_t*
 }
 
 // Care string (chars at read offsets seed_i + 1 + 3 i, MSB first) of a seed shift
-// and its directory range, from the packed read in registers.
+// and its directory range, from the packed read in registers.  The prefix code is
+// accumulated four characters at a time through the LDS table pcode4; characters
+// beyond seed_len are zero, whose code bits are zeros, which is exactly the zero
+// padding dir_range() applies to short seeds.
 template <int NW>
 __device__ __forceinline__ void seed_query(const uint32_t* rd, uint32_t seed_len, uint32_t seed_i, uint32_t ga,
-                                           uint32_t Bd, uint32_t* care, uint32_t& slot, uint32_t& span) {
-  constexpr int NS = NW < 10 ? NW : 10;  // 50 care chars reach base 3*49 + 3 = 150
+                                           uint32_t Bd, const uint16_t* pcode4, uint32_t* care, uint32_t& slot,
+                                           uint32_t& span) {
+  constexpr int NS = NW < 10 ? NW : 10;                       // 50 care chars reach base 3*49 + 3 = 150
+  constexpr int NC = (16 * NS - 1) / 3 + 1 < (int)kMaxRepeats ? (16 * NS - 1) / 3 + 1 : (int)kMaxRepeats;
   uint32_t shd[NS];
   const uint32_t sh = 2 * (seed_i + 1);
 #pragma unroll
   for (int w = 0; w < NS; ++w) shd[w] = funnel_r(rd[w], w + 1 < NW ? rd[w + 1] : 0u, sh);
   care[0] = care[1] = care[2] = care[3] = 0;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int q = 3 * i;  // compile-time offset in the shifted read
+    care[i >> 4] |= ((shd[q >> 4] >> (2 * (q & 15))) & 3u) << (30 - 2 * (i & 15));
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {  // zero the characters at and beyond seed_len
+    const uint32_t keep = seed_len > 16u * w ? seed_len - 16u * w : 0u;
+    care[w] = keep >= 16 ? care[w] : (keep ? care[w] & ~(0xFFFFFFFFu >> (2 * keep)) : 0u);
+  }
+  // prefix code of the first 32 characters (>= 32 bits), 4 characters per table lookup
   uint64_t acc = 0;
   uint32_t nb = 0;
 #pragma unroll
-  for (int i = 0; i < (int)kMaxRepeats; ++i) {
-    constexpr int dummy = 0; (void)dummy;
-    const int q = 3 * i;  // compile-time offset in the shifted read
-    if ((q >> 4) < NS) {
-      uint32_t c = (shd[q >> 4] >> (2 * (q & 15))) & 3u;
-      const bool in_seed = (uint32_t)i < seed_len;
-      c = in_seed ? c : 0u;
-      care[i >> 4] |= c << (30 - 2 * (i & 15));
-      if (i < 32) {
-        const bool take = in_seed && nb < Bd;
-        const uint32_t l = pcode_len(c, ga);
-        acc = take ? ((acc << l) | pcode_bits(c, ga)) : acc;
-        nb += take ? l : 0u;
-      }
-    }
+  for (int g = 0; g < 8; ++g) {
+    const uint32_t e = pcode4[(care[g >> 2] >> (24 - 8 * (g & 3))) & 0xFFu];
+    acc = (acc << (e >> 8)) | (e & 0xFFu);
+    nb += e >> 8;
   }
-  uint32_t v_lo = 0;
-  span = 0;
-  if (seed_len) {
-    if (nb >= Bd) { v_lo = (uint32_t)(acc >> (nb - Bd)); span = 1; }
-    else { v_lo = (uint32_t)(acc << (Bd - nb)); span = 1u << (Bd - nb); }
+  const uint32_t v_lo = (uint32_t)(acc >> (nb - Bd));
+  // code bits the seed itself carries: 2 per character minus the one-bit letters (T after C->T, A after G->A)
+  const uint32_t k = seed_len < 32 ? seed_len : 32;
+  uint32_t shorts = 0;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const uint32_t x = care[w];
+    uint32_t one = ga ? (~x & (~x >> 1)) : (x & (x >> 1));  // bit 2j set: char j is the one-bit letter
+    one &= 0x55555555u;
+    const uint32_t keep = k > 16u * w ? k - 16u * w : 0u;
+    one = keep >= 16 ? one : (keep ? one & ~(0xFFFFFFFFu >> (2 * keep)) : 0u);
+    shorts += __popc(one);
   }
-  slot = seed_len ? (1u << Bd) - v_lo : 0u;
+  const uint32_t nb_seed = 2 * k - shorts;
+  span = seed_len ? (nb_seed < Bd ? 1u << (Bd - nb_seed) : 1u) : 0u;
+  slot = seed_len ? (1u << Bd) - (nb_seed < Bd ? (v_lo >> (Bd - nb_seed)) << (Bd - nb_seed) : v_lo) : 0u;
+}
+
+// getChromID (reference.cpp:43-60) with a fixed number of steps: largest l with
+// si[l] <= pos.  top_step = largest power of two <= n_chrom (wave-uniform).
+__device__ __forceinline__ uint32_t chrom_id_steps(const uint32_t* si, uint32_t n_chrom, uint32_t top_step,
+                                                   uint32_t pos) {
+  uint32_t l = 0;
+  for (uint32_t step = top_step; step; step >>= 1) {
+    const uint32_t c = l + step;
+    const uint32_t v = si[c <= n_chrom ? c : n_chrom];
+    l = (c <= n_chrom && pos >= v) ? c : l;
+  }
+  return l;
+}
+__device__ __forceinline__ uint32_t top_step_of(uint32_t n_chrom) {
+  return n_chrom ? 1u << (31 - __clz((int)n_chrom)) : 0u;
 }
 
 template <int NW>

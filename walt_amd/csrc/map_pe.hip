@@ -72,7 +72,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
       if (act) {
         uint32_t care[kCareWords];
         uint32_t slot, span;
-        seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, care, slot, span);
+        seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
         if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8)) {
           deferred = true;
           mappable = false;

@@ -62,33 +62,37 @@ __device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const
 // loads, 2 bloom/bad test, 3 lookup (dir + entries), 4 masks, 5 own-lane verify,
 // 6 wave-cooperative regions, 7 store, 8 total.
 constexpr int kStampPhases = 9;
-struct Stamps {
-  unsigned long long* buf;  // nullptr = disabled
+template <bool ON>
+struct StampsT {
+  unsigned long long* buf;
   unsigned long long last;
   unsigned long long acc[kStampPhases];
 };
+template <>
+struct StampsT<false> {};  // production kernels carry no stamp state or code
 __device__ __forceinline__ unsigned long long stamp_now() {
   unsigned long long t;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
-__device__ __forceinline__ void stamp_begin(Stamps& st, unsigned long long* buf) {
+__device__ __forceinline__ void stamp_begin(StampsT<true>& st, unsigned long long* buf) {
   st.buf = buf;
   for (int i = 0; i < kStampPhases; ++i) st.acc[i] = 0;
-  st.last = buf ? stamp_now() : 0;
+  st.last = stamp_now();
 }
-__device__ __forceinline__ void stamp(Stamps& st, int phase) {
-  if (st.buf) {
-    const unsigned long long t = stamp_now();
-    st.acc[phase] += t - st.last;
-    st.acc[8] += t - st.last;
-    st.last = t;
-  }
+__device__ __forceinline__ void stamp(StampsT<true>& st, int phase) {
+  const unsigned long long t = stamp_now();
+  st.acc[phase] += t - st.last;
+  st.acc[8] += t - st.last;
+  st.last = t;
 }
-__device__ __forceinline__ void stamp_end(Stamps& st) {
-  if (st.buf && (threadIdx.x & 63) == 0)
+__device__ __forceinline__ void stamp_end(StampsT<true>& st) {
+  if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < kStampPhases; ++i) atomicAdd(&st.buf[i], st.acc[i]);
 }
+__device__ __forceinline__ void stamp_begin(StampsT<false>&, unsigned long long*) {}
+__device__ __forceinline__ void stamp(StampsT<false>&, int) {}
+__device__ __forceinline__ void stamp_end(StampsT<false>&) {}
 
 // Work for one read per lane.  LITERAL = false (pass 1): a lane whose probe
 // lands in a BAD bucket (literal LowerBound/UpperBound search, ~100x the
@@ -99,14 +103,15 @@ struct MapCounters {
   uint32_t probes, verified, big;
 };
 
-template <int NW, bool LITERAL>
+template <int NW, bool LITERAL, bool DIAG>
 __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
                                            const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                            uint32_t* __restrict__ err, uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
                                            uint32_t* __restrict__ defer_list, MapCounters& ctr, uint32_t& len_out,
-                                           uint32_t ablate, Stamps& st) {
+                                           uint32_t ablate_rt, StampsT<DIAG>& st) {
+  const uint32_t ablate = DIAG ? ablate_rt : 0u;
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
@@ -141,7 +146,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
       {
         uint32_t care[kCareWords] = {0, 0, 0, 0};
         uint32_t slot = 0, span = 0;
-        if (act) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, care, slot, span);
+        if (act) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
         stamp(st, 1);
         bool is_bad = false;
         if (act && !LITERAL) is_bad = bloom_maybe(sh.bloom[fi], care[0] >> 8) && bucket_is_bad(sv, care[0] >> 8);
@@ -297,17 +302,17 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
 // 0 when the edge filters of mapping.cpp:280-286 reject the candidate)
 template <int NW>
 __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
-                                                bool active, uint32_t slot_pos, uint32_t seed_i, uint32_t len,
-                                                const uint32_t* rd, const uint32_t* mk, bool& ok, uint32_t& gp,
-                                                uint32_t& mm) {
-  const uint32_t chr = chrom_id(si, n_chrom, slot_pos);
+                                                uint32_t top_step, bool active, uint32_t slot_pos, uint32_t seed_i,
+                                                uint32_t len, const uint32_t* rd, const uint32_t* mk, bool& ok,
+                                                uint32_t& gp, uint32_t& mm) {
+  const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, slot_pos);
   const uint32_t g = slot_pos - seed_i;
   ok = active && (slot_pos - si[chr] >= seed_i) && (g + len < si[chr + 1]);
   gp = ok ? g : 0u;
   mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
 }
 
-template <int NW>
+template <int NW, bool DIAG>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si,
                                                 const uint8_t* __restrict__ bases,
                                                 const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
@@ -315,8 +320,10 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
                                                 bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                                 BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
                                                 uint32_t* __restrict__ defer_list, MapCounters& ctr,
-                                                uint32_t& len_out, uint32_t ablate, Stamps& st) {
+                                                uint32_t& len_out, uint32_t ablate_rt, StampsT<DIAG>& st) {
+  const uint32_t ablate = DIAG ? ablate_rt : 0u;
   const uint32_t n_chrom = iv.n_chrom;
+  const uint32_t top_step = top_step_of(n_chrom);
   const uint32_t lane = threadIdx.x & 63;
   const StrandView& svp = iv.s[strand_base];
   const StrandView& svm = iv.s[strand_base + 1];
@@ -345,7 +352,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
 
     uint32_t care[kCareWords] = {0, 0, 0, 0};
     uint32_t slot = 0, span = 0;
-    if (need_p || need_m) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, care, slot, span);
+    if (need_p || need_m) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
     stamp(st, 1);
     const uint32_t h = care[0] >> 8;
     const bool bad_p = need_p && bloom_maybe(sh.bloom[0], h) && bucket_is_bad(svp, h);
@@ -387,20 +394,20 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
     const bool small_p = size_p && size_p <= kSmallRegion, small_m = size_m && size_m <= kSmallRegion;
     if (small_p || small_m) {
-#pragma unroll
-      for (uint32_t k = 0; k < kSmallRegion; ++k) {
+      const uint32_t kmax = (small_p ? size_p : 0u) > (small_m ? size_m : 0u) ? size_p : (small_m ? size_m : size_p);
+#pragma unroll 1
+      for (uint32_t k = 0; k < kmax; ++k) {  // rolled (code size); pos[] picked by selects, not indexing
         const bool act_p = small_p && k < size_p, act_m = small_m && k < size_m;
-        if (act_p || act_m) {
-          uint32_t pos_p = 0, pos_m = 0;
-          if (act_p) pos_p = k < lp.npos ? lp.pos[k] : svp.ent[lp.reg.l + k].pos;
-          if (act_m) pos_m = k < lm.npos ? lm.pos[k] : svm.ent[lm.reg.l + k].pos;
-          bool ok_p, ok_m;
-          uint32_t gp_p, gp_m, mm_p, mm_m;
-          verify_nobranch<NW>(svp, si, n_chrom, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
-          verify_nobranch<NW>(svm, si, n_chrom, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
-          if (ok_p) { sum_p = summary_merge(sum_p, summary_one(mm_p, gp_p)); ++ctr.verified; }
-          if (ok_m) { sum_m = summary_merge(sum_m, summary_one(mm_m, gp_m)); ++ctr.verified; }
-        }
+        uint32_t pos_p = k == 0 ? lp.pos[0] : k == 1 ? lp.pos[1] : k == 2 ? lp.pos[2] : lp.pos[3];
+        uint32_t pos_m = k == 0 ? lm.pos[0] : k == 1 ? lm.pos[1] : k == 2 ? lm.pos[2] : lm.pos[3];
+        if (act_p && k >= lp.npos) pos_p = svp.ent[lp.reg.l + k].pos;
+        if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
+        bool ok_p, ok_m;
+        uint32_t gp_p, gp_m, mm_p, mm_m;
+        verify_nobranch<NW>(svp, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+        verify_nobranch<NW>(svm, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+        if (ok_p) { sum_p = summary_merge(sum_p, summary_one(mm_p, gp_p)); ++ctr.verified; }
+        if (ok_m) { sum_m = summary_merge(sum_m, summary_one(mm_m, gp_m)); ++ctr.verified; }
       }
     }
     stamp(st, 5);
@@ -547,7 +554,7 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 }
 
 // pass 1: every read of the batch, one per lane
-template <int NW>
+template <int NW, bool DIAG>
 __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView iv, const uint8_t* __restrict__ bases,
                                                     const uint64_t* __restrict__ offsets,
                                                     uint32_t* __restrict__ err, uint32_t win_words,
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
   // filters: ~25 KB) is paid once per block, not once per 256 reads
   MapCounters ctr = {0, 0, 0};
   uint32_t shortv = 0;
-  Stamps st;
+  StampsT<DIAG> st;
   stamp_begin(st, stamps);
   // each block walks its own contiguous slice of the batch (consecutive 256-read
   // chunks share pages: a strided assignment made every load a TLB miss)
@@ -580,8 +587,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    se_process_dual<NW>(iv, sh, si, bases, offsets, err, lds_wave, win_words, r, valid, strand_base, max_mm, b,
-                        out, defer_count, defer_list, ctr, len, ablate, st);
+    se_process_dual<NW, DIAG>(iv, sh, si, bases, offsets, err, lds_wave, win_words, r, valid, strand_base, max_mm,
+                              b, out, defer_count, defer_list, ctr, len, ablate, st);
     // too_short is counted once per strand pass (mapping.cpp:230-233)
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
@@ -609,10 +616,9 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
     const bool valid = i < count;
     const uint32_t r = valid ? defer_list[i] : 0;
     uint32_t len;
-    Stamps st;
-    st.buf = nullptr;
-    se_process<NW, true>(iv, sh, si, bases, offsets, err, r, valid, strand_base, max_mm, b, out, nullptr, nullptr,
-                         ctr, len, 0u, st);
+    StampsT<false> st;
+    se_process<NW, true, false>(iv, sh, si, bases, offsets, err, r, valid, strand_base, max_mm, b, out, nullptr,
+                                nullptr, ctr, len, 0u, st);
   }
   flush_counters(ctr, 0, stats);
 }
@@ -642,12 +648,21 @@ static int launch_map_se(const walt_index* idx, const uint8_t* bases, const uint
   const uint32_t win_words = stage_win_words(max_read_len);
   const size_t lds = stage_lds_bytes(max_read_len);
   if (lds + sizeof(BlockShared) > 160 * 1024) return fail(WALT_EINVAL, "read length too large for the LDS staging window");
-  if (lds > 32 * 1024)
-    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_map_se<NW>),
+  const bool diag = g_ablate != 0 || g_stamps != nullptr;  // diagnostic instantiation (stamps / ablation)
+  if (lds > 32 * 1024) {
+    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_map_se<NW, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_map_se<NW>, dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err, win_words,
-                     n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate,
-                     g_stamps);
+    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_map_se<NW, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  if (diag)
+    hipLaunchKernelGGL((k_map_se<NW, true>), dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err,
+                       win_words, n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list,
+                       g_ablate, g_stamps);
+  else
+    hipLaunchKernelGGL((k_map_se<NW, false>), dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err,
+                       win_words, n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list,
+                       0u, nullptr);
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
