@@ -113,16 +113,18 @@ __device__ __forceinline__ void lane_read_global(LaneRead<NW>& lr, const uint8_t
   if (bad) atomicAdd(err, 1u);
 }
 
-// Stage this wave's reads [r, r + 63] and fill lr.  `valid` lanes have r < n.
+// Stage this wave's reads [r, r + 63] and fill lr.  `valid` lanes have r < n;
+// (o, oe) are this lane's offsets[r], offsets[r + 1] (prefetched by the caller
+// one chunk ahead); total = offsets[n] bounds the 16-byte loads.
+constexpr uint32_t kStageBatch = 8;  // 16-byte loads a lane keeps in flight while staging
+
 template <int NW>
-__device__ __forceinline__ void wave_load_reads(LaneRead<NW>& lr, const uint8_t* __restrict__ bases,
-                                                const uint64_t* __restrict__ offsets, uint32_t r, bool valid,
-                                                uint32_t ga, uint32_t* lds_wave, uint32_t win_words,
+__device__ __forceinline__ void wave_load_reads(LaneRead<NW>& lr, const uint8_t* __restrict__ bases, uint64_t o,
+                                                uint64_t oe, uint64_t total, bool valid, uint32_t ga,
+                                                uint32_t* lds_wave, uint32_t win_words,
                                                 uint32_t* __restrict__ err) {
   const uint32_t lane = threadIdx.x & 63;
-  uint64_t o = 0, oe = 0;
-  if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
-  uint64_t len64 = oe - o;
+  uint64_t len64 = valid ? oe - o : 0;
   if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
   lr.len = (uint32_t)len64;
   lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
@@ -151,28 +153,42 @@ __device__ __forceinline__ void wave_load_reads(LaneRead<NW>& lr, const uint8_t*
   const uint32_t nwin = (span + 15) / 16;
   uint32_t* codes = lds_wave;
   uint32_t* inval = lds_wave + win_words + 2;
-  for (uint32_t i = lane; i < nwin; i += 64) {
-    uint4 q;
-    if (16 * i + 16 <= span) {
-      q = *reinterpret_cast<const uint4*>(bases + a0 + 16 * (uint64_t)i);
-    } else {
-      uint32_t t[4] = {0, 0, 0, 0};
-      for (uint32_t k = 16 * i; k < span; ++k) t[(k & 15) >> 2] |= (uint32_t)bases[a0 + k] << (8 * (k & 3));
-      q = make_uint4(t[0], t[1], t[2], t[3]);
-    }
-    const uint32_t qs[4] = {q.x, q.y, q.z, q.w};
-    uint32_t c = 0, bad = 0;
+  for (uint32_t base = 0; base < nwin; base += 64 * kStageBatch) {
+    uint4 q[kStageBatch];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t code = base_code((uint8_t)(qs[j] >> (8 * k)));
-        c |= (code & 3u) << (2 * (4 * j + k));
-        bad |= (code > 3 ? 1u : 0u) << (4 * j + k);
+    for (uint32_t j = 0; j < kStageBatch; ++j) {  // all loads of the batch are issued before any is used
+      const uint32_t i = base + 64 * j + lane;
+      q[j] = make_uint4(0, 0, 0, 0);
+      if (i < nwin) {
+        if (a0 + 16ull * i + 16 <= total) {
+          q[j] = *reinterpret_cast<const uint4*>(bases + a0 + 16 * (uint64_t)i);
+        } else {  // last bytes of the whole buffer
+          uint32_t t[4] = {0, 0, 0, 0};
+          for (uint64_t k = a0 + 16ull * i; k < total; ++k) t[(k & 15) >> 2] |= (uint32_t)bases[k] << (8 * (k & 3));
+          q[j] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
       }
     }
-    codes[i] = c;
-    inval[i] = bad;
+#pragma unroll
+    for (uint32_t j = 0; j < kStageBatch; ++j) {
+      const uint32_t i = base + 64 * j + lane;
+      if (i < nwin) {
+        const uint32_t qs[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+        uint32_t c = 0, bad = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t code = base_code((uint8_t)(qs[jj] >> (8 * k)));
+            c |= (code & 3u) << (2 * (4 * jj + k));
+            bad |= (code > 3 ? 1u : 0u) << (4 * jj + k);
+          }
+        }
+        // bytes of this window that lie beyond the wave's reads are not part of any read of this wave
+        codes[i] = c;
+        inval[i] = bad;
+      }
+    }
   }
   if (lane < 2) { codes[nwin + lane] = 0; inval[nwin + lane] = 0; }
   // LDS writes of this wave -> reads by other lanes of the same wave

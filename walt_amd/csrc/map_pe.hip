@@ -30,7 +30,7 @@ template <int NW, bool LITERAL>
 __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
                                            const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
                                            uint32_t* __restrict__ err, uint32_t* lds_wave, uint32_t win_words,
-                                           uint32_t r,
+                                           uint64_t total_bytes, uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            uint32_t top_k, HeapEnt* __restrict__ heaps,
                                            uint32_t* __restrict__ heap_n, uint32_t* __restrict__ defer_count,
@@ -47,7 +47,9 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
     lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
     lane_read_global<NW>(lr, bases, o, lr.len, ga, err);
   } else {
-    wave_load_reads<NW>(lr, bases, offsets, r, valid, ga, lds_wave, win_words, err);
+    uint64_t o = 0, oe = 0;
+    if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
+    wave_load_reads<NW>(lr, bases, o, oe, total_bytes, valid, ga, lds_wave, win_words, err);
   }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint8_t*
   uint32_t* lds_wave = dyn_lds + (threadIdx.x >> 6) * stage_words_per_wave(win_words);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   uint32_t n_probe = 0, n_verified = 0, n_big = 0, shortv = 0;
+  const uint64_t total_bytes = offsets[n];
   // each block walks its own contiguous slice of the batch (consecutive 256-read
   // chunks share pages: a strided assignment made every load a TLB miss)
   const uint64_t chunks = ((uint64_t)n + blockDim.x - 1) / blockDim.x;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint8_t*
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    pe_process<NW, false>(iv, sh, si, bases, offsets, err, lds_wave, win_words, r, valid, strand_base, max_mm, b,
+    pe_process<NW, false>(iv, sh, si, bases, offsets, err, lds_wave, win_words, total_bytes, r, valid, strand_base, max_mm, b,
                           top_k, heaps, heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
     // paired.cpp:112-115: too_short once per strand pass
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const 
     const bool valid = i < count;
     const uint32_t r = valid ? defer_list[i] : 0;
     uint32_t len;
-    pe_process<NW, true>(iv, sh, si, bases, offsets, err, nullptr, 0u, r, valid, strand_base, max_mm, b, top_k,
+    pe_process<NW, true>(iv, sh, si, bases, offsets, err, nullptr, 0u, 0ull, r, valid, strand_base, max_mm, b, top_k,
                          heaps, heap_n, nullptr, nullptr, n_probe, n_verified, n_big, len);
   }
   pe_flush(0, n_probe, n_verified, n_big, stats);

@@ -314,8 +314,8 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const uint
 
 template <int NW, bool DIAG>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si,
-                                                const uint8_t* __restrict__ bases,
-                                                const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
+                                                const uint8_t* __restrict__ bases, uint64_t o_read,
+                                                uint64_t oe_read, uint64_t total_bytes, uint32_t* __restrict__ err,
                                                 uint32_t* lds_wave, uint32_t win_words, uint32_t r,
                                                 bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                                 BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
@@ -329,7 +329,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
   const StrandView& svm = iv.s[strand_base + 1];
   const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
   LaneRead<NW> lr;
-  wave_load_reads<NW>(lr, bases, offsets, r, valid, ga, lds_wave, win_words, err);
+  wave_load_reads<NW>(lr, bases, o_read, oe_read, total_bytes, valid, ga, lds_wave, win_words, err);
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
@@ -582,13 +582,25 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
   const uint64_t per_block = (chunks + gridDim.x - 1) / gridDim.x;
   const uint64_t c_lo = (uint64_t)blockIdx.x * per_block;
   const uint64_t c_hi = c_lo + per_block < chunks ? c_lo + per_block : chunks;
+  const uint64_t total_bytes = offsets[n];
+  // this lane's read offsets are fetched one chunk ahead
+  uint64_t o_nx = 0, oe_nx = 0;
+  if (c_lo < c_hi && c_lo * blockDim.x + threadIdx.x < n) {
+    o_nx = offsets[c_lo * blockDim.x + threadIdx.x];
+    oe_nx = offsets[c_lo * blockDim.x + threadIdx.x + 1];
+  }
   for (uint64_t c = c_lo; c < c_hi; ++c) {
     const uint64_t r64 = c * blockDim.x + threadIdx.x;
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
+    const uint64_t o_cur = o_nx, oe_cur = oe_nx;
+    if (c + 1 < c_hi && r64 + blockDim.x < n) {
+      o_nx = offsets[r64 + blockDim.x];
+      oe_nx = offsets[r64 + blockDim.x + 1];
+    }
     uint32_t len;
-    se_process_dual<NW, DIAG>(iv, sh, si, bases, offsets, err, lds_wave, win_words, r, valid, strand_base, max_mm,
-                              b, out, defer_count, defer_list, ctr, len, ablate, st);
+    se_process_dual<NW, DIAG>(iv, sh, si, bases, o_cur, oe_cur, total_bytes, err, lds_wave, win_words, r, valid,
+                              strand_base, max_mm, b, out, defer_count, defer_list, ctr, len, ablate, st);
     // too_short is counted once per strand pass (mapping.cpp:230-233)
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
