@@ -71,13 +71,14 @@ struct LaneRead {
 };
 
 // ---------------------------------------------------------------------------
-// Read front-end, fused into the mapping kernels (no packed-read arrays in HBM):
-// each WAVE stages the contiguous ASCII bytes of its 64 reads as a dense 2-bit
-// array in its own slice of LDS (coalesced 16-byte loads, no block barrier), each
-// lane cuts its read out with funnel shifts and converts C->T / G->A by a bit
-// trick (mapping.cpp:142-164).  The care string of a seed shift and its directory
-// range are computed in registers (seed_query) -- the record index_core.h
-// pack_read() specifies, without the memory round trip.
+// Read front-end.  k_ascii_to_2bit streams the concatenated ASCII reads once into
+// a dense 2-bit array (base i of the byte stream at bits 2(i%16) of word i/16;
+// coalesced, ~28 VALU per 4 bytes, validity of every byte checked there).  Each
+// mapping lane then loads the NW+1 words that hold its read, aligns them with
+// funnel shifts and converts C->T / G->A by a bit trick (mapping.cpp:142-164).
+// The care string of a seed shift and its directory range are computed in
+// registers (seed_query) -- the record index_core.h pack_read() specifies,
+// without ever storing it.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t convert_word(uint32_t x, uint32_t ga) {
   const uint32_t lo = x & 0x55555555u;
@@ -85,138 +86,51 @@ __device__ __forceinline__ uint32_t convert_word(uint32_t x, uint32_t ga) {
   return ga ? (x & (0x55555555u | (lo << 1))) : (x | (lo << 1));
 }
 
-// dynamic LDS: per wave [codes: win_words + 2][inval: win_words + 2]
-__device__ __forceinline__ uint32_t stage_words_per_wave(uint32_t win_words) { return 2 * (win_words + 2); }
-inline uint32_t stage_win_words(uint32_t max_read_len) { return (64 * max_read_len + 16 + 15) / 16; }
-inline size_t stage_lds_bytes(uint32_t max_read_len) {
-  return (size_t)(kBlock / 64) * 2 * (stage_win_words(max_read_len) + 2) * sizeof(uint32_t);
+// 4 ASCII bases in a word -> 4 two-bit codes in bits 0..7 and a 4-bit "not ACGT" mask.
+// code = ((c >> 1) ^ (c >> 2)) & 3 maps A,C,G,T to 0,1,2,3; validity by rebuilding the
+// letter from the code (0x41 + 2 lo + 6 hi + 11 (lo & hi)) and comparing.
+__device__ __forceinline__ void ascii4_to_codes(uint32_t w, uint32_t& codes8, uint32_t& bad4) {
+  const uint32_t x = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
+  uint32_t y = x | (x >> 6);
+  y |= y >> 12;
+  codes8 = y & 0xFFu;
+  const uint32_t lo = x & 0x01010101u, hi = (x >> 1) & 0x01010101u, both = lo & hi;
+  const uint32_t expect = 0x41414141u + (lo << 1) + (hi << 2) + (hi << 1) + (both << 3) + (both << 1) + both;
+  const uint32_t z = expect ^ w;
+  uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;  // bit 7 of each differing byte
+  nz >>= 7;
+  uint32_t t = nz | (nz >> 7);
+  t |= t >> 14;
+  bad4 = t & 0xFu;
 }
 
-// slow path: a lane packs its own read straight from HBM (literal pass, odd layouts)
+// `valid` lanes load the read at byte offset o (length len <= 16 NW) of the dense array
 template <int NW>
-__device__ __forceinline__ void lane_read_global(LaneRead<NW>& lr, const uint8_t* __restrict__ bases, uint64_t o,
-                                                 uint32_t len, uint32_t ga, uint32_t* __restrict__ err) {
-  bool bad = false;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {  // static w: rd[] stays in registers
-    uint32_t v = 0;
-    if (16u * w < len) {
-#pragma unroll 1
-      for (uint32_t k = 0; k < 16 && 16u * w + k < len; ++k) {
-        uint32_t c = base_code(bases[o + 16u * w + k]);
-        if (c > 3) { bad = true; c = 0; }
-        v |= c << (2 * k);
-      }
-    }
-    lr.rd[w] = convert_word(v, ga);
-  }
-  if (bad) atomicAdd(err, 1u);
-}
-
-// Stage this wave's reads [r, r + 63] and fill lr.  `valid` lanes have r < n;
-// (o, oe) are this lane's offsets[r], offsets[r + 1] (prefetched by the caller
-// one chunk ahead); total = offsets[n] bounds the 16-byte loads.
-constexpr uint32_t kStageBatch = 8;  // 16-byte loads a lane keeps in flight while staging
-
-template <int NW>
-__device__ __forceinline__ void wave_load_reads(LaneRead<NW>& lr, const uint8_t* __restrict__ bases, uint64_t o,
-                                                uint64_t oe, uint64_t total, bool valid, uint32_t ga,
-                                                uint32_t* lds_wave, uint32_t win_words,
-                                                uint32_t* __restrict__ err) {
-  const uint32_t lane = threadIdx.x & 63;
+__device__ __forceinline__ void lane_load_read(LaneRead<NW>& lr, const uint32_t* __restrict__ codes2, uint64_t o0,
+                                               uint64_t o, uint64_t oe, bool valid, uint32_t ga,
+                                               uint32_t* __restrict__ err) {
   uint64_t len64 = valid ? oe - o : 0;
   if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
   lr.len = (uint32_t)len64;
   lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
-  // wave-uniform window [a0, o1): first valid lane's start .. last valid lane's end
-  const unsigned long long vm = __ballot(valid);
-  if (vm == 0) {
+  const uint64_t rel = valid ? o - o0 : 0;  // dense array starts at the first read of the batch
+  const uint32_t* p = codes2 + (rel >> 4);
+  const uint32_t sh = 2 * (uint32_t)(rel & 15);
+  uint32_t raw[NW + 1];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) lr.rd[w] = 0;
-    return;
-  }
-  const int last = 63 - (int)__clzll((long long)vm);
-  const uint64_t o0 = ((uint64_t)bcast((uint32_t)(o >> 32), 0) << 32) | bcast((uint32_t)o, 0);
-  const uint64_t o1 = ((uint64_t)bcast((uint32_t)(oe >> 32), last) << 32) | bcast((uint32_t)oe, last);
-  const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(bases) + o0) & 15);
-  const bool use_lds = mis <= o0 && (o1 - (o0 - mis)) <= 16ull * win_words;
-  if (!use_lds) {
-    if (valid) lane_read_global<NW>(lr, bases, o, lr.len, ga, err);
-    else {
-#pragma unroll
-      for (int w = 0; w < NW; ++w) lr.rd[w] = 0;
-    }
-    return;
-  }
-  const uint64_t a0 = o0 - mis;
-  const uint32_t span = (uint32_t)(o1 - a0);
-  const uint32_t nwin = (span + 15) / 16;
-  uint32_t* codes = lds_wave;
-  uint32_t* inval = lds_wave + win_words + 2;
-  for (uint32_t base = 0; base < nwin; base += 64 * kStageBatch) {
-    uint4 q[kStageBatch];
-#pragma unroll
-    for (uint32_t j = 0; j < kStageBatch; ++j) {  // all loads of the batch are issued before any is used
-      const uint32_t i = base + 64 * j + lane;
-      q[j] = make_uint4(0, 0, 0, 0);
-      if (i < nwin) {
-        if (a0 + 16ull * i + 16 <= total) {
-          q[j] = *reinterpret_cast<const uint4*>(bases + a0 + 16 * (uint64_t)i);
-        } else {  // last bytes of the whole buffer
-          uint32_t t[4] = {0, 0, 0, 0};
-          for (uint64_t k = a0 + 16ull * i; k < total; ++k) t[(k & 15) >> 2] |= (uint32_t)bases[k] << (8 * (k & 3));
-          q[j] = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-      }
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < kStageBatch; ++j) {
-      const uint32_t i = base + 64 * j + lane;
-      if (i < nwin) {
-        const uint32_t qs[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-        uint32_t c = 0, bad = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t code = base_code((uint8_t)(qs[jj] >> (8 * k)));
-            c |= (code & 3u) << (2 * (4 * jj + k));
-            bad |= (code > 3 ? 1u : 0u) << (4 * jj + k);
-          }
-        }
-        // bytes of this window that lie beyond the wave's reads are not part of any read of this wave
-        codes[i] = c;
-        inval[i] = bad;
-      }
-    }
-  }
-  if (lane < 2) { codes[nwin + lane] = 0; inval[nwin + lane] = 0; }
-  // LDS writes of this wave -> reads by other lanes of the same wave
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  const uint32_t off = valid ? (uint32_t)(o - a0) : 0u;
-  const uint32_t wi0 = off >> 4, sh = 2 * (off & 15);
-  uint32_t bad = 0;
+  for (int w = 0; w <= NW; ++w) raw[w] = (16u * w < lr.len + 16u) ? p[w] : 0u;  // never past the array's slack
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
-    uint32_t v = 0, ivb = 0;
-    if (16u * w < lr.len) {
-      v = funnel_r(codes[wi0 + w], codes[wi0 + w + 1], sh);
-      ivb = (inval[wi0 + w] >> (off & 15)) | (inval[wi0 + w + 1] << (16 - (off & 15)));
-      const uint32_t nb = lr.len - 16u * w;
-      if (nb < 16) { v &= (1u << (2 * nb)) - 1u; ivb &= (1u << nb) - 1u; }
-      ivb &= 0xFFFFu;
-    }
-    bad |= ivb;
+    uint32_t v = funnel_r(raw[w], raw[w + 1], sh);
+    const uint32_t nb = lr.len > 16u * w ? lr.len - 16u * w : 0u;
+    v = nb >= 16 ? v : (nb ? v & ((1u << (2 * nb)) - 1u) : 0u);
     lr.rd[w] = convert_word(v, ga);
   }
-  if (bad) atomicAdd(err, 1u);
-  // the next staging of this wave must not overtake these reads
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
 }
+
+void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t* d_codes2,
+                          uint32_t* d_err, hipStream_t stream);
+inline uint64_t codes2_words(uint64_t total_bytes) { return total_bytes / 16 + 4; }
 
 // Care string (chars at read offsets seed_i + 1 + 3 i, MSB first) of a seed shift
 // and its directory range, from the packed read in registers.  The prefix code is

@@ -28,9 +28,8 @@ constexpr uint32_t kPeChunk = 1u << 21;  // pairs processed per workspace pass
 // BAD bucket, pass 2 maps them from scratch (their heap restarts empty).
 template <int NW, bool LITERAL>
 __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
-                                           const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
-                                           uint32_t* __restrict__ err, uint32_t* lds_wave, uint32_t win_words,
-                                           uint64_t total_bytes, uint32_t r,
+                                           const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets,
+                                           uint32_t* __restrict__ err, uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            uint32_t top_k, HeapEnt* __restrict__ heaps,
                                            uint32_t* __restrict__ heap_n, uint32_t* __restrict__ defer_count,
@@ -40,16 +39,10 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
   LaneRead<NW> lr;
-  if (LITERAL) {
+  {
     uint64_t o = 0, oe = 0;
     if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
-    lr.len = (oe - o) > 16ull * NW ? 0u : (uint32_t)(oe - o);
-    lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
-    lane_read_global<NW>(lr, bases, o, lr.len, ga, err);
-  } else {
-    uint64_t o = 0, oe = 0;
-    if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
-    wave_load_reads<NW>(lr, bases, o, oe, total_bytes, valid, ga, lds_wave, win_words, err);
+    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err);
   }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
@@ -162,9 +155,9 @@ __device__ __forceinline__ void pe_flush(uint32_t shortv, uint32_t n_probe, uint
 }
 
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t* __restrict__ codes2,
                                                      const uint64_t* __restrict__ offsets,
-                                                     uint32_t* __restrict__ err, uint32_t win_words, uint32_t n,
+                                                     uint32_t* __restrict__ err, uint32_t n,
                                                      uint32_t strand_base,
                                                      uint32_t max_mm, uint32_t b, uint32_t top_k,
                                                      const uint32_t* __restrict__ mask_table,
@@ -173,11 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint8_t*
                                                      uint32_t* __restrict__ defer_count,
                                                      uint32_t* __restrict__ defer_list) {
   __shared__ BlockShared sh;
-  extern __shared__ uint32_t dyn_lds[];
-  uint32_t* lds_wave = dyn_lds + (threadIdx.x >> 6) * stage_words_per_wave(win_words);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   uint32_t n_probe = 0, n_verified = 0, n_big = 0, shortv = 0;
-  const uint64_t total_bytes = offsets[n];
   // each block walks its own contiguous slice of the batch (consecutive 256-read
   // chunks share pages: a strided assignment made every load a TLB miss)
   const uint64_t chunks = ((uint64_t)n + blockDim.x - 1) / blockDim.x;
@@ -189,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint8_t*
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    pe_process<NW, false>(iv, sh, si, bases, offsets, err, lds_wave, win_words, total_bytes, r, valid, strand_base, max_mm, b,
+    pe_process<NW, false>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b,
                           top_k, heaps, heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
     // paired.cpp:112-115: too_short once per strand pass
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
@@ -198,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint8_t*
 }
 
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const uint32_t* __restrict__ codes2,
                                                              const uint64_t* __restrict__ offsets,
                                                              uint32_t* __restrict__ err, uint32_t strand_base,
                                                              uint32_t max_mm,
@@ -218,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const 
     const bool valid = i < count;
     const uint32_t r = valid ? defer_list[i] : 0;
     uint32_t len;
-    pe_process<NW, true>(iv, sh, si, bases, offsets, err, nullptr, 0u, 0ull, r, valid, strand_base, max_mm, b, top_k,
+    pe_process<NW, true>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k,
                          heaps, heap_n, nullptr, nullptr, n_probe, n_verified, n_big, len);
   }
   pe_flush(0, n_probe, n_verified, n_big, stats);
@@ -264,12 +254,13 @@ struct PeWorkspace {
   HeapEnt* heaps[2];
   uint32_t* heap_n[2];
   uint32_t* defer_list[2];
+  uint32_t* codes2[2];
   Candidate* ranked[2];
   uint64_t stride;
   uint64_t total_bytes;
 };
 
-static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) {
+static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, uint32_t max_read_len) {
   PeWorkspace w;
   uint8_t* p = reinterpret_cast<uint8_t*>(base);
   uint64_t off = 0;
@@ -284,30 +275,25 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k) 
   for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
   for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
   for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take(2 * w.stride * 4 + 64));
+  for (int m = 0; m < 2; ++m) w.codes2[m] = reinterpret_cast<uint32_t*>(take(codes2_words((uint64_t)chunk * max_read_len) * 4 + 64));
   for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
   w.total_bytes = off;
   return w;
 }
 
 template <int NW>
-static int launch_pe_topk(const walt_index* idx, const uint8_t* bases, const uint64_t* offsets, uint32_t* err,
-                          uint32_t max_read_len, uint64_t stride, uint32_t n, uint32_t sb,
+static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
+                          uint64_t stride, uint32_t n, uint32_t sb,
                           uint32_t max_mm, uint32_t b, uint32_t top_k, HeapEnt* heaps, uint32_t* heap_n,
                           unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
                           hipStream_t stream) {
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
-  const uint32_t win_words = stage_win_words(max_read_len);
-  const size_t lds = stage_lds_bytes(max_read_len);
-  if (lds + sizeof(BlockShared) > 160 * 1024) return fail(WALT_EINVAL, "read length too large for the LDS staging window");
-  if (lds > 32 * 1024)
-    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_topk<NW>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err, win_words, n,
+  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
                      sb, max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
   uint32_t* defer_sorted = defer_list + stride;  // second half of the list area
   launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   unsigned g2 = grid_for(n) < 1024u ? grid_for(n) : 1024u;
-  hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, bases, offsets, err, sb,
+  hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_sorted);
   return WALT_OK;
 }
@@ -327,12 +313,13 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;
     uint32_t* ctl = w.err + 64 + 32 * m;
+    launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], w.err, stream);
     int rc;
     switch (nw) {
-      case 8: rc = launch_pe_topk<8>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
-      case 16: rc = launch_pe_topk<16>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
-      case 32: rc = launch_pe_topk<32>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
-      default: rc = launch_pe_topk<64>(idx, bases[m], offs[m], w.err, max_read_len, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
     }
     if (rc) return rc;
     launch_reduce_stats(w.shards[m], d_stats + 4 * m, stream);
@@ -365,7 +352,7 @@ size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
   uint32_t chunk = n < kPeChunk ? n : kPeChunk;
-  return (size_t)carve_pe(nullptr, chunk, nw, top_k).total_bytes;
+  return (size_t)carve_pe(nullptr, chunk, nw, top_k, max_read_len).total_bytes;
 }
 
 int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* d_offsets1, const void* d_bases2,
@@ -379,7 +366,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WALT_HIP(hipSetDevice(idx->device));
   const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
-  PeWorkspace w = carve_pe(d_workspace, chunk, nw, top_k);
+  PeWorkspace w = carve_pe(d_workspace, chunk, nw, top_k, max_read_len);
   WALT_HIP(hipMemsetAsync(w.err, 0, 128 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) WALT_HIP(hipMemsetAsync(w.shards[m], 0, kStatShardBytes, stream));
   for (uint32_t start = 0; start < n; start += chunk) {
@@ -430,7 +417,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     e = hipMemcpy(d_off[m], rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
   }
   const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
-  const size_t ws_bytes = carve_pe(nullptr, chunk, nw, top_k).total_bytes;
+  const size_t ws_bytes = carve_pe(nullptr, chunk, nw, top_k, max_len).total_bytes;
   if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * sizeof(walt_pair_result));
   if (e == hipSuccess) e = hipMalloc(&d_stats, 2 * sizeof(walt_batch_stats));
   if (e == hipSuccess) e = hipMalloc(&d_ws, ws_bytes);
@@ -439,7 +426,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     cleanup();
     return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
   }
-  PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k);
+  PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k, max_len);
   hipMemset(w.err, 0, 128 * sizeof(uint32_t));
   for (int m = 0; m < 2; ++m) hipMemset(w.shards[m], 0, kStatShardBytes);
   for (uint32_t start = 0; start < n && !rc; start += chunk) {

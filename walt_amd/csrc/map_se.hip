@@ -19,6 +19,51 @@
 
 namespace walt {
 
+// ASCII -> dense 2-bit array (map_common.h).  The byte stream is offsets[0] ..
+// offsets[n]; thread t converts bytes [16 t, 16 t + 16) of it.  err[0] counts reads
+// ... bytes that are not ACGT (getBits would exit, util.hpp:117-119).
+static __global__ __launch_bounds__(kBlock) void k_ascii_to_2bit(const uint8_t* __restrict__ bases,
+                                                                  const uint64_t* __restrict__ offsets, uint32_t n,
+                                                                  uint32_t* __restrict__ codes2,
+                                                                  uint32_t* __restrict__ err) {
+  const uint64_t o0 = offsets[0], total = offsets[n] - o0;
+  const uint8_t* src = bases + o0;
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15);  // 16-byte loads need an aligned address
+  const uint64_t nwords = (total + 15) / 16;
+  uint32_t bad_total = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t qs[4] = {0, 0, 0, 0};
+    const uint64_t b0 = 16 * i;
+    if (mis == 0 && b0 + 16 <= total) {
+      const uint4 q = *reinterpret_cast<const uint4*>(src + b0);
+      qs[0] = q.x; qs[1] = q.y; qs[2] = q.z; qs[3] = q.w;
+    } else {
+      for (uint64_t k = b0; k < b0 + 16; ++k) {
+        const uint32_t c = k < total ? src[k] : 0x41u;  // pad with 'A' (never part of a read)
+        qs[(k - b0) >> 2] |= c << (8 * (k & 3));
+      }
+    }
+    uint32_t word = 0, bad = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t c8, b4;
+      ascii4_to_codes(qs[j], c8, b4);
+      word |= c8 << (8 * j);
+      bad |= b4;
+    }
+    codes2[i] = word;
+    bad_total += bad ? 1u : 0u;
+  }
+  bad_total = wave_sum_u32(bad_total);
+  if ((threadIdx.x & 63) == 0 && bad_total) atomicAdd(err, bad_total);
+  if (blockIdx.x == 0 && threadIdx.x < 4) codes2[nwords + threadIdx.x] = 0;  // slack read by the last lanes
+}
+void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t* d_codes2,
+                          uint32_t* d_err, hipStream_t stream) {
+  hipLaunchKernelGGL(k_ascii_to_2bit, dim3(256 * 16), dim3(kBlock), 0, stream, d_bases, d_offsets, n, d_codes2, d_err);
+}
+
 // ---------------------------------------------------------------------------
 // Wave-cooperative verification of one large region owned by lane `owner`.
 // All 64 lanes call this with the same (uniform) arguments broadcast from the
@@ -105,7 +150,7 @@ struct MapCounters {
 
 template <int NW, bool LITERAL, bool DIAG>
 __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
-                                           const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets,
+                                           const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets,
                                            uint32_t* __restrict__ err, uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                            BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
@@ -119,9 +164,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
   {
     uint64_t o = 0, oe = 0;
     if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
-    lr.len = (oe - o) > 16ull * NW ? 0u : (uint32_t)(oe - o);
-    lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
-    lane_read_global<NW>(lr, bases, o, lr.len, ga, err);
+    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err);
   }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
@@ -314,9 +357,9 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const uint
 
 template <int NW, bool DIAG>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si,
-                                                const uint8_t* __restrict__ bases, uint64_t o_read,
-                                                uint64_t oe_read, uint64_t total_bytes, uint32_t* __restrict__ err,
-                                                uint32_t* lds_wave, uint32_t win_words, uint32_t r,
+                                                const uint32_t* __restrict__ codes2, uint64_t o_first,
+                                                uint64_t o_read, uint64_t oe_read, uint32_t* __restrict__ err,
+                                                uint32_t r,
                                                 bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                                 BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
                                                 uint32_t* __restrict__ defer_list, MapCounters& ctr,
@@ -329,7 +372,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
   const StrandView& svm = iv.s[strand_base + 1];
   const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
   LaneRead<NW> lr;
-  wave_load_reads<NW>(lr, bases, o_read, oe_read, total_bytes, valid, ga, lds_wave, win_words, err);
+  lane_load_read<NW>(lr, codes2, o_first, o_read, oe_read, valid, ga, err);
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
@@ -555,9 +598,9 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 
 // pass 1: every read of the batch, one per lane
 template <int NW, bool DIAG>
-__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView iv, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
                                                     const uint64_t* __restrict__ offsets,
-                                                    uint32_t* __restrict__ err, uint32_t win_words,
+                                                    uint32_t* __restrict__ err,
                                                     uint32_t n, uint32_t strand_base,
                                                     uint32_t max_mm, uint32_t b,
                                                     const uint32_t* __restrict__ mask_table,
@@ -567,8 +610,6 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
                                                     uint32_t* __restrict__ defer_list, uint32_t ablate,
                                                     unsigned long long* __restrict__ stamps) {
   __shared__ BlockShared sh;
-  extern __shared__ uint32_t dyn_lds[];
-  uint32_t* lds_wave = dyn_lds + (threadIdx.x >> 6) * stage_words_per_wave(win_words);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   // persistent blocks: the LDS prologue (mask table, chromosome starts, Bloom
   // filters: ~25 KB) is paid once per block, not once per 256 reads
@@ -582,7 +623,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
   const uint64_t per_block = (chunks + gridDim.x - 1) / gridDim.x;
   const uint64_t c_lo = (uint64_t)blockIdx.x * per_block;
   const uint64_t c_hi = c_lo + per_block < chunks ? c_lo + per_block : chunks;
-  const uint64_t total_bytes = offsets[n];
+  const uint64_t o_first = offsets[0];
   // this lane's read offsets are fetched one chunk ahead
   uint64_t o_nx = 0, oe_nx = 0;
   if (c_lo < c_hi && c_lo * blockDim.x + threadIdx.x < n) {
@@ -599,8 +640,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
       oe_nx = offsets[r64 + blockDim.x + 1];
     }
     uint32_t len;
-    se_process_dual<NW, DIAG>(iv, sh, si, bases, o_cur, oe_cur, total_bytes, err, lds_wave, win_words, r, valid,
-                              strand_base, max_mm, b, out, defer_count, defer_list, ctr, len, ablate, st);
+    se_process_dual<NW, DIAG>(iv, sh, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
+                              out, defer_count, defer_list, ctr, len, ablate, st);
     // too_short is counted once per strand pass (mapping.cpp:230-233)
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
@@ -610,7 +651,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView 
 
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
                                                             const uint64_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ err, uint32_t strand_base,
                                                             uint32_t max_mm,
@@ -629,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
     const uint32_t r = valid ? defer_list[i] : 0;
     uint32_t len;
     StampsT<false> st;
-    se_process<NW, true, false>(iv, sh, si, bases, offsets, err, r, valid, strand_base, max_mm, b, out, nullptr,
+    se_process<NW, true, false>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, out, nullptr,
                                 nullptr, ctr, len, 0u, st);
   }
   flush_counters(ctr, 0, stats);
@@ -650,36 +691,26 @@ static unsigned long long* g_stamps = nullptr;  // WALT_AMD_STAMPS=1: device buf
 constexpr unsigned kLiteralGrid = 1024;  // blocks of the deferred-read pass (grid-stride)
 
 template <int NW>
-static int launch_map_se(const walt_index* idx, const uint8_t* bases, const uint64_t* offsets, uint32_t* err,
-                         uint32_t max_read_len, uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b,
-                         BestMatch* out, unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
-                         uint64_t stride, hipStream_t stream) {
+static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
+                         uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
+                         unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
+                         hipStream_t stream) {
   unsigned pg = kPersistentGrid;
   if (const char* e = getenv("WALT_AMD_GRID")) pg = atoi(e) > 0 ? (unsigned)atoi(e) : grid_for(n);  // diagnostic knob
   const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
-  const uint32_t win_words = stage_win_words(max_read_len);
-  const size_t lds = stage_lds_bytes(max_read_len);
-  if (lds + sizeof(BlockShared) > 160 * 1024) return fail(WALT_EINVAL, "read length too large for the LDS staging window");
   const bool diag = g_ablate != 0 || g_stamps != nullptr;  // diagnostic instantiation (stamps / ablation)
-  if (lds > 32 * 1024) {
-    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_map_se<NW, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    WALT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_map_se<NW, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
   if (diag)
-    hipLaunchKernelGGL((k_map_se<NW, true>), dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err,
-                       win_words, n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list,
-                       g_ablate, g_stamps);
+    hipLaunchKernelGGL((k_map_se<NW, true>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate,
+                       g_stamps);
   else
-    hipLaunchKernelGGL((k_map_se<NW, false>), dim3(g1), dim3(kBlock), lds, stream, idx->view, bases, offsets, err,
-                       win_words, n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list,
-                       0u, nullptr);
+    hipLaunchKernelGGL((k_map_se<NW, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, nullptr);
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
-  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, bases, offsets, err,
+  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted);
   return WALT_OK;
 }
@@ -705,26 +736,27 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
   WALT_HIP(hipSetDevice(idx->device));
   const uint64_t stride = se_stride(n);
-  // workspace: [64 words: read errors, deferral control] [statistic shards] [deferred list] [sorted deferred list]
+  // workspace: [64 words: read errors, deferral control] [statistic shards] [deferred list] [sorted deferred
+  // list] [dense 2-bit reads]
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   unsigned long long* shards = reinterpret_cast<unsigned long long*>(err + 64);
   uint32_t* defer_count = err + 32;  // control block: [0] count, [8..15] bin counts, [16..23] bin cursors
   uint32_t* defer_list = err + 64 + kStatShardBytes / 4;
+  uint32_t* codes2 = defer_list + 2 * stride;
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
-  if (idx->profile) {
-    WALT_HIP(hipEventRecord(idx->ev[0], stream));
-    WALT_HIP(hipEventRecord(idx->ev[1], stream));  // read packing is fused into the mapping kernel
-  }
   const uint8_t* bases = reinterpret_cast<const uint8_t*>(d_bases);
   const uint64_t* offsets = reinterpret_cast<const uint64_t*>(d_offsets);
+  if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
+  launch_ascii_to_2bit(bases, offsets, n, codes2, err, stream);
+  if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[1], stream));
   BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
   const uint32_t sb = ag ? 2u : 0u;
   int rc;
   switch (nw) {
-    case 8: rc = launch_map_se<8>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 16: rc = launch_map_se<16>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 32: rc = launch_map_se<32>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    default: rc = launch_map_se<64>(idx, bases, offsets, err, max_read_len, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 8: rc = launch_map_se<8>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 16: rc = launch_map_se<16>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 32: rc = launch_map_se<32>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    default: rc = launch_map_se<64>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
   }
   if (rc) return rc;
   launch_reduce_stats(shards, reinterpret_cast<unsigned long long*>(d_stats), stream);
@@ -786,7 +818,8 @@ size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
   (void)nw;
-  return 64 * sizeof(uint32_t) + kStatShardBytes + 2 * se_stride(n) * sizeof(uint32_t);
+  return 64 * sizeof(uint32_t) + kStatShardBytes + 2 * se_stride(n) * sizeof(uint32_t) +
+         codes2_words((uint64_t)n * max_read_len) * sizeof(uint32_t);
 }
 
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
