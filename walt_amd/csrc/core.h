@@ -275,7 +275,7 @@ WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t h) {
 // 128-byte lines, in flight together) and searched in registers; the positions
 // of the first kSmallRegion candidates come back with them.  Longer slots fall
 // back to a binary search.
-constexpr uint32_t kScan = 6;
+constexpr uint32_t kScan = 4;
 constexpr uint32_t kLookupPos = 4;  // == kSmallRegion of the kernels
 
 // equal range [a,u] of masked key T among the sorted entries [lo,hi) by binary

@@ -316,6 +316,7 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], w.err, stream);
     int rc;
     switch (nw) {
+      case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
       case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
       case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
       case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;

@@ -287,11 +287,18 @@ struct SlotProbe {
   Ent e[kScan];         // its first entries (clamped indices, independent loads)
 };
 
+// directory pair of a probe: dir[slot] (start) and dir[slot - span] (end).  span is 1
+// for every seed of >= dir_bits code bits, so the pair is ONE 8-byte load of
+// dir[slot-1 .. slot]; short seeds (span > 1) fetch the far end separately.
 __device__ __forceinline__ void probe_issue(const StrandView& sv, bool need, uint32_t slot, uint32_t span,
                                             uint32_t& lo, uint32_t& hi) {
-  const uint32_t s0 = need ? slot : 0u, sp = need ? span : 0u;
-  lo = sv.dir[s0];
-  hi = sv.dir[s0 - sp];
+  const uint32_t s0 = need ? slot : 1u, sp = need ? span : 1u;  // slot >= 1 whenever a seed exists
+  const uint32_t* p = sv.dir + (s0 - 1);
+  uint32_t pair[2];
+  __builtin_memcpy(pair, p, 8);
+  hi = pair[0];
+  lo = pair[1];
+  if (sp != 1) hi = sv.dir[s0 - sp];
 }
 __device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p) {
 #pragma unroll
@@ -344,13 +351,21 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
 // branch-free candidate check: the genome window is always loaded (from position
 // 0 when the edge filters of mapping.cpp:280-286 reject the candidate)
 template <int NW>
-__device__ __forceinline__ void verify_nobranch(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
-                                                uint32_t top_step, bool active, uint32_t slot_pos, uint32_t seed_i,
-                                                uint32_t len, const uint32_t* rd, const uint32_t* mk, bool& ok,
-                                                uint32_t& gp, uint32_t& mm) {
-  const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, slot_pos);
+__device__ __forceinline__ void verify_nobranch(const StrandView& sv, const BlockShared& sh, const uint32_t* si,
+                                                uint32_t n_chrom, uint32_t top_step, bool active, uint32_t slot_pos,
+                                                uint32_t seed_i, uint32_t len, const uint32_t* rd,
+                                                const uint32_t* mk, bool& ok, uint32_t& gp, uint32_t& mm) {
+  // chromosome starts from LDS when they fit (ds_read), else from HBM; uniform branch
+  uint32_t c_lo, c_hi;
+  if (n_chrom <= kLdsChroms) {
+    const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, slot_pos);
+    c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
+  } else {
+    const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, slot_pos);
+    c_lo = si[chr]; c_hi = si[chr + 1];
+  }
   const uint32_t g = slot_pos - seed_i;
-  ok = active && (slot_pos - si[chr] >= seed_i) && (g + len < si[chr + 1]);
+  ok = active && (slot_pos - c_lo >= seed_i) && (g + len < c_hi);
   gp = ok ? g : 0u;
   mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
 }
@@ -447,8 +462,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
         bool ok_p, ok_m;
         uint32_t gp_p, gp_m, mm_p, mm_m;
-        verify_nobranch<NW>(svp, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
-        verify_nobranch<NW>(svm, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+        verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+        verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
         if (ok_p) { sum_p = summary_merge(sum_p, summary_one(mm_p, gp_p)); ++ctr.verified; }
         if (ok_m) { sum_m = summary_merge(sum_m, summary_one(mm_m, gp_m)); ++ctr.verified; }
       }
@@ -753,6 +768,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   const uint32_t sb = ag ? 2u : 0u;
   int rc;
   switch (nw) {
+    case 7: rc = launch_map_se<7>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 8: rc = launch_map_se<8>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 16: rc = launch_map_se<16>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 32: rc = launch_map_se<32>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
