@@ -183,9 +183,9 @@ def main():
     idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, HG19_NAMES, device=local,
                                       strands=walt_amd.STRANDS_CT, dir_bits=args.dir_bits)
     t_index = time.perf_counter() - t0
-    log("index: CT00 %d + CT01 %d entries, dir_bits %d, %.1f GB in HBM, bad buckets %d/%d (%.1f s)" % (
-        idx.index_size(0), idx.index_size(1), idx.dir_bits, idx.device_bytes / 1e9, idx.bad_buckets(0),
-        idx.bad_buckets(1), t_index))
+    log("index: CT00 %d + CT01 %d entries, dir_bits %d, %.1f GB in HBM, outliers %d/%d, bad buckets %d/%d (%.1f s)" % (
+        idx.index_size(0), idx.index_size(1), idx.dir_bits, idx.device_bytes / 1e9, idx.outliers(0),
+        idx.outliers(1), idx.bad_buckets(0), idx.bad_buckets(1), t_index))
 
     n = args.reads
     t0 = time.perf_counter()
@@ -244,6 +244,8 @@ def main():
                      "store", "total"]
             log("phase shares (s_memtime, drained at boundaries): " +
                 ", ".join("%s %.1f%%" % (nm, 100.0 * buf[i] / tot) for i, nm in enumerate(names[:8])))
+    ctl = d_ws[:64 * 4].view(torch.int32).cpu().numpy()
+    log("deferred to the literal pass: %d reads (bins %s)" % (int(ctl[32]), ctl[40:46].tolist()))
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * n * args.steps / elapsed
     if rank == 0:

@@ -108,8 +108,10 @@ const char* walt_index_chrom_name(const walt_index* idx, uint32_t i);
 uint64_t walt_index_genome_len(const walt_index* idx);
 uint64_t walt_index_device_bytes(const walt_index* idx);
 int walt_index_dir_bits(const walt_index* idx);
-/* number of 4^12 buckets that take the literal search (diagnostic), per strand */
+/* diagnostics, per strand: buckets in which EVERY probe takes the literal search (0 for a
+ * makedb-built index), and chromosome-end entries ("outliers") around which probes do */
 uint64_t walt_index_bad_buckets(const walt_index* idx, int strand);
+uint64_t walt_index_outliers(const walt_index* idx, int strand);
 
 /* ---- single-end: replaces the strand loop + omp loop over SingleEndMapping,
  *      mapping.cpp:486-500 / 224-316 ------------------------------------- */

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../walt_amd/csrc/host_common.h"
@@ -20,6 +21,7 @@ using namespace walt;
 struct HStrand {
   std::vector<uint32_t> g2, cnt, bad, dir;
   std::vector<Ent> ent;
+  std::vector<Outlier> outl;
   StrandView view;
 };
 struct HIndex {
@@ -74,18 +76,35 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
   s.cnt.assign(counter, counter + kNumBuckets + 1);
   s.bad.assign(kNumBuckets / 32, 0);
   s.ent.resize((size_t)index_size + 1);
+  const uint32_t* start = h->start.data();
+  const uint32_t n_chrom = h->view.n_chrom;
+  s.outl.clear();
   for (uint32_t j = 0; j < index_size; ++j) {
     bool t;
     if ((uint64_t)index[j] + kMinSeedLen > genome_len) return -1;
     s.ent[j] = make_ent(s.g2.data(), genome_len, index[j], t);
     uint32_t hsh = hash_at(s.g2.data(), index[j]);
     if (!(s.cnt[hsh] <= j && j < s.cnt[hsh + 1])) return -1;
-    if (t) s.bad[hsh >> 5] |= 1u << (hsh & 31);
+    const uint32_t chr = chrom_id(start, n_chrom, index[j]);
+    const uint32_t room = start[chr + 1] - index[j];
+    if (room <= care_pos(kKeyWeight + kKeyChars - 1)) {
+      Outlier o; o.h = hsh; o.q = first_beyond(room); o.key_hi = s.ent[j].key_hi; o.key_lo = s.ent[j].key_lo;
+      s.outl.push_back(o);
+    }
   }
+  std::sort(s.outl.begin(), s.outl.end(), [](const Outlier& x, const Outlier& y) { return x.h < y.h; });
   for (uint32_t j = 1; j < index_size; ++j) {
-    if (ent_key(s.ent[j - 1]) > ent_key(s.ent[j])) {
-      uint32_t ha = hash_at(s.g2.data(), s.ent[j - 1].pos), hb = hash_at(s.g2.data(), s.ent[j].pos);
-      if (ha == hb) s.bad[ha >> 5] |= 1u << (ha & 31);
+    const Ent a = s.ent[j - 1], b = s.ent[j];
+    if (ent_key(a) > ent_key(b)) {
+      uint32_t ha = hash_at(s.g2.data(), a.pos), hb = hash_at(s.g2.data(), b.pos);
+      if (ha != hb) continue;
+      const uint32_t first_diff = kKeyWeight + (uint32_t)(__builtin_clzll(ent_key(a) ^ ent_key(b)) >> 1);
+      bool explained = false;
+      for (const Ent& e : {a, b}) {
+        const uint32_t chr = chrom_id(start, n_chrom, e.pos);
+        if (first_beyond(start[chr + 1] - e.pos) <= first_diff) explained = true;
+      }
+      if (!explained) s.bad[ha >> 5] |= 1u << (ha & 31);
     }
   }
   const uint32_t Bd = h->view.dir_bits, slots = h->view.dir_slots;
@@ -99,13 +118,13 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
     if (s.dir[k - 1] < s.dir[k]) s.dir[k] = s.dir[k - 1];
   s.view.g2 = s.g2.data(); s.view.cnt = s.cnt.data(); s.view.bad = s.bad.data(); s.view.dir = s.dir.data();
   s.view.ent = s.ent.data(); s.view.index_size = index_size; s.view.genome_len = genome_len; s.view.ga = ga;
-  s.view.pad_ = 0; s.view.bloom = nullptr;
+  s.view.bloom = nullptr; s.view.outl = s.outl.data(); s.view.n_outl = (uint32_t)s.outl.size();
   h->view.s[strand] = s.view;
   h->view.start_index = h->start.data();
   h->present[strand] = true;
   long nbad = 0;
   for (uint32_t w : s.bad) nbad += __builtin_popcount(w);
-  return nbad;
+  return nbad + (long)s.outl.size();  // > 0 when the strand exercises the literal path at all
 }
 
 // test hook: force every bucket onto the literal path (or clear the flags)

@@ -107,7 +107,7 @@ def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
     any_bad = 0
     for D in (24, 26, 31):
         idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_bits=D)
-        any_bad += sum(idx.bad_buckets(s) for s in range(4))
+        any_bad += sum(idx.bad_buckets(s) + idx.outliers(s) for s in range(4))
         got, st = idx.map_se_batch(bct, oct_, ag_wildcard=False, max_mismatches=6, b=5000)
         assert_best_equal(got, want_ct, "CT D=%d" % D)
         assert int(st["too_short"]) == int(wct["too_short"])
@@ -192,3 +192,54 @@ def test_gpu_device_pointer_api_with_torch(wa, g1_db, g1_dev):
     want, work = refio.oracle_se(g1_db, seqs)
     assert_best_equal(got, want, "device api")
     assert int(d_stats[0]) == int(work["too_short"])
+
+
+def test_gpu_crowded_chromosome_ends(wa, scratch):
+    """Same stress as tests/test_harness_cpu.py::test_harness_crowded_chromosome_ends, on the device."""
+    import random as _r
+    rng = _r.Random(99)
+    unit = "".join(rng.choice("ACGT") for _ in range(600))
+    seqs = []
+    for i in range(300):
+        a = rng.randrange(0, 300)
+        L = rng.choice([38, 60, 90, 131, 150, 200, 260])
+        s = list(unit[a:a + L])
+        for _ in range(rng.randrange(0, 3)):
+            k = rng.randrange(len(s))
+            s[k] = rng.choice("ACGT")
+        seqs.append(("u%d" % i, "".join(s)))
+    seqs.append(("long", unit * 3))
+    fa = os.path.join(scratch, "crowded_gpu.fa")
+    with open(fa, "w") as f:
+        for nm, s in seqs:
+            f.write(">%s\n%s\n" % (nm, s))
+    idxp = os.path.join(scratch, "crowded_gpu.dbindex")
+    wa.makedb(fa, idxp, threads=4)
+    db = refio.DbIndex(idxp)
+    reads = []
+    for _ in range(6000):
+        L = rng.choice([38, 50, 75, 100, 140, 150])
+        a = rng.randrange(0, 600 * 3 - L)
+        s = (unit * 3)[a:a + L]
+        if rng.random() < 0.5:
+            s = refio.revcomp(s)
+        s = "".join("T" if (c == "C" and rng.random() < 0.9) else c for c in s)
+        s = "".join(rng.choice("ACGT") if rng.random() < 0.01 else c for c in s)
+        reads.append(s)
+    want, _ = refio.oracle_se(db, reads, max_mm=6, b=5000)
+    want_b, _ = refio.oracle_se(db, reads, max_mm=3, b=40)
+    bases, offs = wa.pack_reads(reads)
+    for B in (-1, 28):
+        idx = wa.Index.open(idxp, device=0, strands=wa.STRANDS_ALL, dir_bits=B)
+        assert sum(idx.outliers(s) for s in range(4)) > 100
+        got, _ = idx.map_se_batch(bases, offs, max_mismatches=6, b=5000)
+        assert_best_equal(got, want, "crowded B=%d" % B)
+        got, _ = idx.map_se_batch(bases, offs, max_mismatches=3, b=40)
+        assert_best_equal(got, want_b, "crowded b=40 B=%d" % B)
+        for k in (2, 50):
+            _, _, (g1, gn1, g2, gn2) = idx.map_pe_batch(bases, offs, bases, offs, top_k=k, want_ranked=True)
+            ro, no, _ = refio.oracle_pe_topk(db, reads, False, 6, 5000, k)
+            assert np.array_equal(gn1, no)
+            for j in range(len(reads)):
+                assert np.array_equal(g1[j][:no[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), (k, j)
+        idx.close()

@@ -143,3 +143,54 @@ def test_harness_random_genomes_vs_oracle(scratch, seed, n_chrom):
                     assert np.array_equal(r[j][:n[j]]["mismatch"], ro[j][:no[j]]["mismatch"])
         h.close()
     assert any_bad, "test genome should contain BAD (chromosome-end) buckets"
+
+
+def test_harness_crowded_chromosome_ends(scratch):
+    """Many short chromosomes cut from ONE repeated sequence: buckets are crowded with
+    chromosome-end entries ('outliers') that share long prefixes with ordinary entries,
+    which is where the key search and the literal search could disagree."""
+    rng = random.Random(99)
+    unit = "".join(rng.choice("ACGT") for _ in range(600))
+    seqs = []
+    for i in range(300):
+        a = rng.randrange(0, 300)
+        L = rng.choice([38, 60, 90, 131, 150, 200, 260])
+        s = list(unit[a:a + L])
+        for _ in range(rng.randrange(0, 3)):
+            k = rng.randrange(len(s))
+            s[k] = rng.choice("ACGT")
+        seqs.append(("u%d" % i, "".join(s)))
+    seqs.append(("long", unit * 3))
+    fa = os.path.join(scratch, "crowded.fa")
+    with open(fa, "w") as f:
+        for nm, s in seqs:
+            f.write(">%s\n%s\n" % (nm, s))
+    idxp = os.path.join(scratch, "crowded.dbindex")
+    assert refio.harness().walt_makedb(fa.encode(), idxp.encode(), 4) == 0
+    db = refio.DbIndex(idxp)
+    reads = []
+    for _ in range(3000):
+        L = rng.choice([38, 50, 75, 100, 140, 150])
+        a = rng.randrange(0, 600 * 3 - L)
+        s = (unit * 3)[a:a + L]
+        if rng.random() < 0.5:
+            s = refio.revcomp(s)
+        s = "".join("T" if (c == "C" and rng.random() < 0.9) else c for c in s)
+        s = "".join(rng.choice("ACGT") if rng.random() < 0.01 else c for c in s)
+        reads.append(s)
+    want, _ = refio.oracle_se(db, reads, max_mm=6, b=5000)
+    want_b, _ = refio.oracle_se(db, reads, max_mm=3, b=40)
+    for D in (24, 28):
+        h = refio.HarnessIndex(db, D)
+        assert sum(h.bad.values()) > 100
+        got, _ = h.map_se(reads, False, 6, 5000)
+        assert_best_equal(got, want, "crowded D=%d" % D)
+        got, _ = h.map_se(reads, False, 3, 40)
+        assert_best_equal(got, want_b, "crowded b=40 D=%d" % D)
+        for k in (2, 50):
+            r, n, _ = h.pe_topk(reads[:500], False, 6, 5000, k)
+            ro, no, _ = refio.oracle_pe_topk(db, reads[:500], False, 6, 5000, k)
+            assert np.array_equal(n, no)
+            for j in range(500):
+                assert np.array_equal(r[j][:n[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), (k, j)
+        h.close()

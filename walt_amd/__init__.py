@@ -102,6 +102,8 @@ def lib():
     L.walt_index_dir_bits.restype = ci
     L.walt_index_bad_buckets.argtypes = [vp, ci]
     L.walt_index_bad_buckets.restype = u64
+    L.walt_index_outliers.argtypes = [vp, ci]
+    L.walt_index_outliers.restype = u64
     L.walt_map_se_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, vp, vp]
     L.walt_se_workspace_bytes.argtypes = [u32, u32]
     L.walt_se_workspace_bytes.restype = c.c_size_t
@@ -271,6 +273,9 @@ class Index:
 
     def bad_buckets(self, strand):
         return lib().walt_index_bad_buckets(self._h, strand)
+
+    def outliers(self, strand):
+        return lib().walt_index_outliers(self._h, strand)
 
     # -- single-end -----------------------------------------------------------
     def map_se_batch(self, bases, offsets, ag_wildcard=False, max_mismatches=6, b=5000):

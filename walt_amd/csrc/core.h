@@ -16,12 +16,12 @@
 //          (F2CAREDPOSITION[12..43], seedpattern.hpp:424-430), char 12 in the
 //          top 2 bits.  It is what LowerBound/UpperBound (mapping.cpp:166-196)
 //          would read through genome.sequence[index[mid] + cmp_pos].
-//   bad  : bitmap over the 4^12 buckets; bit set = keys of this bucket are not
-//          non-decreasing (entries whose care positions run over a chromosome
-//          end are sorted by the "beyond the end is smallest" rule of
-//          reference.cpp:258-288 but are READ as real bytes) or touch the end of
-//          the genome.  Such buckets take the literal search; all others take
-//          the key search, which returns the same [l,u].
+//   outl : the "outlier" entries (struct Outlier below) sorted by bucket; a probe
+//          is DANGEROUS -- must take the literal search -- only when its target
+//          shares an outlier's characters 12..q-1.
+//   bad  : bitmap over the 4^12 buckets for disorder that no outlier explains
+//          (never the case for a makedb-built index): every probe into such a
+//          bucket takes the literal search.
 //   dir  : DERIVED directory over the first Bd BITS of an order-preserving
 //          prefix code of the care characters.  A converted strand has three
 //          letters, one of them half of all bases (T after C->T, A after G->A),
@@ -75,8 +75,21 @@ struct StrandView {
   uint32_t index_size;
   uint32_t genome_len;
   uint32_t ga;  // 0: C->T strand (letters A,G,T)  1: G->A strand (letters A,C,T)
-  uint32_t pad_;
-  const uint32_t* bloom;  // kBloomBits-bit Bloom filter over the BAD bucket ids (2 hashes)
+  uint32_t n_outl;
+  const uint32_t* bloom;  // kBloomBits-bit Bloom filter over the buckets that hold outliers / are BAD
+  const struct Outlier* outl;  // chromosome-end entries, sorted by bucket (see probe_is_dangerous)
+};
+
+// An index entry whose care positions run over the end of its chromosome before
+// care character 44.  makedb sorted it as if every character from index q on
+// were smaller than any base (reference.cpp:271-276), but LowerBound/UpperBound
+// read the real bytes there.  Characters 12..q-1 are real on both sides, so the
+// entry sits correctly among entries that differ from it before q; the order is
+// only unreliable inside the group that shares its characters 12..q-1.
+struct Outlier {
+  uint32_t h;        // 4^12 bucket
+  uint32_t q;        // first care character index that lies beyond the chromosome end (12..43)
+  uint32_t key_hi, key_lo;  // the entry's key (real bytes)
 };
 
 struct IndexView {
@@ -257,9 +270,31 @@ constexpr uint32_t kBloomBits = 1u << 14;  // 2 KB of LDS per strand
 constexpr uint32_t kBloomWords = kBloomBits / 32;
 WALT_HD uint32_t bloom_h1(uint32_t h) { return (h * 0x9E3779B1u) >> 18; }
 WALT_HD uint32_t bloom_h2(uint32_t h) { return (h * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 18; }
+WALT_HD uint64_t key_mask(uint32_t nk);
+WALT_HD uint64_t target_key(const uint32_t* care);
 WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t h) {
   const uint32_t a = bloom_h1(h), b = bloom_h2(h);
   return ((bloom[a >> 5] >> (a & 31)) & (bloom[b >> 5] >> (b & 31)) & 1u) != 0;
+}
+
+// Does this probe have to take the literal LowerBound/UpperBound search?
+WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
+  const uint32_t h = care[0] >> 8;
+  if (bucket_is_bad(sv, h)) return true;
+  uint32_t lo = 0, hi = sv.n_outl;  // first outlier of bucket h
+  while (lo < hi) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if (sv.outl[mid].h < h) lo = mid + 1; else hi = mid;
+  }
+  const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
+  const uint64_t T = target_key(care);
+  for (; lo < sv.n_outl && sv.outl[lo].h == h; ++lo) {
+    const Outlier o = sv.outl[lo];
+    if (o.q >= lim) continue;  // the search never compares a character this entry lacks
+    const uint64_t k = ((uint64_t)o.key_hi << 32) | o.key_lo;
+    if (((T ^ k) & key_mask(o.q - kKeyWeight)) == 0) return true;
+  }
+  return false;
 }
 
 // Full seed lookup for one (read, strand, seed shift): the region
@@ -318,7 +353,7 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
   out.reg = empty_region();
   uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
   uint32_t n = seed_len - kKeyWeight;
-  if (!known_good && bucket_is_bad(sv, h)) {
+  if (!known_good && probe_is_dangerous(sv, care, seed_len)) {
     uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
     if (first == second) return;                         // mapping.cpp:271-272
     out.reg = lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);

@@ -28,6 +28,7 @@ struct walt_index {
   uint32_t* d_mask_table = nullptr;   // compare_mask_table() on the device
   uint64_t device_bytes = 0;
   uint64_t bad_buckets[4] = {0, 0, 0, 0};
+  uint64_t outliers[4] = {0, 0, 0, 0};
   unsigned strand_mask = 0;
   // measurement hooks (walt_profile_enable / walt_profile_last)
   bool profile = false;

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -53,10 +54,12 @@ __global__ void k_pack_genome(const uint8_t* __restrict__ bytes, uint32_t len, u
   if (bad) atomicAdd(err, bad);
 }
 
-// index[] -> Ent {key, pos}; marks buckets whose entries touch the genome end.
+// index[] -> Ent {key, pos}; entries whose care characters < 44 run over their
+// chromosome's end are appended to the outlier list (core.h struct Outlier).
 __global__ void k_make_ent(const uint32_t* __restrict__ g2, uint32_t genome_len,
                            const uint32_t* __restrict__ index, uint32_t n, Ent* __restrict__ ent,
-                           uint32_t* __restrict__ bad, uint32_t* __restrict__ err) {
+                           const uint32_t* __restrict__ start, uint32_t n_chrom, Outlier* __restrict__ outl,
+                           uint32_t outl_cap, uint32_t* __restrict__ err) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   uint32_t pos = index[j];
@@ -69,21 +72,39 @@ __global__ void k_make_ent(const uint32_t* __restrict__ g2, uint32_t genome_len,
   bool touches;
   Ent e = make_ent(g2, genome_len, pos, touches);
   ent[j] = e;
-  if (touches) {
-    uint32_t h = hash_at(g2, pos);
-    atomicOr(&bad[h >> 5], 1u << (h & 31));
+  const uint32_t chr = chrom_id(start, n_chrom, pos);
+  const uint32_t room = start[chr + 1] - pos;
+  if (room <= care_pos(kKeyWeight + kKeyChars - 1)) {
+    const uint32_t k = atomicAdd(err + 3, 1u);
+    if (k < outl_cap) {
+      Outlier o; o.h = hash_at(g2, pos); o.q = first_beyond(room); o.key_hi = e.key_hi; o.key_lo = e.key_lo;
+      outl[k] = o;
+    }
   }
 }
 
-// bucket b is BAD when its keys are not non-decreasing.
+// Adjacent keys of one bucket out of order: explained when one of the two is an
+// outlier whose beyond-the-end characters start at or before the first character
+// in which the two differ; anything else marks the whole bucket BAD.
 __global__ void k_mark_unsorted(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t n,
+                                const uint32_t* __restrict__ start, uint32_t n_chrom,
                                 uint32_t* __restrict__ bad) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1;
   if (j >= n) return;
   Ent a = ent[j - 1], b = ent[j];
   if (ent_key(a) > ent_key(b)) {
     uint32_t ha = hash_at(g2, a.pos), hb = hash_at(g2, b.pos);
-    if (ha == hb) atomicOr(&bad[ha >> 5], 1u << (ha & 31));
+    if (ha != hb) return;
+    const uint64_t x = ent_key(a) ^ ent_key(b);
+    const uint32_t first_diff = kKeyWeight + (uint32_t)(__clzll((long long)x) >> 1);  // care char index
+    bool explained = false;
+    const Ent two[2] = {a, b};
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t chr = chrom_id(start, n_chrom, two[t].pos);
+      const uint32_t q = first_beyond(start[chr + 1] - two[t].pos);
+      if (q <= first_diff) explained = true;
+    }
+    if (!explained) atomicOr(&bad[ha >> 5], 1u << (ha & 31));
   }
 }
 
@@ -188,9 +209,13 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   WALT_HIP(hipMemsetAsync(err, 0, 4 * sizeof(uint32_t), stream));
   WALT_HIP(hipMemsetAsync(bad, 0, kNumBuckets / 8, stream));
   WALT_HIP(hipMemcpyAsync(cnt, d_counter, ((uint64_t)kNumBuckets + 1) * 4, hipMemcpyDeviceToDevice, stream));
+  const uint32_t n_chrom = (uint32_t)idx->head.lengths.size();
+  const uint32_t outl_cap = n_chrom * 100 + 16;  // <= 94 positions per chromosome have room in [37, 130]
+  Outlier* outl = nullptr;
+  if ((rc = dev_alloc(idx, &outl, outl_cap))) return rc;
   if (index_size) {
     hipLaunchKernelGGL(k_make_ent, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, genome_len, d_index,
-                       index_size, ent, bad, err);
+                       index_size, ent, idx->view.start_index, n_chrom, outl, outl_cap, err);
   }
   uint32_t herr[4] = {0, 0, 0, 0};
   WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
@@ -205,7 +230,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
                        cnt, err);
     if (index_size > 1)
       hipLaunchKernelGGL(k_mark_unsorted, dim3(grid_for(index_size - 1)), dim3(kBlock), 0, stream, g2, ent,
-                         index_size, bad);
+                         index_size, idx->view.start_index, n_chrom, bad);
   }
   // reversed directory: fill with "past the end", scatter run starts, running minimum
   hipLaunchKernelGGL(k_fill_u32, dim3(grid_for((uint64_t)slots + 1)), dim3(kBlock), 0, stream, dir,
@@ -243,9 +268,33 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   if (herr[2])
     return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[2]) +
                                   " index entries are not in the bucket of their hash");
+  // outliers: sort by bucket on the host (a few per chromosome end), add them to the Bloom filter
+  const uint32_t n_outl = herr[3] < outl_cap ? herr[3] : outl_cap;
+  if (herr[3] > outl_cap) return fail(WALT_EFORMAT, "more chromosome-end entries than a makedb index can hold");
+  if (n_outl) {
+    std::vector<Outlier> ho(n_outl);
+    std::vector<uint32_t> hb(kBloomWords);
+    WALT_HIP(hipMemcpy(ho.data(), outl, n_outl * sizeof(Outlier), hipMemcpyDeviceToHost));
+    WALT_HIP(hipMemcpy(hb.data(), bloom, kBloomWords * 4, hipMemcpyDeviceToHost));
+    std::sort(ho.begin(), ho.end(), [](const Outlier& x, const Outlier& y) {
+      if (x.h != y.h) return x.h < y.h;
+      if (x.q != y.q) return x.q < y.q;
+      if (x.key_hi != y.key_hi) return x.key_hi < y.key_hi;
+      return x.key_lo < y.key_lo;
+    });
+    for (const Outlier& o : ho) {
+      const uint32_t a = bloom_h1(o.h), b = bloom_h2(o.h);
+      hb[a >> 5] |= 1u << (a & 31);
+      hb[b >> 5] |= 1u << (b & 31);
+    }
+    WALT_HIP(hipMemcpy(outl, ho.data(), n_outl * sizeof(Outlier), hipMemcpyHostToDevice));
+    WALT_HIP(hipMemcpy(bloom, hb.data(), kBloomWords * 4, hipMemcpyHostToDevice));
+  }
   idx->bad_buckets[strand] = nbad;
+  idx->outliers[strand] = n_outl;
+  sv.outl = outl; sv.n_outl = n_outl;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
-  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.pad_ = 0; sv.bloom = bloom;
+  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom;
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }
@@ -274,15 +323,7 @@ int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, con
 }
 
 int finish_index_device(walt_index* idx) {
-  const uint32_t n = (uint32_t)idx->head.lengths.size();
-  idx->start_index.assign(n + 1, 0);
-  for (uint32_t i = 0; i < n; ++i) idx->start_index[i + 1] = idx->start_index[i] + idx->head.lengths[i];
-  uint32_t* d_start = nullptr;
   int rc;
-  if ((rc = dev_alloc(idx, &d_start, n + 1))) return rc;
-  WALT_HIP(hipMemcpy(d_start, idx->start_index.data(), (n + 1) * 4, hipMemcpyHostToDevice));
-  idx->view.start_index = d_start;
-  idx->view.n_chrom = n;
   const std::vector<uint32_t>& mt = compare_mask_table();
   if ((rc = dev_alloc(idx, &idx->d_mask_table, mt.size()))) return rc;
   WALT_HIP(hipMemcpy(idx->d_mask_table, mt.data(), mt.size() * 4, hipMemcpyHostToDevice));
@@ -301,6 +342,22 @@ int new_index(int device, const IndexHead& head, int dir_bits, walt_index** out)
   memset(&idx->view, 0, sizeof(idx->view));
   idx->view.dir_bits = (uint32_t)choose_dir_bits(head.max_index_size, dir_bits);
   idx->view.dir_slots = 1u << idx->view.dir_bits;
+  // chromosome starts are needed by the strand builders (outlier detection)
+  const uint32_t n = (uint32_t)idx->head.lengths.size();
+  idx->start_index.assign(n + 1, 0);
+  for (uint32_t i = 0; i < n; ++i) idx->start_index[i + 1] = idx->start_index[i] + idx->head.lengths[i];
+  uint32_t* d_start = nullptr;
+  int rc = dev_alloc(idx, &d_start, n + 1);
+  if (!rc && hipMemcpy(d_start, idx->start_index.data(), (n + 1) * 4, hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(WALT_EHIP, "upload of chromosome starts failed");
+  if (rc) {
+    std::string keep = walt_last_error();
+    walt_index_close(idx);
+    set_error(keep);
+    return rc;
+  }
+  idx->view.start_index = d_start;
+  idx->view.n_chrom = n;
   *out = idx;
   return WALT_OK;
 }
@@ -439,6 +496,9 @@ uint64_t walt_index_device_bytes(const walt_index* idx) { return idx ? idx->devi
 int walt_index_dir_bits(const walt_index* idx) { return idx ? (int)idx->view.dir_bits : -1; }
 uint64_t walt_index_bad_buckets(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->bad_buckets[strand] : 0;
+}
+uint64_t walt_index_outliers(const walt_index* idx, int strand) {
+  return idx && strand >= 0 && strand < 4 ? idx->outliers[strand] : 0;
 }
 
 }  // extern "C"

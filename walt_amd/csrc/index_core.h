@@ -37,6 +37,14 @@ WALT_HD Ent make_ent(const uint32_t* g2, uint32_t genome_len, uint32_t pos, bool
   return e;
 }
 
+// first care character index (>= 12) of an entry that lies at or beyond the end of
+// its chromosome; room = chromosome end - pos.  kNumCare when every character fits.
+WALT_HD uint32_t first_beyond(uint32_t room) {
+  // care_pos(q) = 1 + 3 q >= room  <=>  q >= (room - 1) / 3 rounded up
+  const uint32_t q = room <= 1 ? 0u : (room - 1 + 2) / 3;
+  return q < kKeyWeight ? kKeyWeight : q;
+}
+
 // Code prefix (first Bd bits, zero padded) of the care characters behind an index
 // entry: characters 0..11 from the genome, 12..43 from the entry key.
 WALT_HD uint32_t ent_prefix(const uint32_t* g2, const Ent& e, uint32_t ga, uint32_t Bd) {
