@@ -262,20 +262,44 @@ WALT_HD uint64_t key_mask(uint32_t nk) { return nk >= 32 ? ~0ull : ~(~0ull >> (2
 
 WALT_HD bool bucket_is_bad(const StrandView& sv, uint32_t h) { return (sv.bad[h >> 5] >> (h & 31)) & 1u; }
 
-// The 2 MB BAD bitmap does not stay in the L2 under the mapping kernels' random
-// traffic, so every probe's bitmap read became an HBM-side request.  BAD
-// buckets are rare (a few per chromosome end), so the kernels test a small
-// Bloom filter held in LDS first and read the bitmap only on a filter hit.
-constexpr uint32_t kBloomBits = 1u << 14;  // 2 KB of LDS per strand
+// Pass 1 of the mapping kernels must decide "might this probe be dangerous?"
+// without any extra memory round trip (a slow path taken by even 1 % of the lanes
+// stalls nearly every wavefront), so it tests a Bloom filter held in LDS and
+// defers the read on a hit; the exact test (probe_is_dangerous) runs in pass 2.
+// Filter key = (bucket, care characters 12 and 13): an outlier with q >= 14 inserts
+// its own pair, q == 13 inserts every second character, q == 12 (and a BAD bucket)
+// every pair -- so only probes that agree with an outlier on the characters it
+// really has can hit.
+constexpr uint32_t kBloomBits = 1u << 16;  // 8 KB of LDS per strand
 constexpr uint32_t kBloomWords = kBloomBits / 32;
-WALT_HD uint32_t bloom_h1(uint32_t h) { return (h * 0x9E3779B1u) >> 18; }
-WALT_HD uint32_t bloom_h2(uint32_t h) { return (h * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 18; }
+WALT_HD uint32_t bloom_key(uint32_t h, uint32_t c12, uint32_t c13) { return (h << 4) | (c12 << 2) | c13; }
+WALT_HD uint32_t bloom_hash(uint32_t key, uint32_t i) {
+  const uint32_t m = i == 0 ? 0x9E3779B1u : i == 1 ? 0x85EBCA6Bu : 0xC2B2AE35u;
+  uint32_t x = (key + i) * m;
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  return x >> 16;
+}
+WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t key) {
+  uint32_t hit = 1;
+  for (uint32_t i = 0; i < 3; ++i) {
+    const uint32_t a = bloom_hash(key, i);
+    hit &= bloom[a >> 5] >> (a & 31);
+  }
+  return (hit & 1u) != 0;
+}
+WALT_HD void bloom_insert(uint32_t* bloom, uint32_t key) {
+  for (uint32_t i = 0; i < 3; ++i) {
+    const uint32_t a = bloom_hash(key, i);
+    bloom[a >> 5] |= 1u << (a & 31);
+  }
+}
+// key of a probe: bucket and care characters 12, 13 of its (zero padded) care string
+WALT_HD uint32_t bloom_key_of_care(const uint32_t* care) {
+  return bloom_key(care[0] >> 8, (care[0] >> 6) & 3u, (care[0] >> 4) & 3u);
+}
 WALT_HD uint64_t key_mask(uint32_t nk);
 WALT_HD uint64_t target_key(const uint32_t* care);
-WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t h) {
-  const uint32_t a = bloom_h1(h), b = bloom_h2(h);
-  return ((bloom[a >> 5] >> (a & 31)) & (bloom[b >> 5] >> (b & 31)) & 1u) != 0;
-}
 
 // Does this probe have to take the literal LowerBound/UpperBound search?
 WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {

@@ -132,21 +132,6 @@ __global__ void k_dir_scatter(const uint32_t* __restrict__ g2, const Ent* __rest
   if (j == 0 || ent_prefix(g2, ent[j - 1], ga, Bd) != v) atomicMin(&dir[(1u << Bd) - v], j);
 }
 
-// Bloom filter over the BAD bucket ids (one thread per bitmap word)
-__global__ void k_build_bloom(const uint32_t* __restrict__ bad, uint32_t nwords, uint32_t* __restrict__ bloom) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nwords) return;
-  uint32_t w = bad[i];
-  while (w) {
-    uint32_t bit = __ffs((int)w) - 1;
-    w &= w - 1;
-    uint32_t h = i * 32 + bit;
-    uint32_t a = bloom_h1(h), b = bloom_h2(h);
-    atomicOr(&bloom[a >> 5], 1u << (a & 31));
-    atomicOr(&bloom[b >> 5], 1u << (b & 31));
-  }
-}
-
 __global__ void k_popcount(const uint32_t* __restrict__ words, uint32_t n, unsigned long long* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t c = i < n ? __popc(words[i]) : 0;
@@ -256,8 +241,6 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   WALT_HIP(hipMemsetAsync(d_cnt64, 0, sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(k_popcount, dim3(grid_for(kNumBuckets / 32)), dim3(kBlock), 0, stream, bad, kNumBuckets / 32,
                      d_cnt64);
-  hipLaunchKernelGGL(k_build_bloom, dim3(grid_for(kNumBuckets / 32)), dim3(kBlock), 0, stream, bad, kNumBuckets / 32,
-                     bloom);
   unsigned long long nbad = 0;
   WALT_HIP(hipMemcpyAsync(&nbad, d_cnt64, sizeof(nbad), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
@@ -268,14 +251,14 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   if (herr[2])
     return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[2]) +
                                   " index entries are not in the bucket of their hash");
-  // outliers: sort by bucket on the host (a few per chromosome end), add them to the Bloom filter
+  // outliers: sort by bucket on the host (a few per chromosome end); Bloom filter of the
+  // (bucket, char 12, char 13) keys a dangerous probe can have (core.h)
   const uint32_t n_outl = herr[3] < outl_cap ? herr[3] : outl_cap;
   if (herr[3] > outl_cap) return fail(WALT_EFORMAT, "more chromosome-end entries than a makedb index can hold");
-  if (n_outl) {
+  {
     std::vector<Outlier> ho(n_outl);
-    std::vector<uint32_t> hb(kBloomWords);
-    WALT_HIP(hipMemcpy(ho.data(), outl, n_outl * sizeof(Outlier), hipMemcpyDeviceToHost));
-    WALT_HIP(hipMemcpy(hb.data(), bloom, kBloomWords * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> hb(kBloomWords, 0);
+    if (n_outl) WALT_HIP(hipMemcpy(ho.data(), outl, n_outl * sizeof(Outlier), hipMemcpyDeviceToHost));
     std::sort(ho.begin(), ho.end(), [](const Outlier& x, const Outlier& y) {
       if (x.h != y.h) return x.h < y.h;
       if (x.q != y.q) return x.q < y.q;
@@ -283,11 +266,20 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       return x.key_lo < y.key_lo;
     });
     for (const Outlier& o : ho) {
-      const uint32_t a = bloom_h1(o.h), b = bloom_h2(o.h);
-      hb[a >> 5] |= 1u << (a & 31);
-      hb[b >> 5] |= 1u << (b & 31);
+      const uint32_t c12 = o.key_hi >> 30, c13 = (o.key_hi >> 28) & 3u;
+      for (uint32_t a = 0; a < 4; ++a)
+        for (uint32_t b = 0; b < 4; ++b)
+          if ((o.q <= kKeyWeight || a == c12) && (o.q <= kKeyWeight + 1 || b == c13)) bloom_insert(hb.data(), bloom_key(o.h, a, b));
     }
-    WALT_HIP(hipMemcpy(outl, ho.data(), n_outl * sizeof(Outlier), hipMemcpyHostToDevice));
+    if (nbad) {  // buckets with unexplained disorder: every probe into them is dangerous
+      std::vector<uint32_t> bm(kNumBuckets / 32);
+      WALT_HIP(hipMemcpy(bm.data(), bad, kNumBuckets / 8, hipMemcpyDeviceToHost));
+      for (uint32_t w = 0; w < kNumBuckets / 32; ++w)
+        for (uint32_t bit = 0; bm[w] >> bit; ++bit)
+          if ((bm[w] >> bit) & 1u)
+            for (uint32_t ab = 0; ab < 16; ++ab) bloom_insert(hb.data(), bloom_key(w * 32 + bit, ab >> 2, ab & 3u));
+    }
+    if (n_outl) WALT_HIP(hipMemcpy(outl, ho.data(), n_outl * sizeof(Outlier), hipMemcpyHostToDevice));
     WALT_HIP(hipMemcpy(bloom, hb.data(), kBloomWords * 4, hipMemcpyHostToDevice));
   }
   idx->bad_buckets[strand] = nbad;

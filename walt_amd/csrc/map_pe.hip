@@ -68,7 +68,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         uint32_t care[kCareWords];
         uint32_t slot, span;
         seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
-        if (!LITERAL && bloom_maybe(sh.bloom[fi], care[0] >> 8) && probe_is_dangerous(sv, care, lr.repeats)) {
+        if (!LITERAL && bloom_maybe(sh.bloom[fi], bloom_key_of_care(care))) {
           deferred = true;
           mappable = false;
           defer_iter = fi * 3 + seed_i;

@@ -192,7 +192,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         if (act) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
         stamp(st, 1);
         bool is_bad = false;
-        if (act && !LITERAL) is_bad = bloom_maybe(sh.bloom[fi], care[0] >> 8) && probe_is_dangerous(sv, care, lr.repeats);
+        if (act && !LITERAL) is_bad = bloom_maybe(sh.bloom[fi], bloom_key_of_care(care));
         stamp(st, 2);
         if (act) {
           if (is_bad) {
@@ -412,9 +412,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     uint32_t slot = 0, span = 0;
     if (need_p || need_m) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
     stamp(st, 1);
-    const uint32_t h = care[0] >> 8;
-    const bool bad_p = need_p && bloom_maybe(sh.bloom[0], h) && probe_is_dangerous(svp, care, lr.repeats);
-    const bool bad_m = need_m && bloom_maybe(sh.bloom[1], h) && probe_is_dangerous(svm, care, lr.repeats);
+    const bool bad_p = need_p && bloom_maybe(sh.bloom[0], bloom_key_of_care(care));
+    const bool bad_m = need_m && bloom_maybe(sh.bloom[1], bloom_key_of_care(care));
     if (bad_p || bad_m) {
       deferred = true;
       mappable = false;
