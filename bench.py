@@ -114,6 +114,90 @@ def make_reads(torch, dev, genome_ascii, n, read_len, seed):
     return out.reshape(-1), offsets
 
 
+def make_pairs(torch, dev, genome_ascii, n, read_len, seed):
+    """n pairs on the GPU: fragment length U[120,500] from either strand, bisulfite (95 % C->T on the
+    fragment), mate 1 = fragment[:L], mate 2 = revcomp(fragment)[:L], 1 % substitutions."""
+    L = genome_ascii.numel()
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    m1 = torch.empty((n, read_len), dtype=torch.uint8, device=dev)
+    m2 = torch.empty((n, read_len), dtype=torch.uint8, device=dev)
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in ((65, 84), (67, 71), (71, 67), (84, 65)):
+        comp[a] = b
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    ar = torch.arange(read_len, device=dev)
+    chunk = 1 << 21
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        flen = torch.randint(max(120, read_len), 501, (m,), generator=g, device=dev)
+        pos = torch.randint(0, L - 600, (m,), generator=g, device=dev)
+        rev = torch.rand(m, generator=g, device=dev) < 0.5
+        # 5' end of the fragment on its own strand, and the 5' end of the opposite strand
+        left = genome_ascii[pos[:, None] + ar[None, :]]                                  # genome[pos : pos+L]
+        right = comp[genome_ascii[(pos + flen)[:, None] - 1 - ar[None, :]].long()]       # revcomp of the last L bases
+        f5 = torch.where(rev[:, None], right, left)     # fragment[:L]
+        f3rc = torch.where(rev[:, None], left, right)   # what revcomp(fragment)[:L] is BEFORE conversion ...
+        # bisulfite acts on the fragment strand: C->T in f5; the mate-2 read is the reverse complement of the
+        # converted fragment end, i.e. G->A relative to the opposite strand
+        r1 = torch.where((f5 == 67) & (torch.rand(f5.shape, generator=g, device=dev) < 0.95), torch.full_like(f5, 84), f5)
+        r2 = torch.where((f3rc == 71) & (torch.rand(f5.shape, generator=g, device=dev) < 0.95), torch.full_like(f5, 65), f3rc)
+        for r, dst in ((r1, m1), (r2, m2)):
+            sub = torch.rand(r.shape, generator=g, device=dev) < 0.01
+            rnd = lut[torch.randint(0, 4, r.shape, generator=g, device=dev)]
+            dst[s:s + m] = torch.where(sub, rnd, r)
+    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * read_len
+    return m1.reshape(-1), m2.reshape(-1), offsets
+
+
+def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
+    """configs[2]: paired-end mapping (top-k heaps + pair merge on the device); reports pairs/s."""
+    t0 = time.perf_counter()
+    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, HG19_NAMES, device=local,
+                                      strands=walt_amd.STRANDS_ALL, dir_bits=args.dir_bits)
+    t_index = time.perf_counter() - t0
+    log("index (4 strands): %.1f GB in HBM, dir_bits %d (%.1f s)" % (idx.device_bytes / 1e9, idx.dir_bits, t_index))
+    n = args.reads
+    d1, d2, d_off = make_pairs(torch, dev, genome_ascii, n, args.read_len, seed=2000 + rank)
+    torch.cuda.synchronize()
+    del genome_ascii
+    torch.cuda.empty_cache()
+    d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+    d_ws = torch.empty(walt_amd.lib().walt_pe_workspace_bytes(n, args.read_len, args.top_k), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        rc = walt_amd.lib().walt_map_pe_batch_device(idx.handle, d1.data_ptr(), d_off.data_ptr(), d2.data_ptr(),
+                                                     d_off.data_ptr(), n, args.read_len, args.max_mismatches,
+                                                     args.bucket, args.top_k, args.frag_range, d_out.data_ptr(),
+                                                     d_stats.data_ptr(), d_ws.data_ptr(), stream)
+        assert rc == 0, walt_amd.lib().walt_last_error()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    res = d_out.view(torch.int32).view(n, 16)
+    bt = res[:, 8]
+    out = {"metric": "mapped read pairs/sec (2 x %d bp paired-end, hg19-scale index, -m %d -k %d -L %d)" % (
+               args.read_len, args.max_mismatches, args.top_k, args.frag_range),
+           "value": world * n * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": "configs[2]: hg19-scale synthetic genome, %d pairs 2 x %d bp, fragment U[120,500]" % (
+               n, args.read_len), "index_hbm_gb": round(idx.device_bytes / 1e9, 2)},
+           "mapping": {"pairs": n, "unique_pairs": int((bt == 1).sum()), "ambiguous_pairs": int((bt >= 2).sum()),
+                       "unpaired": int((bt == 0).sum())}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    idx.close()
+
+
 def cpu_baseline(idx, reads_host, read_len, n_sample, lens, max_mm, b):
     """Oracle restatement on the host cores, one strand index in memory at a time
     (as the reference itself does, mapping.cpp:491-492)."""
@@ -153,6 +237,9 @@ def main():
     ap.add_argument("--bucket", type=int, default=5000)
     ap.add_argument("--dir-bits", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["se", "pe"], default="se", help="se = configs[1] (headline), pe = configs[2]")
+    ap.add_argument("--top-k", type=int, default=50)
+    ap.add_argument("--frag-range", type=int, default=1000)
     args = ap.parse_args()
 
     import walt_amd  # loads the HIP library (and the HIP runtime torch will share)
@@ -179,6 +266,11 @@ def main():
     log("genome: %d bp in %d chromosomes (%.1f s)" % (sum(lens), len(lens), t_genome))
 
     torch.cuda.empty_cache()  # hand the generator's cached blocks back: the library allocates with hipMalloc
+    if args.mode == "pe":
+        run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     t0 = time.perf_counter()
     idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, HG19_NAMES, device=local,
                                       strands=walt_amd.STRANDS_CT, dir_bits=args.dir_bits)
