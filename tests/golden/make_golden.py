@@ -268,6 +268,30 @@ def main():
     write_fastq(os.path.join(HERE, "pe_1.fastq"), p1)
     write_fastq(os.path.join(HERE, "pe_2.fastq"), p2)
 
+    # adaptor-contaminated sets for -C (util.hpp:189-233): separate RNG so the sets above stay unchanged
+    rng2 = random.Random(777)
+    AD1, AD2 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+
+    def contaminate(recs, adaptor):
+        out = []
+        for nm, sq, q in recs:
+            r = rng2.random()
+            if len(sq) >= 60 and r < 0.5:
+                keep = rng2.choice([len(sq) - 3, len(sq) - 5, len(sq) - 6, len(sq) - 9, len(sq) - 14, len(sq) - 20, len(sq) - 33])
+                tail = adaptor[:len(sq) - keep]
+                if rng2.random() < 0.3 and len(tail) > 6:  # one error inside the adaptor part
+                    k = rng2.randrange(len(tail))
+                    tail = tail[:k] + rng2.choice([c for c in "ACGT" if c != tail[k]]) + tail[k + 1:]
+                sq = sq[:keep] + tail
+            out.append((nm, sq, q))
+        return out
+
+    se_all = make_se_reads(random.Random(4242), seqs, "CT", 500, "clip")
+    write_fastq(os.path.join(HERE, "se_clip.fastq"), contaminate(se_all, AD1))
+    c1, c2 = make_pe_reads(random.Random(4243), seqs, 400, "pclip")
+    write_fastq(os.path.join(HERE, "pe_clip_1.fastq"), contaminate(c1, AD1))
+    write_fastq(os.path.join(HERE, "pe_clip_2.fastq"), contaminate(c2, AD2))
+
     tmp = tempfile.mkdtemp(prefix="walt_golden_")
     idx = os.path.join(tmp, "g1.dbindex")
     run([os.path.join(REF_BIN, "makedb"), "-c", os.path.join(HERE, "g1.fa"), "-o", idx], tmp)
@@ -296,6 +320,10 @@ def main():
         "pe_sam_au_m2": ("pe", ["-sam", "-a", "-u", "-m", "2"]),
         "pe_sam_au_m10_b20": ("pe", ["-sam", "-a", "-u", "-m", "10", "-b", "20"]),
         "pe_sam_au_N250": ("pe", ["-sam", "-a", "-u", "-N", "250"]),
+        "se_clip_sam_au": ("se_clip", ["-sam", "-a", "-u", "-C", AD1]),
+        "se_clip_mr_au_N100": ("se_clip", ["-a", "-u", "-C", AD1[:20], "-N", "100"]),
+        "pe_clip_sam_au": ("pe_clip", ["-sam", "-a", "-u", "-C", AD1 + ":" + AD2]),
+        "pe_clip_mr_au": ("pe_clip", ["-a", "-u", "-C", AD1[:25]]),
     }
     outroot = os.path.join(HERE, "out")
     shutil.rmtree(outroot, ignore_errors=True)
@@ -305,8 +333,8 @@ def main():
         os.makedirs(wd)
         out = os.path.join(wd, "out.sam" if "-sam" in extra else "out.mr")
         cmd = [os.path.join(REF_BIN, "walt"), "-i", idx, "-o", out] + extra
-        if kind == "pe":
-            cmd += ["-1", os.path.join(HERE, "pe_1.fastq"), "-2", os.path.join(HERE, "pe_2.fastq")]
+        if kind in ("pe", "pe_clip"):
+            cmd += ["-1", os.path.join(HERE, kind + "_1.fastq"), "-2", os.path.join(HERE, kind + "_2.fastq")]
         else:
             cmd += ["-r", os.path.join(HERE, kind + ".fastq")]
         run(cmd, wd)

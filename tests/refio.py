@@ -287,9 +287,28 @@ _libc = ctypes.CDLL("libc.so.6")
 _libc.rand.restype = ctypes.c_int
 
 
+def _similarity(s, pos, adaptor):  # util.hpp:193-200
+    lim = min(len(s) - pos, len(adaptor), 14)
+    return sum(1 for i in range(lim) if s[pos + i] == adaptor[i])
+
+
+def clip_adaptor(adaptor, s):
+    """clip_adaptor_from_read, util.hpp:202-216 (s: bytearray, clipped tail -> 'N')."""
+    n = len(s)
+    lim1 = n - 14 + 1
+    for i in range(max(lim1, 0)):
+        if _similarity(s, i, adaptor) >= 11:
+            s[i:] = b"N" * (n - i)
+            return
+    for i in range(max(lim1, 0), n - 5 + 1):
+        if _similarity(s, i, adaptor) >= n - i - 1:
+            s[i:] = b"N" * (n - i)
+            return
+
+
 def load_fastq_batches(path, batch_size, adaptor=""):
     """Yields (names, seqs, scores) per batch exactly as the reference loads them."""
-    assert not adaptor, "adaptor clipping is not restated in the test helper"
+    adaptor = adaptor.encode() if isinstance(adaptor, str) else adaptor
     with open(path, "rb") as f:
         done = False
         while not done:
@@ -312,6 +331,8 @@ def load_fastq_batches(path, batch_size, adaptor=""):
                     name = line[1:] if sp < 0 else line[1:sp]
                 elif line_code == 1:
                     s = bytearray(line)
+                    if adaptor:
+                        clip_adaptor(adaptor, s)
                     for i, c in enumerate(s):
                         if c not in b"ACGT":
                             s[i] = b"ACGT"[_libc.rand() % 4]
@@ -546,7 +567,7 @@ def golden_file(case, name):
 
 def args_to_opts(args):
     """reference CLI args (walt.cpp:130-166) -> dict with defaults (walt.cpp:103-126)."""
-    o = dict(sam=False, ambiguous=False, unmapped=False, ag=False, m=6, N=10000000, b=5000, k=50, L=1000, t=1)
+    o = dict(sam=False, ambiguous=False, unmapped=False, ag=False, m=6, N=10000000, b=5000, k=50, L=1000, t=1, C="")
     i = 0
     while i < len(args):
         a = args[i]
@@ -558,6 +579,9 @@ def args_to_opts(args):
             o["unmapped"] = True
         elif a == "-A":
             o["ag"] = True
+        elif a == "-C":
+            o["C"] = args[i + 1]
+            i += 1
         else:
             o[a[1:]] = int(args[i + 1])
             i += 1
