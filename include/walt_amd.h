@@ -178,7 +178,9 @@ int walt_index_export_strand(const walt_index* idx, int strand, uint8_t* genome_
                              uint32_t* counter_out, uint32_t* index_out);
 
 /* WriteIndex x4 + WriteIndexHeadInfo (reference.cpp:302-322, 353-379) from the
- * resident index; needs all four strands. */
+ * resident index.  Writes the head file and the strand file of every resident
+ * strand (a C->T-only index writes <path>, <path>_CT00 and <path>_CT01, which is
+ * all the reference's single-end mode without -A reads, mapping.cpp:491-492). */
 int walt_index_write(const walt_index* idx, const char* dbindex_path);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------- */

@@ -319,11 +319,12 @@ int walt_index_export_strand(const walt_index* idx, int strand, uint8_t* genome_
 // be resident.
 int walt_index_write(const walt_index* idx, const char* dbindex_path) {
   if (!idx || !dbindex_path) return fail(WALT_EINVAL, "walt_index_write: bad argument");
-  if ((idx->strand_mask & 15u) != 15u) return fail(WALT_EINVAL, "walt_index_write needs all four strands resident");
+  if ((idx->strand_mask & 15u) == 0) return fail(WALT_EINVAL, "walt_index_write: no strand resident");
   static const char* sfx[4] = {"_CT00", "_CT01", "_GA10", "_GA11"};
   IndexHead head = idx->head;
   head.max_index_size = 0;
   for (int s = 0; s < 4; ++s) {
+    if (!(idx->strand_mask & (1u << s))) continue;  // a C->T-only (or G->A-only) index writes its two strand files
     StrandFile sf;
     sf.strand = (s & 1) ? '-' : '+';
     sf.genome.resize(head.genome_len);

@@ -234,12 +234,23 @@ __global__ void k_pe_merge(IndexView iv, const Candidate* __restrict__ ranked1, 
                            const Candidate* __restrict__ ranked2, const uint32_t* __restrict__ n2,
                            const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, uint32_t n,
                            uint32_t top_k, int frag_range, uint32_t max_mm, PairResult* __restrict__ out) {
+  // chromosome starts in LDS when they fit: getChromID is a chain of dependent loads per candidate pair
+  __shared__ uint32_t s_start[kLdsChroms + 1];
+  const bool fits = iv.n_chrom <= kLdsChroms;
+  if (fits)
+    for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  __syncthreads();
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   PairResult pr;
-  pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r],
-             (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), iv.start_index, iv.n_chrom,
-             frag_range, max_mm, pr);
+  if (fits)
+    pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r],
+               (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), s_start, iv.n_chrom, frag_range,
+               max_mm, pr);
+  else
+    pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r],
+               (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), iv.start_index, iv.n_chrom,
+               frag_range, max_mm, pr);
   out[r] = pr;
 }
 
