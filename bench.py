@@ -202,7 +202,8 @@ def cpu_baseline(idx, reads_host, read_len, n_sample, lens, max_mm, b):
     """Oracle restatement on the host cores, one strand index in memory at a time
     (as the reference itself does, mapping.cpp:491-492)."""
     import refio
-    cores = len(os.sched_getaffinity(0))
+    import walt_amd
+    cores = walt_amd.effective_cpus()  # affinity capped by the cgroup CPU quota (the GPU box grants 16 of 256)
     orc = refio.oracle()
     n = n_sample
     bases = np.ascontiguousarray(reads_host[:n * read_len])
@@ -379,7 +380,7 @@ def main():
                 except (ValueError, KeyError):
                     pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK, "traffic": traffic, "kernel": "k_map_se<8> (+ literal pass)",
+                               "frac": achieved / HBM_PEAK, "traffic": traffic, "kernel": "k_map_se<7> (+ literal pass)",
                                "algorithmic_bytes_per_read": bytes_per_read,
                                "per_read": {"probes": P, "search_steps": S, "candidates": C}}
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",

@@ -80,6 +80,13 @@ typedef struct walt_index walt_index;
 const char* walt_last_error(void);
 int walt_device_count(void);
 
+/* Page-locked host memory for the read / result buffers a caller hands to
+ * walt_map_se_batch / walt_map_pe_batch (the reference keeps them in
+ * std::vector<std::string>, mapping.cpp:462-464); transfers from such buffers
+ * run at PCIe rate.  Ordinary pageable pointers are accepted by every call too. */
+int walt_host_alloc(size_t bytes, void** out);
+void walt_host_free(void* p);
+
 /* ---- index ------------------------------------------------------------- */
 
 /* Replaces ReadIndexHeadInfo + per-batch ReadIndex (reference.cpp:381-417,

@@ -62,8 +62,32 @@ def build_harness(force=False):
     return HARNESS_SO
 
 
+HOSTIO_SO = os.path.join(HERE, "build", "libhostio_harness.so")
+
+
+def build_hostio_harness(force=False):
+    srcs = [os.path.join(HERE, "hostio_harness.cpp"), os.path.join(ROOT, "walt_amd", "csrc", "host", "hostio.h")]
+    if not force and _newer(HOSTIO_SO, srcs):
+        return HOSTIO_SO
+    os.makedirs(os.path.dirname(HOSTIO_SO), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-fopenmp", "-shared", "-fPIC", "-std=c++17", "-Wall", "-o", HOSTIO_SO, srcs[0]],
+                   check=True)
+    return HOSTIO_SO
+
+
 _oracle = None
 _harness = None
+_hostio = None
+
+
+def hostio_harness():
+    global _hostio
+    if _hostio is None:
+        L = ctypes.CDLL(build_hostio_harness())
+        L.hio_dump.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        _hostio = L
+    return _hostio
 
 
 def oracle():
@@ -328,7 +352,7 @@ def load_fastq_batches(path, batch_size, adaptor=""):
                     continue
                 if line_code == 0:
                     sp = line.find(b" ")
-                    name = line[1:] if sp < 0 else line[1:sp]
+                    name = line[1:] if sp <= 0 else line[1:sp]  # substr(1, 0 - 1): the unsigned wrap keeps the rest
                 elif line_code == 1:
                     s = bytearray(line)
                     if adaptor:

@@ -66,6 +66,9 @@ def run_timed(cmd):
     dt = time.perf_counter() - t0
     if p.returncode != 0:
         raise SystemExit("command failed (%d): %s\n%s" % (p.returncode, " ".join(cmd), p.stdout[-2000:]))
+    for ln in p.stdout.splitlines():
+        if ln.startswith("[walt_amd"):
+            log(ln)
     return dt
 
 
@@ -90,7 +93,7 @@ def main():
     for b in (ref_bin, our_bin):
         if not os.path.exists(b):
             raise SystemExit("missing " + b + " (run __graft_entry__.build() in the build container)")
-    threads = args.threads or len(os.sched_getaffinity(0))
+    threads = args.threads or walt_amd.effective_cpus()
     dev = torch.device("cuda", 0)
     scale = args.genome_mbp * 1e6 / sum(bench.HG19)
     genome_ascii, lens = bench.make_genome(torch, dev, scale, seed=2)
@@ -149,7 +152,7 @@ def main():
             res = {}
             for who, binary in (("gpu", our_bin), ("ref", ref_bin)):
                 o = os.path.join(scratch, "%s_%s.out" % (tag, who))
-                dt = run_timed([binary] + inp + ["-o", o] + common)
+                dt = run_timed([binary] + inp + ["-o", o] + common + (["-v"] if who == "gpu" else []))
                 res[who + "_wall_s"] = round(dt, 2)
                 log("%s %s: %.1f s wall" % (tag, who, dt))
             sfx = [""] + ([] if args.sam else (["_1_ambiguous", "_1_unmapped", "_2_ambiguous", "_2_unmapped"] if pe

@@ -25,6 +25,27 @@ WALT_OK = 0
 STRAND_CT00, STRAND_CT01, STRAND_GA10, STRAND_GA11 = 1, 2, 4, 8
 STRANDS_CT, STRANDS_GA, STRANDS_ALL = 3, 12, 15
 
+
+def effective_cpus():
+    """CPUs this process may use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
 # numpy views of the C structs (include/walt_amd.h)
 best_match_dtype = np.dtype(
     [("genome_pos", "<u4"), ("times", "<u4"), ("strand", "S1"), ("pad", "V3"), ("mismatch", "<u4")])

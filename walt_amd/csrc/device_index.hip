@@ -4,11 +4,17 @@
 // Replaces ReadIndexHeadInfo + the per-batch, per-strand ReadIndex of the
 // reference (reference.cpp:324-351,381-417; call sites mapping.cpp:437,492,
 // paired.cpp:583,661): all selected strands are loaded ONCE and stay resident.
+#include <fcntl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -392,6 +398,134 @@ static int upload_strand(walt_index* idx, int strand, const uint8_t* genome, con
   return rc;
 }
 
+
+// ---------------------------------------------------------------------------
+// strand file -> HBM without a host copy of the 15 GB arrays: reader threads
+// pread 32 MiB pieces into page-locked buffers and queue each piece on their own
+// stream (ReadIndex, reference.cpp:324-351, freads the whole file into vectors)
+// ---------------------------------------------------------------------------
+struct StreamRing {
+  static constexpr int kThreads = 16, kDepth = 2;
+  static constexpr size_t kPiece = 16u << 20;
+  char* buf = nullptr;  // kThreads * kDepth * kPiece, page-locked
+  hipStream_t stream[kThreads] = {};
+  int device = 0;
+  int init(int dev) {
+    device = dev;
+    if (hipHostMalloc(reinterpret_cast<void**>(&buf), (size_t)kThreads * kDepth * kPiece, hipHostMallocDefault) != hipSuccess)
+      return fail(WALT_ENOMEM, "hipHostMalloc failed (index staging)");
+    for (int t = 0; t < kThreads; ++t)
+      if (hipStreamCreateWithFlags(&stream[t], hipStreamNonBlocking) != hipSuccess) return fail(WALT_EHIP, "hipStreamCreate failed");
+    return WALT_OK;
+  }
+  ~StreamRing() {
+    for (int t = 0; t < kThreads; ++t)
+      if (stream[t]) hipStreamDestroy(stream[t]);
+    if (buf) hipHostFree(buf);
+  }
+  // file[off, off + bytes) -> d_dst[0, bytes)
+  int copy(int fd, uint64_t off, void* d_dst, uint64_t bytes) {
+    const uint64_t pieces = (bytes + kPiece - 1) / kPiece;
+    std::atomic<int> err(0);
+    auto worker = [&](int t) {
+      if (hipSetDevice(device) != hipSuccess) { err = WALT_EHIP; return; }
+      hipEvent_t done[kDepth] = {};
+      for (int d = 0; d < kDepth; ++d)
+        if (hipEventCreateWithFlags(&done[d], hipEventDisableTiming) != hipSuccess) err = WALT_EHIP;
+      bool used[kDepth] = {};
+      int slot = 0;
+      for (uint64_t p = t; p < pieces && !err; p += kThreads, slot = (slot + 1) % kDepth) {
+        char* b = buf + ((size_t)t * kDepth + slot) * kPiece;
+        if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess) { err = WALT_EHIP; break; }
+        const uint64_t at = p * kPiece, len = std::min<uint64_t>(kPiece, bytes - at);
+        uint64_t got = 0;
+        while (got < len) {
+          ssize_t r = pread(fd, b + got, len - got, (off_t)(off + at + got));
+          if (r <= 0) { err = WALT_EFORMAT; break; }
+          got += (uint64_t)r;
+        }
+        if (err) break;
+        if (hipMemcpyAsync(static_cast<char*>(d_dst) + at, b, len, hipMemcpyHostToDevice, stream[t]) != hipSuccess ||
+            hipEventRecord(done[slot], stream[t]) != hipSuccess) { err = WALT_EHIP; break; }
+        used[slot] = true;
+      }
+      if (hipStreamSynchronize(stream[t]) != hipSuccess && !err) err = WALT_EHIP;
+      for (int d = 0; d < kDepth; ++d)
+        if (done[d]) hipEventDestroy(done[d]);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < kThreads; ++t) th.emplace_back(worker, t);
+    for (auto& x : th) x.join();
+    if (err == WALT_EFORMAT) return fail(WALT_EFORMAT, "read file error (strand index): file too short");
+    if (err) return fail(WALT_EHIP, "streaming upload failed");
+    return WALT_OK;
+  }
+};
+
+static double wall_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static int stream_strand_file(walt_index* idx, int strand, const std::string& path, StreamRing& ring) {
+  const bool verbose = getenv("WALT_AMD_VERBOSE") != nullptr;
+  double t0 = wall_s();
+  int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) return fail(WALT_EIO, "cannot open input file " + path);
+  const uint32_t genome_len = idx->head.genome_len;
+  char strand_byte = 0;
+  uint32_t sizes[2] = {0, 0};  // counter_size, index_size (reference.cpp:311-316)
+  bool ok = pread(fd, &strand_byte, 1, 0) == 1 && pread(fd, sizes, 8, (off_t)1 + genome_len) == 8;
+  if (ok && sizes[0] != kNumBuckets) ok = false;
+  if (!ok) { ::close(fd); return fail(WALT_EFORMAT, "read file error (strand index) " + path); }
+  if (strand_byte != ((strand & 1) ? '-' : '+')) { ::close(fd); return fail(WALT_EFORMAT, "strand byte mismatch in " + path); }
+  const uint32_t index_size = sizes[1];
+  const uint64_t counter_bytes = ((uint64_t)kNumBuckets + 1) * 4;
+  const uint64_t off_counter = (uint64_t)1 + genome_len + 8, off_index = off_counter + counter_bytes;
+  std::vector<uint32_t> counter((size_t)kNumBuckets + 1);
+  {
+    uint64_t got = 0;
+    while (got < counter_bytes) {
+      ssize_t r = pread(fd, reinterpret_cast<char*>(counter.data()) + got, counter_bytes - got, (off_t)(off_counter + got));
+      if (r <= 0) break;
+      got += (uint64_t)r;
+    }
+    if (got != counter_bytes) { ::close(fd); return fail(WALT_EFORMAT, "read file error (strand index) " + path); }
+  }
+  int rc = check_counter(counter.data(), index_size);
+  if (rc) { ::close(fd); return rc; }
+  uint8_t* d_bytes = nullptr;
+  uint32_t *d_counter = nullptr, *d_index = nullptr;
+  auto cleanup = [&]() {
+    if (d_bytes) hipFree(d_bytes);
+    if (d_counter) hipFree(d_counter);
+    if (d_index) hipFree(d_index);
+    ::close(fd);
+  };
+  hipError_t e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&d_bytes), (uint64_t)genome_len + 16)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&d_counter), counter_bytes)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&d_index), ((uint64_t)index_size + 1) * 4)) != hipSuccess) {
+    cleanup();
+    return fail(WALT_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  }
+  if ((e = hipMemcpy(d_counter, counter.data(), counter_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+    cleanup();
+    return fail(WALT_EHIP, std::string("hipMemcpy failed: ") + hipGetErrorString(e));
+  }
+  rc = ring.copy(fd, 1, d_bytes, genome_len);
+  if (!rc) rc = ring.copy(fd, off_index, d_index, (uint64_t)index_size * 4);
+  double t1 = wall_s();
+  if (!rc) rc = build_strand_device(idx, strand, d_bytes, d_counter, d_index, index_size, nullptr);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(WALT_EHIP, "strand build failed");
+  if (verbose)
+    fprintf(stderr, "[walt_amd index: %s  %.1f GB streamed in %.2f s, derived structures %.2f s]\n", path.c_str(),
+            (genome_len + 4.0 * index_size) / 1e9, t1 - t0, wall_s() - t1);
+  cleanup();
+  return rc;
+}
+
 }  // namespace walt
 
 using namespace walt;
@@ -404,6 +538,18 @@ int walt_device_count(void) {
   return n;
 }
 
+int walt_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(WALT_EINVAL, "walt_host_alloc: bad argument");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(WALT_ENOMEM, std::string("hipHostMalloc failed: ") + hipGetErrorString(e));
+  return WALT_OK;
+}
+
+void walt_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_bits, walt_index** out) {
   if (!dbindex_path || !out || !(strand_mask & 15u)) return fail(WALT_EINVAL, "walt_index_open: bad argument");
   *out = nullptr;
@@ -413,12 +559,13 @@ int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, 
   walt_index* idx = nullptr;
   if ((rc = new_index(device, head, dir_bits, &idx))) return rc;
   static const char* sfx[4] = {"_CT00", "_CT01", "_GA10", "_GA11"};
-  for (int s = 0; s < 4 && !rc; ++s) {
-    if (!(strand_mask & (1u << s))) continue;
-    StrandFile sf;
-    rc = read_strand_file(std::string(dbindex_path) + sfx[s], head.genome_len, sf);
-    if (!rc && sf.strand != ((s & 1) ? '-' : '+')) rc = fail(WALT_EFORMAT, std::string("strand byte mismatch in ") + sfx[s]);
-    if (!rc) rc = upload_strand(idx, s, sf.genome.data(), sf.counter.data(), sf.index.data(), (uint32_t)sf.index.size());
+  {
+    StreamRing ring;
+    rc = ring.init(device);
+    for (int s = 0; s < 4 && !rc; ++s) {
+      if (!(strand_mask & (1u << s))) continue;
+      rc = stream_strand_file(idx, s, std::string(dbindex_path) + sfx[s], ring);
+    }
   }
   if (!rc) rc = finish_index_device(idx);
   if (rc) {

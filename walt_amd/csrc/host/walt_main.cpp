@@ -2,11 +2,13 @@
 // C ABI (include/walt_amd.h).  It restates, in its own code, the parts of the
 // reference that sit AROUND the hot path so that a user can swap binaries:
 //   option table ............ walt.cpp:130-166 (single-dash long names)
-//   FASTQ batch loader ...... mapping.cpp:65-121 (srand(0) per batch, N -> rand()%4)
-//   adaptor clipping -C ..... util.hpp:189-233
+//   FASTQ batch loader ...... mapping.cpp:65-121 (srand(0) per batch, N -> rand()%4)   [hostio.h]
+//   adaptor clipping -C ..... util.hpp:189-233                                          [hostio.h]
 //   SAM / MR / mapstats ..... mapping.cpp:47-63,329-419; paired.cpp:52-77,210-294,333-435,515-569
 // The mapping itself (mapping.cpp:486-500, paired.cpp:642-699) is one library call
-// per batch.  Output is byte-identical to the reference binary's
+// per batch.  Ingest and output formatting run on -t host threads (default: all),
+// each thread owning a contiguous range of the batch, so the files come out in
+// read order and byte-identical to the reference binary's
 // (tests/test_gpu_cli.py compares against the golden files).
 #include <stdint.h>
 #include <stdio.h>
@@ -24,9 +26,14 @@
 #include <vector>
 
 #include "../../../include/walt_amd.h"
+#include "hostio.h"
 
 using std::string;
 using std::vector;
+using hostio::Batch;
+using hostio::OutFile;
+using hostio::Sink;
+using hostio::View;
 
 static const uint32_t MAX_LINE_LENGTH = 1000;  // util.hpp:43
 static const int MINIMALREADLEN = 38;          // seedpattern.hpp:359
@@ -39,7 +46,7 @@ struct Options {
   string index_file, se_csv, pe1_csv, pe2_csv, out_csv, adaptor;
   bool sam = false, ambiguous = false, unmapped = false, ag = false, verbose = false;
   uint32_t max_mismatches = 6, batch_size = 10000000, b = 5000, top_k = 50;
-  int frag_range = 1000, threads = 1, device = 0;
+  int frag_range = 1000, threads = 0, device = 0;
 };
 
 static bool is_opt(const string& a, const char* s, const char* l) { return a == string("-") + s || a == string("-") + l || a == string("--") + l; }
@@ -89,70 +96,11 @@ static bool valid_suffix(const string& fn) {  // walt.cpp:58-64 (checks .fastq /
 }
 static bool exists(const string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
-// ---------------------------------------------------------------- adaptor clipping, util.hpp:189-233
-static const size_t head_length = 14, sufficient_head_match = 11, min_overlap = 5;
-static size_t similarity(const string& s, size_t pos, const string& adaptor) {
-  const size_t lim = std::min(std::min(s.length() - pos, adaptor.length()), head_length);
-  size_t count = 0;
-  for (size_t i = 0; i < lim; ++i) count += (s[pos + i] == adaptor[i]);
-  return count;
-}
-static size_t clip_adaptor_from_read(const string& adaptor, string& s) {
-  size_t lim1 = s.length() - head_length + 1;
-  for (size_t i = 0; i < lim1; ++i)
-    if (similarity(s, i, adaptor) >= sufficient_head_match) { std::fill(s.begin() + i, s.end(), 'N'); return s.length() - i; }
-  const size_t lim2 = s.length() - min_overlap + 1;
-  for (size_t i = lim1; i < lim2; ++i)
-    if (similarity(s, i, adaptor) >= s.length() - i - 1) { std::fill(s.begin() + i, s.end(), 'N'); return s.length() - i; }
-  return 0;
-}
-static void extract_adaptors(const string& adaptor, string& t_ad, string& a_ad) {
+static void extract_adaptors(const string& adaptor, string& t_ad, string& a_ad) {  // util.hpp:220-232
   const size_t sep = adaptor.find_first_of(":");
   if (adaptor.find_last_of(":") != sep) die("ERROR: adaptor format \"T_adaptor[:A_adaptor]\"");
   if (sep == string::npos) t_ad = a_ad = adaptor;
   else { t_ad = adaptor.substr(0, sep); a_ad = adaptor.substr(sep + 1); }
-}
-
-// ---------------------------------------------------------------- FASTQ loader, mapping.cpp:65-121
-struct Batch {
-  vector<string> names, seqs, scores;
-  uint32_t n = 0;
-};
-static char to_acgt(char c) {  // toACGT, util.hpp:156-163
-  if (c == 'A' || c == 'C' || c == 'G' || c == 'T') return c;
-  return "ACGT"[rand() % 4];
-}
-static void load_batch(FILE* fin, uint32_t n_per_batch, const string& adaptor, Batch& bt) {
-  srand(0);
-  char cline[MAX_LINE_LENGTH];
-  string line;
-  int line_code = 0;
-  uint32_t line_count = 0;
-  bt.n = 0;
-  const uint64_t lim = (uint64_t)n_per_batch * 4;
-  while (line_count < lim && fgets(cline, MAX_LINE_LENGTH, fin)) {
-    cline[strlen(cline) - 1] = 0;
-    line = cline;
-    if (line.size() == 0) continue;
-    if (bt.names.size() <= bt.n) { bt.names.resize(bt.n + 1); bt.seqs.resize(bt.n + 1); bt.scores.resize(bt.n + 1); }
-    switch (line_code) {
-      case 0: {
-        size_t sp = line.find_first_of(' ');
-        bt.names[bt.n] = sp == string::npos ? line.substr(1) : line.substr(1, sp - 1);
-        break;
-      }
-      case 1: {
-        if (!adaptor.empty()) clip_adaptor_from_read(adaptor, line);
-        for (size_t i = 0; i < line.size(); ++i) line[i] = to_acgt(line[i]);
-        bt.seqs[bt.n] = line;
-        break;
-      }
-      case 2: break;
-      case 3: bt.scores[bt.n] = line; bt.n++; break;
-    }
-    ++line_count;
-    if (++line_code == 4) line_code = 0;
-  }
 }
 
 // ---------------------------------------------------------------- genome info + helpers
@@ -179,32 +127,25 @@ static uint32_t chrom_id(const GenomeInfo& g, uint32_t pos) {  // getChromID, re
   }
   return l;
 }
-static string rev_str(const string& s) { return string(s.rbegin(), s.rend()); }
-static string revcomp(const string& s) {
-  string r(s.rbegin(), s.rend());
-  for (char& c : r) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
-  return r;
-}
-static void sam_head(const GenomeInfo& g, FILE* f) {  // SAMHead, reference.cpp:430-440
-  fprintf(f, "@HD\tVN:1.0\n");
-  for (size_t i = 0; i < g.name.size(); ++i) fprintf(f, "@SQ\tSN:%s\tLN:%u\n", g.name[i].c_str(), g.length[i]);
-  fprintf(f, "@PG\tID:WALT\tVN:%s\tCL:%s\n", "1.0", "walt");
+static string sam_head(const GenomeInfo& g) {  // SAMHead, reference.cpp:430-440
+  std::ostringstream os;
+  os << "@HD\tVN:1.0\n";
+  for (size_t i = 0; i < g.name.size(); ++i) os << "@SQ\tSN:" << g.name[i] << "\tLN:" << g.length[i] << "\n";
+  os << "@PG\tID:WALT\tVN:1.0\tCL:walt\n";
+  return os.str();
 }
 
-struct SeStats {  // StatSingleReads, mapping.hpp:55-108
+// sinks of one host thread: main output, then the _ambiguous / _unmapped side files of mate 1 and mate 2
+enum { kMain = 0, kAmb1 = 1, kUnm1 = 2, kAmb2 = 3, kUnm2 = 4, kSinks = 5 };
+
+struct SeCounts {  // StatSingleReads, mapping.hpp:55-108
   uint32_t total = 0, unique = 0, ambiguous = 0, unmapped = 0, too_short = 0;
-  FILE* famb = nullptr;
-  FILE* funm = nullptr;
-  bool out_amb = false, out_unm = false, sam = false;
-  void open(bool a, bool u, const string& out, bool is_sam) {
-    out_amb = a; out_unm = u; sam = is_sam;
-    if (a && !sam && !(famb = fopen((out + "_ambiguous").c_str(), "w"))) die("cannot open input file " + out + "_ambiguous");
-    if (u && !sam && !(funm = fopen((out + "_unmapped").c_str(), "w"))) die("cannot open input file " + out + "_unmapped");
-  }
-  void close() { if (famb) fclose(famb); if (funm) fclose(funm); famb = funm = nullptr; }
   void update(uint32_t times) {  // StatInfoUpdate, mapping.cpp:318-327
     ++total;
     if (times == 0) unmapped++; else if (times == 1) unique++; else ambiguous++;
+  }
+  void add(const SeCounts& o) {
+    total += o.total; unique += o.unique; ambiguous += o.ambiguous; unmapped += o.unmapped; too_short += o.too_short;
   }
   string tostring(size_t n_tabs = 0) const {  // mapping.cpp:47-63
     string t;
@@ -221,87 +162,148 @@ struct SeStats {  // StatSingleReads, mapping.hpp:55-108
     return oss.str();
   }
 };
+struct SideFiles {  // the _ambiguous / _unmapped files of StatSingleReads (mapping.hpp:75-87)
+  OutFile amb, unm;
+  bool out_amb = false, out_unm = false;
+  void open(bool a, bool u, const string& out, bool sam) {
+    out_amb = a; out_unm = u;
+    if (a && !sam && !amb.open_trunc(out + "_ambiguous")) die("cannot open input file " + out + "_ambiguous");
+    if (u && !sam && !unm.open_trunc(out + "_unmapped")) die("cannot open input file " + out + "_unmapped");
+  }
+  void close() { amb.close(); unm.close(); }
+};
 
 // ---------------------------------------------------------------- single-end writers, mapping.cpp:329-419
-static void out_mr_line(const walt_best_match& bm, const string& name, const string& seq, const string& score,
-                        const GenomeInfo& g, bool ag, FILE* f) {
+static void out_mr_line(const walt_best_match& bm, View name, View seq, View score, bool flip, const GenomeInfo& g,
+                        bool ag, Sink& f) {
   uint32_t chr = chrom_id(g, bm.genome_pos);
   uint32_t start = bm.genome_pos - g.start[chr];
-  if (bm.strand == '-') start = g.length[chr] - start - (uint32_t)seq.size();
-  uint32_t end = start + (uint32_t)seq.size();
+  if (bm.strand == '-') start = g.length[chr] - start - seq.len;
+  uint32_t end = start + seq.len;
   char strand = bm.strand;
   if (ag) strand = bm.strand == '+' ? '-' : '+';
-  fprintf(f, "%s\t%u\t%u\t%s\t%u\t%c\t%s\t%s\n", g.name[chr].c_str(), start, end, name.c_str(), bm.mismatch, strand,
-          seq.c_str(), score.c_str());
+  f.put(g.name[chr]); f.ch('\t'); f.u32(start); f.ch('\t'); f.u32(end); f.ch('\t'); f.put(name); f.ch('\t');
+  f.u32(bm.mismatch); f.ch('\t'); f.ch(strand); f.ch('\t');
+  if (flip) { f.revcomp(seq); f.ch('\t'); f.rev(score); } else { f.put(seq); f.ch('\t'); f.put(score); }
+  f.ch('\n');
 }
-static void out_single_results(const walt_best_match& bm, const string& name, const string& seq, const string& score,
-                               const GenomeInfo& g, bool ag, SeStats& st, FILE* fout) {
-  string s = seq, q = score;
-  if (ag) { s = revcomp(s); q = rev_str(q); }
-  if (bm.times == 0 && st.out_unm) fprintf(st.funm, "%s\t%s\t%s\n", name.c_str(), s.c_str(), q.c_str());
-  else if (bm.times == 1) out_mr_line(bm, name, s, q, g, ag, fout);
-  else if (bm.times >= 2 && st.out_amb) out_mr_line(bm, name, s, q, g, ag, st.famb);
+// OutputSingleResults, mapping.cpp:329-380: A-rich reads are printed reverse-complemented
+static void out_single_results(const walt_best_match& bm, View name, View seq, View score, const GenomeInfo& g, bool ag,
+                               bool out_amb, bool out_unm, Sink& fout, Sink& famb, Sink& funm) {
+  if (bm.times == 0 && out_unm) {
+    funm.put(name); funm.ch('\t');
+    if (ag) { funm.revcomp(seq); funm.ch('\t'); funm.rev(score); } else { funm.put(seq); funm.ch('\t'); funm.put(score); }
+    funm.ch('\n');
+  } else if (bm.times == 1) {
+    out_mr_line(bm, name, seq, score, ag, g, ag, fout);
+  } else if (bm.times >= 2 && out_amb) {
+    out_mr_line(bm, name, seq, score, ag, g, ag, famb);
+  }
 }
-static void out_single_sam(const walt_best_match& bm, const string& name, const string& seq, const string& score,
-                           const GenomeInfo& g, SeStats& st, FILE* fout) {
+static void put_seq_qual(Sink& f, View seq, View score, bool flip) {
+  if (flip) { f.revcomp(seq); f.ch('\t'); f.rev(score); } else { f.put(seq); f.ch('\t'); f.put(score); }
+}
+// OutputSingleSAM, mapping.cpp:382-419
+static void out_single_sam(const walt_best_match& bm, View name, View seq, View score, const GenomeInfo& g,
+                           bool out_amb, bool out_unm, Sink& f) {
   uint32_t chr = chrom_id(g, bm.genome_pos);
   uint32_t start = bm.genome_pos - g.start[chr];
-  if (bm.strand == '-') start = g.length[chr] - start - (uint32_t)seq.size();
-  string s = seq, q = score;
-  if (bm.strand == '-') { s = revcomp(s); q = rev_str(q); }
-  uint32_t len = (uint32_t)seq.size();
+  if (bm.strand == '-') start = g.length[chr] - start - seq.len;
+  const bool flip = bm.strand == '-';
   int flag = (bm.times == 0 ? 0x4 : 0) + (bm.strand == '-' ? 0x10 : 0) + (bm.times >= 2 ? 0x100 : 0);
-  if (bm.times == 0 && st.out_unm)
-    fprintf(fout, "%s\t%d\t*\t0\t255\t*\t*\t0\t0\t%s\t%s\tNM:i:0\n", name.c_str(), flag, s.c_str(), q.c_str());
-  else if (bm.times == 1 || (bm.times >= 2 && st.out_amb))
-    fprintf(fout, "%s\t%d\t%s\t%u\t255\t%uM\t*\t0\t0\t%s\t%s\tNM:i:%u\n", name.c_str(), flag, g.name[chr].c_str(),
-            start + 1, len, s.c_str(), q.c_str(), bm.mismatch);
+  if (bm.times == 0 && out_unm) {
+    f.put(name); f.ch('\t'); f.i32(flag); f.lit("\t*\t0\t255\t*\t*\t0\t0\t");
+    put_seq_qual(f, seq, score, flip);
+    f.lit("\tNM:i:0\n");
+  } else if (bm.times == 1 || (bm.times >= 2 && out_amb)) {
+    f.put(name); f.ch('\t'); f.i32(flag); f.ch('\t'); f.put(g.name[chr]); f.ch('\t'); f.u32(start + 1);
+    f.lit("\t255\t"); f.u32(seq.len); f.lit("M\t*\t0\t0\t");
+    put_seq_qual(f, seq, score, flip);
+    f.lit("\tNM:i:"); f.u32(bm.mismatch); f.ch('\n');
+  }
 }
 
-static void pack_batch(const Batch& bt, string& bases, vector<uint64_t>& offsets) {
-  bases.clear();
-  offsets.assign(bt.n + 1, 0);
-  for (uint32_t j = 0; j < bt.n; ++j) { bases += bt.seqs[j]; offsets[j + 1] = bases.size(); }
+static int host_threads(const Options& o) { return o.threads > 0 ? o.threads : hostio::effective_cpus(); }
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
 // ProcessSingledEndReads, mapping.cpp:421-526
 static void process_se(const Options& o, const string& reads_file, const string& out_file) {
+  const int T = host_threads(o);
+  double t0 = now_s();
   walt_index* idx = nullptr;
   check(walt_index_open(o.index_file.c_str(), o.device, o.ag ? WALT_STRANDS_GA : WALT_STRANDS_CT, -1, &idx));
+  double t_index = now_s() - t0, t_load = 0, t_map = 0, t_out = 0;
   GenomeInfo g = genome_of(idx);
-  FILE* fin = fopen(reads_file.c_str(), "r");
-  if (!fin) die("cannot open input file " + reads_file);
-  FILE* fout = fopen(out_file.c_str(), "a");
-  if (!fout) die("cannot open input file " + out_file);
-  SeStats st;
-  st.open(o.ambiguous, o.unmapped, out_file, o.sam);
+  hostio::FastqReader rd;
+  rd.open(reads_file, T);
+  OutFile fout;
+  if (!fout.open_append(out_file)) die("cannot open input file " + out_file);
+  SideFiles side;
+  side.open(o.ambiguous, o.unmapped, out_file, o.sam);
+  SeCounts st;
   if (o.verbose) std::cerr << "input_file: " << reads_file << std::endl << "output_file: " << out_file << std::endl;
-  if (o.sam) sam_head(g, fout);
+  if (o.sam) { string h = sam_head(g); fout.write(h.data(), h.size()); }
   Batch bt;
-  string bases;
-  vector<uint64_t> offsets;
-  vector<walt_best_match> res;
+  walt_best_match* res = nullptr;
+  size_t res_cap = 0;
+  vector<Sink> sinks((size_t)T * kSinks);
+  vector<SeCounts> acc(T);
   for (;;) {
-    load_batch(fin, o.batch_size, o.adaptor, bt);
+    t0 = now_s();
+    rd.load(o.batch_size, o.adaptor, bt);
+    t_load += now_s() - t0;
     if (bt.n == 0) break;
-    pack_batch(bt, bases, offsets);
-    res.resize(bt.n);
-    walt_batch_stats bs;
-    check(walt_map_se_batch(idx, bases.data(), offsets.data(), bt.n, o.ag, o.max_mismatches, o.b, res.data(), &bs));
-    st.too_short += (uint32_t)bs.too_short;
-    for (uint32_t j = 0; j < bt.n; ++j) {
-      st.update(res[j].times);
-      if (!o.sam) out_single_results(res[j], bt.names[j], bt.seqs[j], bt.scores[j], g, o.ag, st, fout);
-      else out_single_sam(res[j], bt.names[j], bt.seqs[j], bt.scores[j], g, st, fout);
+    const uint32_t n = bt.n;
+    if (res_cap < n) {
+      walt_host_free(res);
+      res = nullptr;
+      res_cap = n + n / 8;
+      check(walt_host_alloc(res_cap * sizeof(walt_best_match), (void**)&res));
     }
-    if (bt.n < o.batch_size) break;
+    t0 = now_s();
+    walt_batch_stats bs;
+    check(walt_map_se_batch(idx, bt.bases, bt.offsets, n, o.ag, o.max_mismatches, o.b, res, &bs));
+    t_map += now_s() - t0;
+    st.too_short += (uint32_t)bs.too_short;
+    t0 = now_s();
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; ++t) {
+      Sink* s = &sinks[(size_t)t * kSinks];
+      for (int k = 0; k < kSinks; ++k) s[k].clear();
+      SeCounts c;
+      const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+      for (uint32_t j = lo; j < hi; ++j) {
+        c.update(res[j].times);
+        if (!o.sam) out_single_results(res[j], bt.name(j), bt.seq(j), bt.score(j), g, o.ag, side.out_amb, side.out_unm,
+                                       s[kMain], s[kAmb1], s[kUnm1]);
+        else out_single_sam(res[j], bt.name(j), bt.seq(j), bt.score(j), g, side.out_amb, side.out_unm, s[kMain]);
+      }
+      acc[t] = c;
+    }
+    for (int t = 0; t < T; ++t) st.add(acc[t]);
+    fout.write_sinks(sinks, kSinks, kMain, T);
+    side.amb.write_sinks(sinks, kSinks, kAmb1, T);
+    side.unm.write_sinks(sinks, kSinks, kUnm1, T);
+    t_out += now_s() - t0;
+    if (n < o.batch_size) break;
   }
-  fclose(fin);
-  fclose(fout);
-  st.close();
+  if (o.verbose)
+    fprintf(stderr, "[walt_amd ingest: line scan %.2f s, views %.2f s, buffers %.2f s, copy %.2f s, N draws %.2f s]\n",
+            rd.t_scan, rd.t_views, rd.t_alloc, rd.t_copy, rd.t_rng);
+  rd.close();
+  fout.close();
+  side.close();
+  walt_host_free(res);
   std::ofstream mapstats(out_file + ".mapstats", std::ios::app);
   mapstats << st.tostring() << std::endl;
   walt_index_close(idx);
+  if (o.verbose)
+    fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, output %.2f s]\n", T, t_index,
+            t_load, t_map, t_out);
 }
 
 // ---------------------------------------------------------------- paired-end writers
@@ -311,12 +313,19 @@ static void forward_pos(uint32_t gp, char strand, uint32_t chr, uint32_t read_le
   s = strand == '+' ? s : g.length[chr] - s - read_len;
   e = s + read_len;
 }
+static string revcomp_str(View v) {
+  string r(v.len, 'N');
+  for (uint32_t i = 0; i < v.len; ++i) {
+    char c = v.p[v.len - 1 - i];
+    r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+  }
+  return r;
+}
+static string rev_str(View v) { return string(std::reverse_iterator<const char*>(v.p + v.len), std::reverse_iterator<const char*>(v.p)); }
 // OutputBestPairedResults, paired.cpp:210-294
 static int out_best_pair(const walt_candidate& r1, const walt_candidate& r2, int frag_range, const GenomeInfo& g,
-                         const string& name, const string& seq1, const string& scr1, const string& seq2,
-                         const string& scr2, bool sam, FILE* fout) {
-  const uint32_t len1 = (uint32_t)seq1.size(), len2 = (uint32_t)seq2.size();
-  string seq2r = revcomp(seq2), scr2r = rev_str(scr2);
+                         View name, View vseq1, View vscr1, View vseq2, View vscr2, bool sam, Sink& fout) {
+  const uint32_t len1 = vseq1.len, len2 = vseq2.len;
   uint32_t c1 = chrom_id(g, r1.genome_pos), c2 = chrom_id(g, r2.genome_pos);
   uint32_t s1, s2, e1, e2;
   forward_pos(r1.genome_pos, r1.strand, c1, len1, g, s1, e1);
@@ -329,6 +338,8 @@ static int out_best_pair(const walt_candidate& r1, const walt_candidate& r2, int
   uint32_t two_r = plus ? e2 : std::min(ov_s, e2);
   int len = plus ? (int)(two_r - one_l) : (int)(one_r - two_l);
   if (sam) return len;
+  const string seq1(vseq1.p, vseq1.len), scr1(vscr1.p, vscr1.len);
+  const string seq2r = revcomp_str(vseq2), scr2r = rev_str(vscr2);
   string seq(len, 'N'), scr(len, 'B');
   if (len > 0 && len <= frag_range) {
     uint32_t lim_one = one_r - one_l;
@@ -352,8 +363,9 @@ static int out_best_pair(const walt_candidate& r1, const walt_candidate& r2, int
     }
   }
   uint32_t start_pos = plus ? s1 : s2;
-  fprintf(fout, "%s\t%u\t%u\tFRAG:%s\t%u\t%c\t%s\t%s\n", g.name[c1].c_str(), start_pos, start_pos + len, name.c_str(),
-          r1.mismatch + r2.mismatch, r1.strand, seq.c_str(), scr.c_str());
+  fout.put(g.name[c1]); fout.ch('\t'); fout.u32(start_pos); fout.ch('\t'); fout.u32(start_pos + len);
+  fout.lit("\tFRAG:"); fout.put(name); fout.ch('\t'); fout.u32(r1.mismatch + r2.mismatch); fout.ch('\t');
+  fout.ch(r1.strand); fout.ch('\t'); fout.put(seq); fout.ch('\t'); fout.put(scr); fout.ch('\n');
   return len;
 }
 static int sam_flag(bool paired_mapped, bool unmapped, bool next_unmapped, bool rev, bool next_rev, bool first,
@@ -361,15 +373,23 @@ static int sam_flag(bool paired_mapped, bool unmapped, bool next_unmapped, bool 
   return 0x1 + (paired_mapped ? 0x2 : 0) + (unmapped ? 0x4 : 0) + (next_unmapped ? 0x8 : 0) + (rev ? 0x10 : 0) +
          (next_rev ? 0x20 : 0) + (first ? 0x40 : 0x80) + (secondary ? 0x100 : 0);
 }
+static void sam_mate_line(Sink& f, View name, int flag, bool mapped, const string& chrom, uint32_t pos, uint32_t read_len,
+                          const string& rnext, uint32_t pnext, int tlen, View seq, View score, bool flip, uint32_t mm) {
+  f.put(name); f.ch('\t'); f.i32(flag); f.ch('\t');
+  if (mapped) { f.put(chrom); f.ch('\t'); f.u32(pos); f.lit("\t255\t"); f.u32(read_len); f.lit("M\t"); }
+  else { f.lit("*\t"); f.u32(pos); f.lit("\t255\t*\t"); }
+  f.put(rnext); f.ch('\t'); f.u32(pnext); f.ch('\t'); f.i32(tlen); f.ch('\t');
+  put_seq_qual(f, seq, score, flip);
+  f.lit("\tNM:i:"); f.u32(mm); f.ch('\n');
+}
 // OutputPairedSAM, paired.cpp:333-435
-static void out_paired_sam(const walt_best_match& b1, const walt_best_match& b2, const GenomeInfo& g,
-                           const string& name, const string& seq1, const string& scr1, const string& seq2,
-                           const string& scr2, int len, int flag_1, int flag_2, bool out_amb, bool out_unm,
-                           FILE* fout) {
+static void out_paired_sam(const walt_best_match& b1, const walt_best_match& b2, const GenomeInfo& g, View name,
+                           View seq1, View scr1, View seq2, View scr2, int len, int flag_1, int flag_2, bool out_amb,
+                           bool out_unm, Sink& fout) {
   uint32_t c1 = chrom_id(g, b1.genome_pos), c2 = chrom_id(g, b2.genome_pos);
   uint32_t s1, s2, e1, e2;
-  forward_pos(b1.genome_pos, b1.strand, c1, (uint32_t)seq1.size(), g, s1, e1);
-  forward_pos(b2.genome_pos, b2.strand, c2, (uint32_t)seq2.size(), g, s2, e2);
+  forward_pos(b1.genome_pos, b1.strand, c1, seq1.len, g, s1, e1);
+  forward_pos(b2.genome_pos, b2.strand, c2, seq2.len, g, s2, e2);
   uint32_t mm1 = b1.mismatch, mm2 = b2.mismatch;
   if (b1.times == 0) { s1 = 0; mm1 = 0; } else s1 += 1;
   if (b2.times == 0) { s2 = 0; mm2 = 0; } else s2 += 1;
@@ -380,53 +400,56 @@ static void out_paired_sam(const walt_best_match& b1, const walt_best_match& b2,
     rn1 = b1.times == 0 ? "*" : g.name[c1];
     rn2 = b2.times == 0 ? "*" : g.name[c2];
   }
-  string q1 = seq1, q2 = seq2, k1 = scr1, k2 = scr2;
-  if (b1.strand == '-') { q1 = revcomp(q1); k1 = rev_str(k1); }
-  if (b2.strand == '-') { q2 = revcomp(q2); k2 = rev_str(k2); }
-  const uint32_t rl1 = (uint32_t)seq1.size(), rl2 = (uint32_t)seq2.size();
   if (b1.times == 0 && out_unm)
-    fprintf(fout, "%s\t%d\t*\t%u\t255\t*\t%s\t%u\t%d\t%s\t%s\tNM:i:%u\n", name.c_str(), flag_1, s1, rn2.c_str(), s2, len1,
-            q1.c_str(), k1.c_str(), mm1);
+    sam_mate_line(fout, name, flag_1, false, g.name[c1], s1, seq1.len, rn2, s2, len1, seq1, scr1, b1.strand == '-', mm1);
   else if (b1.times == 1 || (b1.times >= 2 && out_amb))
-    fprintf(fout, "%s\t%d\t%s\t%u\t255\t%uM\t%s\t%u\t%d\t%s\t%s\tNM:i:%u\n", name.c_str(), flag_1, g.name[c1].c_str(), s1,
-            rl1, rn2.c_str(), s2, len1, q1.c_str(), k1.c_str(), mm1);
+    sam_mate_line(fout, name, flag_1, true, g.name[c1], s1, seq1.len, rn2, s2, len1, seq1, scr1, b1.strand == '-', mm1);
   if (b2.times == 0 && out_unm)
-    fprintf(fout, "%s\t%d\t*\t%u\t255\t*\t%s\t%u\t%d\t%s\t%s\tNM:i:%u\n", name.c_str(), flag_2, s2, rn1.c_str(), s1, len2,
-            q2.c_str(), k2.c_str(), mm2);
+    sam_mate_line(fout, name, flag_2, false, g.name[c2], s2, seq2.len, rn1, s1, len2, seq2, scr2, b2.strand == '-', mm2);
   else if (b2.times == 1 || (b2.times >= 2 && out_amb))
-    fprintf(fout, "%s\t%d\t%s\t%u\t255\t%uM\t%s\t%u\t%d\t%s\t%s\tNM:i:%u\n", name.c_str(), flag_2, g.name[c2].c_str(), s2,
-            rl2, rn1.c_str(), s1, len2, q2.c_str(), k2.c_str(), mm2);
+    sam_mate_line(fout, name, flag_2, true, g.name[c2], s2, seq2.len, rn1, s1, len2, seq2, scr2, b2.strand == '-', mm2);
 }
+
+struct PeAcc {
+  SeCounts st1, st2;
+  uint32_t unique_pairs = 0, ambiguous_pairs = 0, unmapped_pairs = 0;
+  vector<uint32_t> frag_count;
+};
 
 // ProcessPairedEndReads, paired.cpp:572-713
 static void process_pe(const Options& o, const string& f1, const string& f2, const string& out_file) {
+  const int T = host_threads(o);
+  double t0 = now_s();
   walt_index* idx = nullptr;
   check(walt_index_open(o.index_file.c_str(), o.device, WALT_STRANDS_ALL, -1, &idx));
+  double t_index = now_s() - t0, t_load = 0, t_map = 0, t_out = 0;
   GenomeInfo g = genome_of(idx);
-  FILE* fin[2] = {fopen(f1.c_str(), "r"), fopen(f2.c_str(), "r")};
-  if (!fin[0]) die("cannot open input file " + f1);
-  if (!fin[1]) die("cannot open input file " + f2);
+  hostio::FastqReader rd[2];
+  rd[0].open(f1, T);
+  rd[1].open(f2, T);
   string adaptors[2];
   extract_adaptors(o.adaptor, adaptors[0], adaptors[1]);
-  FILE* fout = fopen(out_file.c_str(), "a");
-  if (!fout) die("cannot open input file " + out_file);
-  SeStats st1, st2;  // StatPairedReads, paired.hpp:78-106
-  st1.open(o.ambiguous, o.unmapped, out_file + "_1", o.sam);
-  st2.open(o.ambiguous, o.unmapped, out_file + "_2", o.sam);
+  OutFile fout;
+  if (!fout.open_append(out_file)) die("cannot open input file " + out_file);
+  SideFiles side1, side2;  // StatPairedReads, paired.hpp:78-106
+  side1.open(o.ambiguous, o.unmapped, out_file + "_1", o.sam);
+  side2.open(o.ambiguous, o.unmapped, out_file + "_2", o.sam);
+  SeCounts st1, st2;
   uint32_t total_pairs = 0, unique_pairs = 0, ambiguous_pairs = 0, unmapped_pairs = 0;
   vector<uint32_t> frag_count(o.frag_range + 1, 0);
   fprintf(stderr, "[MAPPING PAIRED-END READS FROM THE FOLLOWING TWO FILES]\n   %s (AND)\n   %s\n", f1.c_str(), f2.c_str());
   fprintf(stderr, "[OUTPUT MAPPING RESULTS TO %s]\n", out_file.c_str());
-  if (o.sam) sam_head(g, fout);
+  if (o.sam) { string h = sam_head(g); fout.write(h.data(), h.size()); }
   Batch bt[2];
-  string bases[2];
-  vector<uint64_t> offs[2];
-  vector<walt_pair_result> pr;
-  vector<walt_candidate> rk[2];
-  vector<uint32_t> rn[2];
+  walt_pair_result* pr = nullptr;
+  size_t pr_cap = 0;
+  vector<Sink> sinks((size_t)T * kSinks);
+  vector<PeAcc> acc(T);
   for (;;) {
-    load_batch(fin[0], o.batch_size, adaptors[0], bt[0]);
-    if (bt[0].n) load_batch(fin[1], o.batch_size, adaptors[1], bt[1]); else bt[1].n = 0;
+    t0 = now_s();
+    rd[0].load(o.batch_size, adaptors[0], bt[0]);
+    if (bt[0].n) rd[1].load(o.batch_size, adaptors[1], bt[1]); else bt[1].n = 0;
+    t_load += now_s() - t0;
     if (bt[0].n && bt[0].n != bt[1].n) {
       fprintf(stderr, "The number of reads in paired-end files should be the same.\n");
       exit(EXIT_FAILURE);
@@ -434,48 +457,77 @@ static void process_pe(const Options& o, const string& f1, const string& f2, con
     if (bt[0].n == 0) break;
     const uint32_t n = bt[0].n;
     total_pairs += n;
-    for (int m = 0; m < 2; ++m) { pack_batch(bt[m], bases[m], offs[m]); rk[m].resize((size_t)n * o.top_k); rn[m].resize(n); }
-    pr.resize(n);
+    if (pr_cap < n) {
+      walt_host_free(pr);
+      pr = nullptr;
+      pr_cap = n + n / 8;
+      check(walt_host_alloc(pr_cap * sizeof(walt_pair_result), (void**)&pr));
+    }
+    t0 = now_s();
     walt_batch_stats bs[2];
-    check(walt_map_pe_batch(idx, bases[0].data(), offs[0].data(), bases[1].data(), offs[1].data(), n, o.max_mismatches,
-                            o.b, o.top_k, o.frag_range, pr.data(), rk[0].data(), rn[0].data(), rk[1].data(),
-                            rn[1].data(), bs));
+    // the best pair's two candidates come back inside walt_pair_result (m1/m2), so the ranked lists stay on the GPU
+    check(walt_map_pe_batch(idx, bt[0].bases, bt[0].offsets, bt[1].bases, bt[1].offsets, n, o.max_mismatches, o.b,
+                            o.top_k, o.frag_range, pr, nullptr, nullptr, nullptr, nullptr, bs));
+    t_map += now_s() - t0;
     st1.too_short += (uint32_t)bs[0].too_short;
     st2.too_short += (uint32_t)bs[1].too_short;
-    for (uint32_t j = 0; j < n; ++j) {  // MergePairedEndResults tail, paired.cpp:515-569
-      const walt_pair_result& p = pr[j];
-      const string &name = bt[0].names[j], &q1 = bt[0].seqs[j], &k1 = bt[0].scores[j], &q2 = bt[1].seqs[j],
-                   &k2 = bt[1].scores[j];
-      walt_best_match bm1 = {0, 0, '+', {0, 0, 0}, o.max_mismatches}, bm2 = bm1;
-      bool is_paired = false;
-      int len = 0;
-      if (p.best_times == 1) {
-        unique_pairs++;
-        const walt_candidate& r1 = rk[0][(size_t)j * o.top_k + p.best_i];
-        const walt_candidate& r2 = rk[1][(size_t)j * o.top_k + p.best_j];
-        len = out_best_pair(r1, r2, o.frag_range, g, name, q1, k1, q2, k2, o.sam, fout);
-        frag_count[len]++;
-        if (o.sam) { is_paired = true; bm1 = p.m1; bm2 = p.m2; }
-      } else {
-        if (p.best_times >= 2) ambiguous_pairs++; else unmapped_pairs++;
-        bm1 = p.m1; bm2 = p.m2;
-        st1.update(bm1.times);
-        st2.update(bm2.times);
-        if (!o.sam) {
-          out_single_results(bm1, name, q1, k1, g, false, st1, fout);
-          out_single_results(bm2, name, q2, k2, g, true, st2, fout);
+    t0 = now_s();
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; ++t) {
+      Sink* s = &sinks[(size_t)t * kSinks];
+      for (int k = 0; k < kSinks; ++k) s[k].clear();
+      PeAcc a;
+      a.frag_count.assign(o.frag_range + 1, 0);
+      const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+      for (uint32_t j = lo; j < hi; ++j) {  // MergePairedEndResults tail, paired.cpp:515-569
+        const walt_pair_result& p = pr[j];
+        const View name = bt[0].name(j), q1 = bt[0].seq(j), k1 = bt[0].score(j), q2 = bt[1].seq(j), k2 = bt[1].score(j);
+        walt_best_match bm1 = {0, 0, '+', {0, 0, 0}, o.max_mismatches}, bm2 = bm1;
+        bool is_paired = false;
+        int len = 0;
+        if (p.best_times == 1) {
+          a.unique_pairs++;
+          walt_candidate r1 = {p.m1.genome_pos, p.m1.strand, {0, 0, 0}, p.m1.mismatch};
+          walt_candidate r2 = {p.m2.genome_pos, p.m2.strand, {0, 0, 0}, p.m2.mismatch};
+          len = out_best_pair(r1, r2, o.frag_range, g, name, q1, k1, q2, k2, o.sam, s[kMain]);
+          a.frag_count[len]++;
+          if (o.sam) { is_paired = true; bm1 = p.m1; bm2 = p.m2; }
+        } else {
+          if (p.best_times >= 2) a.ambiguous_pairs++; else a.unmapped_pairs++;
+          bm1 = p.m1; bm2 = p.m2;
+          a.st1.update(bm1.times);
+          a.st2.update(bm2.times);
+          if (!o.sam) {
+            out_single_results(bm1, name, q1, k1, g, false, side1.out_amb, side1.out_unm, s[kMain], s[kAmb1], s[kUnm1]);
+            out_single_results(bm2, name, q2, k2, g, true, side2.out_amb, side2.out_unm, s[kMain], s[kAmb2], s[kUnm2]);
+          }
+        }
+        if (o.sam) {
+          int fl1 = sam_flag(is_paired, bm1.times == 0, bm2.times == 0, bm1.strand == '-', bm2.strand == '-', true, bm1.times >= 2);
+          int fl2 = sam_flag(is_paired, bm2.times == 0, bm1.times == 0, bm2.strand == '-', bm1.strand == '-', false, bm2.times >= 2);
+          out_paired_sam(bm1, bm2, g, name, q1, k1, q2, k2, len, fl1, fl2, o.ambiguous, o.unmapped, s[kMain]);
         }
       }
-      if (o.sam) {
-        int fl1 = sam_flag(is_paired, bm1.times == 0, bm2.times == 0, bm1.strand == '-', bm2.strand == '-', true, bm1.times >= 2);
-        int fl2 = sam_flag(is_paired, bm2.times == 0, bm1.times == 0, bm2.strand == '-', bm1.strand == '-', false, bm2.times >= 2);
-        out_paired_sam(bm1, bm2, g, name, q1, k1, q2, k2, len, fl1, fl2, o.ambiguous, o.unmapped, fout);
-      }
+      acc[t] = std::move(a);
     }
+    for (int t = 0; t < T; ++t) {
+      st1.add(acc[t].st1);
+      st2.add(acc[t].st2);
+      unique_pairs += acc[t].unique_pairs; ambiguous_pairs += acc[t].ambiguous_pairs; unmapped_pairs += acc[t].unmapped_pairs;
+      for (size_t i = 0; i < frag_count.size(); ++i) frag_count[i] += acc[t].frag_count[i];
+    }
+    fout.write_sinks(sinks, kSinks, kMain, T);
+    side1.amb.write_sinks(sinks, kSinks, kAmb1, T);
+    side1.unm.write_sinks(sinks, kSinks, kUnm1, T);
+    side2.amb.write_sinks(sinks, kSinks, kAmb2, T);
+    side2.unm.write_sinks(sinks, kSinks, kUnm2, T);
+    t_out += now_s() - t0;
     if (n < o.batch_size) break;
   }
-  fclose(fin[0]); fclose(fin[1]); fclose(fout);
-  st1.close(); st2.close();
+  rd[0].close(); rd[1].close();
+  fout.close();
+  side1.close(); side2.close();
+  walt_host_free(pr);
   std::ofstream mapstats(out_file + ".mapstats", std::ios::app);  // StatPairedReads::tostring, paired.cpp:52-77
   std::ostringstream oss;
   oss << "pairs:" << std::endl
@@ -496,6 +548,9 @@ static void process_pe(const Options& o, const string& f1, const string& f2, con
   oss << "frag_len_mean: " << total / std::accumulate(frag_count.begin(), frag_count.end(), 0.0);
   mapstats << oss.str() << std::endl;
   walt_index_close(idx);
+  if (o.verbose)
+    fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, output %.2f s]\n", T, t_index,
+            t_load, t_map, t_out);
 }
 
 int main(int argc, const char** argv) {
