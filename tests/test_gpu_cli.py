@@ -119,3 +119,73 @@ def test_cli_awkward_fastq_matches_reference_binary(cli_index, scratch, mode, ex
     for fn in outs["ref"]:
         assert outs["gpu"][fn] == outs["ref"][fn], "%s: %s differs" % (tag, fn)
     assert len(outs["ref"]["out"]) > 1000
+
+
+def _run_cli(wd, args):
+    os.makedirs(wd, exist_ok=True)
+    for fn in os.listdir(wd):
+        os.remove(os.path.join(wd, fn))
+    subprocess.run([WALT_BIN] + args, check=True, cwd=wd, stderr=subprocess.DEVNULL)
+    return {fn: open(os.path.join(wd, fn)).read() for fn in sorted(os.listdir(wd))}
+
+
+def _swap_mapstats_mates(text):
+    lines = text.split("\n")
+    i1, i2 = lines.index("mate1:"), lines.index("mate2:")
+    i3 = lines.index("frag_len_distribution:")
+    return "\n".join(lines[:i1] + ["mate1:"] + lines[i2 + 1:i3] + ["mate2:"] + lines[i1 + 1:i2] + lines[i3:])
+
+
+def test_cli_pbat_is_the_mate_swapped_run_put_back_in_user_order(cli_index, scratch):
+    """-P has no implementation in the reference snapshot (parity unpinned).  It is defined by
+    equivalence: `-P -1 X -2 Y` maps like `-1 Y -2 X`, then restores the user's order: X's record first,
+    0x40 on X / 0x80 on Y, QNAME from X, _1 side files and the mate1 mapstats block for X.  So with
+    X = pe_2.fastq, Y = pe_1.fastq the expected files are a rewrite of the golden pe_1/pe_2 outputs."""
+    p1, p2 = os.path.join(refio.GOLDEN, "pe_1.fastq"), os.path.join(refio.GOLDEN, "pe_2.fastq")
+
+    def qname(n):  # golden runs print pe_1's names ("…/1"); the PBAT run prints its own -1 file's ("…/2")
+        assert n.endswith("/1")
+        return n[:-1] + "2"
+
+    # SAM
+    got = _run_cli(os.path.join(scratch, "pbat_sam"), ["-i", cli_index, "-o", "out.sam", "-P", "-1", p2, "-2", p1,
+                                                      "-sam", "-a", "-u"])
+    want_lines = refio.golden_file("pe_sam_au", "out.sam").splitlines()
+    head = [ln for ln in want_lines if ln.startswith("@")]
+    body = [ln for ln in want_lines if not ln.startswith("@")]
+    assert len(body) % 2 == 0
+    exp = list(head)
+    for a, b in zip(body[0::2], body[1::2]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert int(fa[1]) & 0x40 and int(fb[1]) & 0x80
+        fa[1], fb[1] = str(int(fa[1]) ^ 0xC0), str(int(fb[1]) ^ 0xC0)
+        fa[0], fb[0] = qname(fa[0]), qname(fb[0])
+        exp += ["\t".join(fb), "\t".join(fa)]
+    assert got["out.sam"].splitlines() == exp
+    assert got["out.sam.mapstats"] == _swap_mapstats_mates(refio.golden_file("pe_sam_au", "out.sam.mapstats"))
+
+    # MR with side files
+    got = _run_cli(os.path.join(scratch, "pbat_mr"), ["-i", cli_index, "-o", "out.mr", "-P", "-1", p2, "-2", p1, "-a", "-u"])
+
+    def rename(line, col):
+        f = line.split("\t")
+        f[col] = ("FRAG:" + qname(f[col][5:])) if f[col].startswith("FRAG:") else qname(f[col])
+        return "\t".join(f)
+
+    want_main = [rename(ln, 3) for ln in refio.golden_file("pe_mr_au", "out.mr").splitlines()]
+    got_main = got["out.mr"].splitlines()
+    frag = lambda ls: [ln for ln in ls if "\tFRAG:" in ln]
+    single = lambda ls: sorted(ln for ln in ls if "\tFRAG:" not in ln)
+    assert frag(got_main) == frag(want_main) and single(got_main) == single(want_main)
+    assert len(frag(got_main)) > 100
+    for mine, theirs in (("1", "2"), ("2", "1")):
+        for kind, col in (("ambiguous", 3), ("unmapped", 0)):
+            want = [rename(ln, col) for ln in refio.golden_file("pe_mr_au", "out.mr_%s_%s" % (theirs, kind)).splitlines()]
+            assert got["out.mr_%s_%s" % (mine, kind)].splitlines() == want, (mine, kind)
+    assert got["out.mr.mapstats"] == _swap_mapstats_mates(refio.golden_file("pe_mr_au", "out.mr.mapstats"))
+
+    # single-end: -P is -A
+    ga = os.path.join(refio.GOLDEN, "se_ga.fastq")
+    a = _run_cli(os.path.join(scratch, "pbat_se_a"), ["-i", cli_index, "-o", "o.sam", "-A", "-r", ga, "-sam", "-a", "-u"])
+    b = _run_cli(os.path.join(scratch, "pbat_se_p"), ["-i", cli_index, "-o", "o.sam", "-P", "-r", ga, "-sam", "-a", "-u"])
+    assert a == b and len(a["o.sam"]) > 1000

@@ -44,7 +44,7 @@ static void check(int rc) { if (rc != WALT_OK) die(walt_last_error()); }
 // ---------------------------------------------------------------- options
 struct Options {
   string index_file, se_csv, pe1_csv, pe2_csv, out_csv, adaptor;
-  bool sam = false, ambiguous = false, unmapped = false, ag = false, verbose = false;
+  bool sam = false, ambiguous = false, unmapped = false, ag = false, verbose = false, pbat = false;
   uint32_t max_mismatches = 6, batch_size = 10000000, b = 5000, top_k = 50;
   int frag_range = 1000, threads = 0, device = 0;
 };
@@ -70,6 +70,7 @@ static Options parse(int argc, const char** argv) {
     else if (is_opt(a, "u", "unmapped")) o.unmapped = true;
     else if (is_opt(a, "C", "clip")) o.adaptor = val();
     else if (is_opt(a, "A", "ag-wild")) o.ag = true;
+    else if (is_opt(a, "P", "pbat")) o.pbat = true;  // README.md:64,100-104; no code in the reference snapshot
     else if (is_opt(a, "b", "bucket")) o.b = (uint32_t)strtoul(val().c_str(), 0, 10);
     else if (is_opt(a, "k", "topk")) o.top_k = (uint32_t)strtoul(val().c_str(), 0, 10);
     else if (is_opt(a, "L", "fraglen")) o.frag_range = atoi(val().c_str());
@@ -80,6 +81,7 @@ static Options parse(int argc, const char** argv) {
     else die("unknown option " + a);
   }
   if (o.index_file.empty() || o.out_csv.empty()) die("options -i and -o are required");
+  if (o.pbat && !o.se_csv.empty()) o.ag = true;  // single-end PBAT reads are A-rich: same as -A
   return o;
 }
 
@@ -385,7 +387,7 @@ static void sam_mate_line(Sink& f, View name, int flag, bool mapped, const strin
 // OutputPairedSAM, paired.cpp:333-435
 static void out_paired_sam(const walt_best_match& b1, const walt_best_match& b2, const GenomeInfo& g, View name,
                            View seq1, View scr1, View seq2, View scr2, int len, int flag_1, int flag_2, bool out_amb,
-                           bool out_unm, Sink& fout) {
+                           bool out_unm, bool second_first, Sink& fout) {
   uint32_t c1 = chrom_id(g, b1.genome_pos), c2 = chrom_id(g, b2.genome_pos);
   uint32_t s1, s2, e1, e2;
   forward_pos(b1.genome_pos, b1.strand, c1, seq1.len, g, s1, e1);
@@ -400,14 +402,19 @@ static void out_paired_sam(const walt_best_match& b1, const walt_best_match& b2,
     rn1 = b1.times == 0 ? "*" : g.name[c1];
     rn2 = b2.times == 0 ? "*" : g.name[c2];
   }
-  if (b1.times == 0 && out_unm)
-    sam_mate_line(fout, name, flag_1, false, g.name[c1], s1, seq1.len, rn2, s2, len1, seq1, scr1, b1.strand == '-', mm1);
-  else if (b1.times == 1 || (b1.times >= 2 && out_amb))
-    sam_mate_line(fout, name, flag_1, true, g.name[c1], s1, seq1.len, rn2, s2, len1, seq1, scr1, b1.strand == '-', mm1);
-  if (b2.times == 0 && out_unm)
-    sam_mate_line(fout, name, flag_2, false, g.name[c2], s2, seq2.len, rn1, s1, len2, seq2, scr2, b2.strand == '-', mm2);
-  else if (b2.times == 1 || (b2.times >= 2 && out_amb))
-    sam_mate_line(fout, name, flag_2, true, g.name[c2], s2, seq2.len, rn1, s1, len2, seq2, scr2, b2.strand == '-', mm2);
+  auto first = [&]() {
+    if (b1.times == 0 && out_unm)
+      sam_mate_line(fout, name, flag_1, false, g.name[c1], s1, seq1.len, rn2, s2, len1, seq1, scr1, b1.strand == '-', mm1);
+    else if (b1.times == 1 || (b1.times >= 2 && out_amb))
+      sam_mate_line(fout, name, flag_1, true, g.name[c1], s1, seq1.len, rn2, s2, len1, seq1, scr1, b1.strand == '-', mm1);
+  };
+  auto second = [&]() {
+    if (b2.times == 0 && out_unm)
+      sam_mate_line(fout, name, flag_2, false, g.name[c2], s2, seq2.len, rn1, s1, len2, seq2, scr2, b2.strand == '-', mm2);
+    else if (b2.times == 1 || (b2.times >= 2 && out_amb))
+      sam_mate_line(fout, name, flag_2, true, g.name[c2], s2, seq2.len, rn1, s1, len2, seq2, scr2, b2.strand == '-', mm2);
+  };
+  if (second_first) { second(); first(); } else { first(); second(); }
 }
 
 struct PeAcc {
@@ -416,8 +423,17 @@ struct PeAcc {
   vector<uint32_t> frag_count;
 };
 
-// ProcessPairedEndReads, paired.cpp:572-713
-static void process_pe(const Options& o, const string& f1, const string& f2, const string& out_file) {
+// ProcessPairedEndReads, paired.cpp:572-713.
+// -P (PBAT): the snapshot of the reference has no code for it ("parity unpinned"); it is DEFINED
+// here by equivalence to a run the reference can do: mate 1 is the A-rich read, so the pair is mapped with the
+// mate files exchanged (mate 2 against the C->T indexes, mate 1 against the G->A indexes), and the output is
+// then put back in the user's order: mate 1's record / line / _1 side files / mapstats block first, FLAG
+// 0x40 on mate 1 and 0x80 on mate 2, QNAME from the -1 file.
+static void process_pe(const Options& o, const string& file1, const string& file2, const string& out_file) {
+  const bool pbat = o.pbat;
+  const string& f1 = pbat ? file2 : file1;  // slot 0: the T-rich mate, mapped on _CT00/_CT01
+  const string& f2 = pbat ? file1 : file2;  // slot 1: the A-rich mate, mapped on _GA10/_GA11
+  const int name_slot = pbat ? 1 : 0;       // paired.cpp:694 prints the -1 file's name for both records
   const int T = host_threads(o);
   double t0 = now_s();
   walt_index* idx = nullptr;
@@ -437,7 +453,7 @@ static void process_pe(const Options& o, const string& f1, const string& f2, con
   SeCounts st1, st2;
   uint32_t total_pairs = 0, unique_pairs = 0, ambiguous_pairs = 0, unmapped_pairs = 0;
   vector<uint32_t> frag_count(o.frag_range + 1, 0);
-  fprintf(stderr, "[MAPPING PAIRED-END READS FROM THE FOLLOWING TWO FILES]\n   %s (AND)\n   %s\n", f1.c_str(), f2.c_str());
+  fprintf(stderr, "[MAPPING PAIRED-END READS FROM THE FOLLOWING TWO FILES]\n   %s (AND)\n   %s\n", file1.c_str(), file2.c_str());
   fprintf(stderr, "[OUTPUT MAPPING RESULTS TO %s]\n", out_file.c_str());
   if (o.sam) { string h = sam_head(g); fout.write(h.data(), h.size()); }
   Batch bt[2];
@@ -481,7 +497,7 @@ static void process_pe(const Options& o, const string& f1, const string& f2, con
       const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
       for (uint32_t j = lo; j < hi; ++j) {  // MergePairedEndResults tail, paired.cpp:515-569
         const walt_pair_result& p = pr[j];
-        const View name = bt[0].name(j), q1 = bt[0].seq(j), k1 = bt[0].score(j), q2 = bt[1].seq(j), k2 = bt[1].score(j);
+        const View name = bt[name_slot].name(j), q1 = bt[0].seq(j), k1 = bt[0].score(j), q2 = bt[1].seq(j), k2 = bt[1].score(j);
         walt_best_match bm1 = {0, 0, '+', {0, 0, 0}, o.max_mismatches}, bm2 = bm1;
         bool is_paired = false;
         int len = 0;
@@ -497,15 +513,18 @@ static void process_pe(const Options& o, const string& f1, const string& f2, con
           bm1 = p.m1; bm2 = p.m2;
           a.st1.update(bm1.times);
           a.st2.update(bm2.times);
-          if (!o.sam) {
+          if (!o.sam && !pbat) {
             out_single_results(bm1, name, q1, k1, g, false, side1.out_amb, side1.out_unm, s[kMain], s[kAmb1], s[kUnm1]);
             out_single_results(bm2, name, q2, k2, g, true, side2.out_amb, side2.out_unm, s[kMain], s[kAmb2], s[kUnm2]);
+          } else if (!o.sam) {  // the user's mate 1 sits in slot 1
+            out_single_results(bm2, name, q2, k2, g, true, side1.out_amb, side1.out_unm, s[kMain], s[kAmb1], s[kUnm1]);
+            out_single_results(bm1, name, q1, k1, g, false, side2.out_amb, side2.out_unm, s[kMain], s[kAmb2], s[kUnm2]);
           }
         }
         if (o.sam) {
-          int fl1 = sam_flag(is_paired, bm1.times == 0, bm2.times == 0, bm1.strand == '-', bm2.strand == '-', true, bm1.times >= 2);
-          int fl2 = sam_flag(is_paired, bm2.times == 0, bm1.times == 0, bm2.strand == '-', bm1.strand == '-', false, bm2.times >= 2);
-          out_paired_sam(bm1, bm2, g, name, q1, k1, q2, k2, len, fl1, fl2, o.ambiguous, o.unmapped, s[kMain]);
+          int fl1 = sam_flag(is_paired, bm1.times == 0, bm2.times == 0, bm1.strand == '-', bm2.strand == '-', !pbat, bm1.times >= 2);
+          int fl2 = sam_flag(is_paired, bm2.times == 0, bm1.times == 0, bm2.strand == '-', bm1.strand == '-', pbat, bm2.times >= 2);
+          out_paired_sam(bm1, bm2, g, name, q1, k1, q2, k2, len, fl1, fl2, o.ambiguous, o.unmapped, pbat, s[kMain]);
         }
       }
       acc[t] = std::move(a);
@@ -537,8 +556,8 @@ static void process_pe(const Options& o, const string& f1, const string& f2, con
       << "        percent_unique: " << (100.0 * unique_pairs) / total_pairs << std::endl
       << "        ambiguous: " << ambiguous_pairs << std::endl
       << "    unmapped: " << unmapped_pairs << std::endl
-      << "mate1:" << std::endl << st1.tostring(1) << std::endl
-      << "mate2:" << std::endl << st2.tostring(1) << std::endl;
+      << "mate1:" << std::endl << (pbat ? st2 : st1).tostring(1) << std::endl
+      << "mate2:" << std::endl << (pbat ? st1 : st2).tostring(1) << std::endl;
   oss << "frag_len_distribution:" << std::endl;
   double total = 0.0;
   for (size_t i = 0; i < frag_count.size(); ++i) {
@@ -556,7 +575,7 @@ static void process_pe(const Options& o, const string& f1, const string& f2, con
 int main(int argc, const char** argv) {
   try {
     if (argc == 1) {
-      fprintf(stderr, "Usage: walt -i <index> -r <reads> | -1 <reads1> -2 <reads2> -o <out> [-m -N -a -u -C -A -b -k -L -sam -v -t -g]\n");
+      fprintf(stderr, "Usage: walt -i <index> -r <reads> | -1 <reads1> -2 <reads2> -o <out> [-m -N -a -u -C -A -P -b -k -L -sam -v -t -g]\n");
       return EXIT_SUCCESS;
     }
     Options o = parse(argc, argv);
