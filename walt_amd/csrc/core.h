@@ -656,6 +656,26 @@ WALT_HD int pair_len(const Candidate& r1, const Candidate& r2, uint32_t len1, ui
   uint32_t two_r = plus ? e2 : (ov_s < e2 ? ov_s : e2);
   return plus ? (int)(two_r - one_l) : (int)(one_r - two_l);
 }
+// Tail of MergePairedEndResults (paired.cpp:515-545): a unique best pair is reported as such, otherwise each
+// mate falls back to its own best candidate (GetBestMatch4Single).
+WALT_HD void pair_finish(const Candidate* r1, int n1, const Candidate* r2, int n2, uint32_t len1, uint32_t len2,
+                         const uint32_t* start_index, uint32_t n_chrom, uint32_t max_mm, int bi, int bj,
+                         uint32_t best_times, PairResult& out) {
+  BestMatch init; init.genome_pos = 0; init.times = 0; init.strand = '+'; init.mismatch = max_mm;
+  out.m1 = init; out.m2 = init;
+  out.best_times = best_times; out.frag_len = 0; out.best_i = -1; out.best_j = -1; out.pair_mm = 0;
+  out.pad_[0] = out.pad_[1] = out.pad_[2] = 0;
+  if (best_times == 1) {
+    out.best_i = bi; out.best_j = bj;
+    out.frag_len = pair_len(r1[bi], r2[bj], len1, len2, start_index, n_chrom);
+    out.pair_mm = r1[bi].mismatch + r2[bj].mismatch;
+    out.m1.genome_pos = r1[bi].genome_pos; out.m1.times = 1; out.m1.strand = r1[bi].strand; out.m1.mismatch = r1[bi].mismatch;
+    out.m2.genome_pos = r2[bj].genome_pos; out.m2.times = 1; out.m2.strand = r2[bj].strand; out.m2.mismatch = r2[bj].mismatch;
+  } else {
+    best4single(r1, n1, out.m1);
+    best4single(r2, n2, out.m2);
+  }
+}
 WALT_HD void pair_merge(const Candidate* r1, int n1, const Candidate* r2, int n2, uint32_t len1, uint32_t len2,
                         const uint32_t* start_index, uint32_t n_chrom, int frag_range, uint32_t max_mm,
                         PairResult& out) {
@@ -685,20 +705,7 @@ WALT_HD void pair_merge(const Candidate* r1, int n1, const Candidate* r2, int n2
       }
     }
   }
-  BestMatch init; init.genome_pos = 0; init.times = 0; init.strand = '+'; init.mismatch = max_mm;
-  out.m1 = init; out.m2 = init;
-  out.best_times = best_times; out.frag_len = 0; out.best_i = -1; out.best_j = -1; out.pair_mm = 0;
-  out.pad_[0] = out.pad_[1] = out.pad_[2] = 0;
-  if (best_times == 1) {
-    out.best_i = bi; out.best_j = bj;
-    out.frag_len = pair_len(r1[bi], r2[bj], len1, len2, start_index, n_chrom);
-    out.pair_mm = r1[bi].mismatch + r2[bj].mismatch;
-    out.m1.genome_pos = r1[bi].genome_pos; out.m1.times = 1; out.m1.strand = r1[bi].strand; out.m1.mismatch = r1[bi].mismatch;
-    out.m2.genome_pos = r2[bj].genome_pos; out.m2.times = 1; out.m2.strand = r2[bj].strand; out.m2.mismatch = r2[bj].mismatch;
-  } else {
-    best4single(r1, n1, out.m1);
-    best4single(r2, n2, out.m2);
-  }
+  pair_finish(r1, n1, r2, n2, len1, len2, start_index, n_chrom, max_mm, bi, bj, best_times, out);
 }
 
 }  // namespace walt

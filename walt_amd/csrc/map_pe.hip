@@ -230,28 +230,134 @@ __global__ void k_pe_drain(HeapEnt* __restrict__ heaps, const uint32_t* __restri
   }
 }
 
+// Pairs whose candidate lists span more than kLightCombos (i, j) combinations are
+// left to k_pe_merge_heavy: one such lane would otherwise hold its whole wave for
+// thousands of iterations (repeat families fill both lists to top_k).
+constexpr uint32_t kLightCombos = 64;
+
 __global__ void k_pe_merge(IndexView iv, const Candidate* __restrict__ ranked1, const uint32_t* __restrict__ n1,
                            const Candidate* __restrict__ ranked2, const uint32_t* __restrict__ n2,
                            const uint64_t* __restrict__ off1, const uint64_t* __restrict__ off2, uint32_t n,
-                           uint32_t top_k, int frag_range, uint32_t max_mm, PairResult* __restrict__ out) {
+                           uint32_t top_k, int frag_range, uint32_t max_mm, PairResult* __restrict__ out,
+                           uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list) {
   // chromosome starts in LDS when they fit: getChromID is a chain of dependent loads per candidate pair
   __shared__ uint32_t s_start[kLdsChroms + 1];
   const bool fits = iv.n_chrom <= kLdsChroms;
   if (fits)
     for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
   __syncthreads();
-  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  PairResult pr;
-  if (fits)
-    pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r],
-               (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), s_start, iv.n_chrom, frag_range,
+  const uint32_t* starts = fits ? s_start : iv.start_index;
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = r < n;
+  const uint32_t a = valid ? n1[r] : 0, b = valid ? n2[r] : 0;
+  const bool heavy = a * b > kLightCombos;
+  if (valid && !heavy) {
+    PairResult pr;
+    pair_merge(ranked1 + (uint64_t)r * top_k, (int)a, ranked2 + (uint64_t)r * top_k, (int)b,
+               (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), starts, iv.n_chrom, frag_range,
                max_mm, pr);
-  else
-    pair_merge(ranked1 + (uint64_t)r * top_k, (int)n1[r], ranked2 + (uint64_t)r * top_k, (int)n2[r],
-               (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), iv.start_index, iv.n_chrom,
-               frag_range, max_mm, pr);
-  out[r] = pr;
+    out[r] = pr;
+  }
+  const unsigned long long hv = __ballot(heavy);
+  if (hv) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)hv) - 1)) base = atomicAdd(heavy_count, (uint32_t)__popcll(hv));
+    base = bcast(base, __ffsll((long long)hv) - 1);
+    if (heavy) heavy_list[base + (uint32_t)__popcll(hv & ((1ull << lane) - 1ull))] = r;
+  }
+}
+
+// One wavefront per heavy pair: 64 (i, j) combinations per step, in the reference's order
+// (i descending, j descending inside, paired.cpp:478-513).  The sequential fold
+//   mm < min  -> new best, times = 1;   mm == min && key != best_key -> last-wins, times++
+// over one step equals: m* = smallest mm among the step's valid combinations; if m* < min the
+// FIRST lane holding m* restarts the fold and the later lanes with mm == m* and a different
+// key count; if m* == min the lanes with mm == min and a key different from best_key count.
+// The reference's ordered `break` (486-487) only skips combinations with mm > min, which never
+// change the fold, so evaluating them (and rejecting on mm > min) is equivalent.
+__global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const Candidate* __restrict__ ranked1,
+                                                            const uint32_t* __restrict__ n1,
+                                                            const Candidate* __restrict__ ranked2,
+                                                            const uint32_t* __restrict__ n2,
+                                                            const uint64_t* __restrict__ off1,
+                                                            const uint64_t* __restrict__ off2, uint32_t top_k,
+                                                            int frag_range, uint32_t max_mm,
+                                                            PairResult* __restrict__ out,
+                                                            const uint32_t* __restrict__ heavy_count,
+                                                            const uint32_t* __restrict__ heavy_list) {
+  __shared__ uint32_t s_start[kLdsChroms + 1];
+  const bool fits = iv.n_chrom <= kLdsChroms;
+  if (fits)
+    for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  __syncthreads();
+  const uint32_t* starts = fits ? s_start : iv.start_index;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t count = *heavy_count;
+  for (uint32_t h = blockIdx.x * waves_per_block + (threadIdx.x >> 6); h < count; h += gridDim.x * waves_per_block) {
+    const uint32_t r = heavy_list[h];
+    const Candidate* r1 = ranked1 + (uint64_t)r * top_k;
+    const Candidate* r2 = ranked2 + (uint64_t)r * top_k;
+    const uint32_t na = n1[r], nb = n2[r];
+    const uint32_t len1 = (uint32_t)(off1[r + 1] - off1[r]), len2 = (uint32_t)(off2[r + 1] - off2[r]);
+    const uint32_t total = na * nb;
+    uint32_t min_mm = max_mm, best_times = 0;
+    uint32_t best_hi = 0, best_lo = 0;  // best_pos = (pos1 << 32) + pos2
+    int bi = -1, bj = -1;
+    for (uint32_t base = 0; base < total; base += 64) {
+      const uint32_t c = base + lane;
+      bool ok = false;
+      uint32_t mm = 0xFFFFFFFFu, p1 = 0, p2 = 0;
+      int i = 0, j = 0;
+      if (c < total) {
+        i = (int)(na - 1 - c / nb);
+        j = (int)(nb - 1 - c % nb);
+        const Candidate A = r1[i], B = r2[j];
+        p1 = A.genome_pos; p2 = B.genome_pos;
+        if (A.strand != B.strand) {
+          mm = A.mismatch + B.mismatch;
+          if (mm <= min_mm) {
+            const uint32_t c1 = chrom_id(starts, iv.n_chrom, p1), c2 = chrom_id(starts, iv.n_chrom, p2);
+            if (c1 == c2) {
+              uint32_t s1, e1, s2, e2;
+              forward_pos(p1, A.strand, c1, len1, starts, s1, e1);
+              forward_pos(p2, B.strand, c2, len2, starts, s2, e2);
+              const int frag = A.strand == '+' ? (int)(e2 - s1) : (int)(e1 - s2);
+              ok = frag > 0 && frag <= frag_range;
+            }
+          }
+        }
+      }
+      const uint32_t m_star = wave_min_u32(ok ? mm : 0xFFFFFFFFu);
+      if (m_star == 0xFFFFFFFFu || m_star > min_mm) continue;
+      unsigned long long cnt_mask;
+      if (m_star < min_mm) {
+        const unsigned long long at_min = __ballot(ok && mm == m_star);
+        const int f = __ffsll((long long)at_min) - 1;
+        min_mm = m_star;
+        best_hi = bcast(p1, f);
+        best_lo = bcast(p2, f);
+        bi = (int)bcast((uint32_t)i, f);
+        bj = (int)bcast((uint32_t)j, f);
+        cnt_mask = __ballot(ok && mm == m_star && (int)lane > f && (p1 != best_hi || p2 != best_lo));
+        best_times = 1 + (uint32_t)__popcll(cnt_mask);
+      } else {
+        cnt_mask = __ballot(ok && mm == min_mm && (p1 != best_hi || p2 != best_lo));
+        best_times += (uint32_t)__popcll(cnt_mask);
+      }
+      if (cnt_mask) {
+        const int last = 63 - __clzll((long long)cnt_mask);
+        bi = (int)bcast((uint32_t)i, last);
+        bj = (int)bcast((uint32_t)j, last);
+      }
+    }
+    if (lane == 0) {
+      PairResult pr;
+      pair_finish(r1, (int)na, r2, (int)nb, len1, len2, starts, iv.n_chrom, max_mm, bi, bj, best_times, pr);
+      out[r] = pr;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -281,7 +387,8 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
     return q;
   };
   w.stride = align_up(chunk ? chunk : 1, 64);
-  w.err = reinterpret_cast<uint32_t*>(take(128 * sizeof(uint32_t)));  // [0..1] pack errors, [64 + 32 m ...] deferral control of mate m
+  // [0..1] pack errors, [64 + 32 m ...] deferral control of mate m, [128] heavy-pair count of the merge
+  w.err = reinterpret_cast<uint32_t*>(take(192 * sizeof(uint32_t)));
   for (int m = 0; m < 2; ++m) w.shards[m] = reinterpret_cast<unsigned long long*>(take(kStatShardBytes));
   for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
   for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
@@ -318,7 +425,7 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   const uint8_t* bases[2] = {d_bases1, d_bases2};
   const uint64_t* offs[2] = {d_off1, d_off2};
   // err words: [0..1] pack errors (kept across chunks), [64 + 32 m ..] deferral control block of mate m (per chunk)
-  WALT_HIP(hipMemsetAsync(w.err + 64, 0, 64 * sizeof(uint32_t), stream));
+  WALT_HIP(hipMemsetAsync(w.err + 64, 0, 128 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) {
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
     unsigned long long* st = w.shards[m];
@@ -338,8 +445,15 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     hipLaunchKernelGGL(k_pe_drain, dim3(grid_for(n)), dim3(kBlock), 0, stream, w.heaps[m], w.heap_n[m], n, top_k,
                        w.ranked[m]);
   }
+  // both mates are mapped: mate 1's deferral list area is free and holds the heavy-pair list of the merge
+  uint32_t* heavy_count = w.err + 128;
+  uint32_t* heavy_list = w.defer_list[0];
   hipLaunchKernelGGL(k_pe_merge, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, w.ranked[0], w.heap_n[0],
-                     w.ranked[1], w.heap_n[1], d_off1, d_off2, n, top_k, frag_range, max_mm, d_out);
+                     w.ranked[1], w.heap_n[1], d_off1, d_off2, n, top_k, frag_range, max_mm, d_out, heavy_count,
+                     heavy_list);
+  hipLaunchKernelGGL(k_pe_merge_heavy, dim3(grid_for(n) < 2048u ? grid_for(n) : 2048u), dim3(kBlock), 0, stream,
+                     idx->view, w.ranked[0], w.heap_n[0], w.ranked[1], w.heap_n[1], d_off1, d_off2, top_k, frag_range,
+                     max_mm, d_out, heavy_count, heavy_list);
   WALT_HIP(hipGetLastError());
   return WALT_OK;
 }
