@@ -182,6 +182,9 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last chunk (map_pe.hip carve_pe)
+    log("last chunk: literal-list %d / %d, complex-list %d / %d (mate 1 / mate 2), heavy pairs %d" % (
+        int(ctl[64]), int(ctl[96]), int(ctl[88]), int(ctl[120]), int(ctl[128])))
     res = d_out.view(torch.int32).view(n, 16)
     bt = res[:, 8]
     out = {"metric": "mapped read pairs/sec (2 x %d bp paired-end, hg19-scale index, -m %d -k %d -L %d)" % (

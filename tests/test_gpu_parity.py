@@ -74,7 +74,11 @@ def test_gpu_se_records_equal_oracle_exact_times(wa, g1_db, g1_dev):
                 assert int(stats["candidates"]) >= 0
 
 
-def test_gpu_pe_ranked_lists_and_pairs_equal_oracle(wa, g1_db, g1_dev):
+@pytest.mark.parametrize("pe_chunk", [None, "333"])
+def test_gpu_pe_ranked_lists_and_pairs_equal_oracle(wa, g1_db, g1_dev, pe_chunk, monkeypatch):
+    """pe_chunk forces the batch through several workspace passes (two-stream fork/join per pass)."""
+    if pe_chunk:
+        monkeypatch.setenv("WALT_AMD_PE_CHUNK", pe_chunk)
     _, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 10 ** 7))
     _, s2, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_2.fastq"), 10 ** 7))
     b1, o1 = wa.pack_reads(s1)

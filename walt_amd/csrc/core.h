@@ -554,7 +554,9 @@ struct HeapEnt {
 };
 WALT_HD uint32_t heap_mm(const HeapEnt& e) { return e.mms & 0x7FFFFFFFu; }
 
-WALT_HD void heap_sift_up(HeapEnt* h, uint32_t hole, uint32_t top, HeapEnt v) {  // __push_heap
+// H is anything indexable like HeapEnt* (an HBM array, or a strided view of LDS in the paired-end kernel)
+template <class H>
+WALT_HD void heap_sift_up(H h, uint32_t hole, uint32_t top, HeapEnt v) {  // __push_heap
   while (hole > top) {
     uint32_t parent = (hole - 1) / 2;
     if (!(heap_mm(h[parent]) < heap_mm(v))) break;
@@ -563,11 +565,13 @@ WALT_HD void heap_sift_up(HeapEnt* h, uint32_t hole, uint32_t top, HeapEnt v) { 
   }
   h[hole] = v;
 }
-WALT_HD void heap_push(HeapEnt* h, uint32_t& size, HeapEnt v) {  // push_back + push_heap
+template <class H>
+WALT_HD void heap_push(H h, uint32_t& size, HeapEnt v) {  // push_back + push_heap
   heap_sift_up(h, size, 0, v);
   ++size;
 }
-WALT_HD void heap_adjust(HeapEnt* h, uint32_t hole, uint32_t len, HeapEnt v) {  // __adjust_heap
+template <class H>
+WALT_HD void heap_adjust(H h, uint32_t hole, uint32_t len, HeapEnt v) {  // __adjust_heap
   const uint32_t top = hole;
   uint32_t child = hole;
   while ((int32_t)child < ((int32_t)len - 1) / 2) {
@@ -584,7 +588,8 @@ WALT_HD void heap_adjust(HeapEnt* h, uint32_t hole, uint32_t len, HeapEnt v) {  
   heap_sift_up(h, hole, top, v);
 }
 // pop_heap + pop_back; returns the removed top
-WALT_HD HeapEnt heap_pop(HeapEnt* h, uint32_t& size) {
+template <class H>
+WALT_HD HeapEnt heap_pop(H h, uint32_t& size) {
   HeapEnt topv = h[0];
   if (size > 1) {
     HeapEnt v = h[size - 1];
@@ -595,7 +600,8 @@ WALT_HD HeapEnt heap_pop(HeapEnt* h, uint32_t& size) {
   return topv;
 }
 // TopCandidates::Push, paired.hpp:63-70
-WALT_HD void topk_push(HeapEnt* h, uint32_t& size, uint32_t k, HeapEnt v) {
+template <class H>
+WALT_HD void topk_push(H h, uint32_t& size, uint32_t k, HeapEnt v) {
   if (size < k) {
     heap_push(h, size, v);
   } else if (heap_mm(v) < heap_mm(h[0])) {

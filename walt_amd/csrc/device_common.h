@@ -34,6 +34,9 @@ struct walt_index {
   bool profile = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before pack, before map, after map
   bool ev_valid = false;
+  // paired-end: mate 2's kernels run on this second stream beside mate 1's (created on first use)
+  hipStream_t pe_stream = nullptr;
+  hipEvent_t pe_fork = nullptr, pe_join = nullptr;
 };
 
 namespace walt {

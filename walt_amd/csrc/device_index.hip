@@ -620,6 +620,9 @@ void walt_index_close(walt_index* idx) {
   for (void* p : idx->allocs) hipFree(p);
   for (int i = 0; i < 3; ++i)
     if (idx->ev[i]) hipEventDestroy(idx->ev[i]);
+  if (idx->pe_fork) hipEventDestroy(idx->pe_fork);
+  if (idx->pe_join) hipEventDestroy(idx->pe_join);
+  if (idx->pe_stream) hipStreamDestroy(idx->pe_stream);
   delete idx;
 }
 

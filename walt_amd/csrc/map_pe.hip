@@ -7,22 +7,50 @@
 // fallback of MergePairedEndResults (paired.cpp:474-545), which the reference
 // runs serially on the host.
 //
-// Kernels:
-//   k_pe_topk   one read per lane (lookup as in map_se.hip); candidates with
-//               mismatch <= max_mm are pushed IN CANDIDATE ORDER into the
-//               read's heap in HBM; large regions are verified by the whole
-//               wave and pushed by the owner lane in lane order.
-//   k_pe_drain  pops every heap (-> ascending array in place, std::pop_heap
-//               leaves the popped top at the end) and writes the ranked list in
-//               pop order.
-//   k_pe_merge  one pair per lane, pair_merge() of core.h.
+// Kernels (per mate):
+//   k_pe_topk_dual  pass 1, every read, one per lane, seed-major like map_se.hip's pass 1:
+//               the '+' and '-' probes of a seed shift are issued together.  It completes
+//               the reads whose heap can never fill (every region <= 4 slots, at most
+//               kFastCands candidates, fewer than top_k): with a heap that is never full
+//               the reference takes no early exit (paired.cpp:133-141), so all six probes
+//               are needed and only the PUSH ORDER (+s0 +s1 +s2 -s0 -s1 -s2) has to be
+//               reproduced.  '+' candidates are pushed on arrival, '-' candidates wait in
+//               registers; the heap lives in LDS and is popped there, so these reads write
+//               their ranked list directly.
+//               Other reads go to one of two lists.
+//   k_pe_topk_list<.., false>  "complex" reads (a large region, many candidates, small
+//               top_k): strand-major sequential probing with the exact early exits,
+//               candidates pushed IN CANDIDATE ORDER into the read's heap (LDS, top_k slots);
+//               large regions are verified by the whole wave and pushed by the owner lane.
+//               A short list is spread down to one read per wavefront.
+//   k_pe_topk_list<.., true>   reads whose probe met the Bloom filter of chromosome-end
+//               entries: the same, with the literal search of the reference.
+//               Every kernel pops its heaps itself (paired.cpp:685-692) and writes the ranked
+//               lists in pop order; no heap ever lives in HBM.
+//   k_pe_merge / k_pe_merge_heavy  pair search, one pair per lane / per wavefront.
+#include <stdlib.h>
 #include <string.h>
 
 #include "map_common.h"
 
 namespace walt {
 
-constexpr uint32_t kPeChunk = 1u << 21;  // pairs processed per workspace pass
+// Pairs processed per workspace pass.  The list kernels are latency-bound (a handful of slow reads, one per
+// wavefront), so their cost per pass is nearly constant: large passes amortise it.  The ranked lists
+// (2 x top_k x 12 B per pair) bound the pass by a ~10 GB workspace budget.
+constexpr uint32_t kPeChunkMax = 1u << 23;
+static inline uint32_t pe_chunk_pairs(uint32_t n, uint32_t top_k) {
+  const uint64_t budget = 10ull << 30;
+  uint64_t c = budget / ((uint64_t)(top_k ? top_k : 1) * 2 * sizeof(Candidate));
+  if (c > kPeChunkMax) c = kPeChunkMax;
+  if (c < (1u << 16)) c = 1u << 16;
+  if (const char* e = getenv("WALT_AMD_PE_CHUNK")) {  // test hook: force several passes on a small batch
+    const long v = atol(e);
+    if (v > 0) c = (uint64_t)v;
+  }
+  return n < c ? n : (uint32_t)c;
+}
+constexpr uint32_t kCoopUnroll = 4;    // 64-candidate groups of a large region verified per step
 
 // One read per lane.  LITERAL as in map_se.hip: pass 1 defers reads that hit a
 // BAD bucket, pass 2 maps them from scratch (their heap restarts empty).
@@ -31,7 +59,8 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
                                            const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets,
                                            uint32_t* __restrict__ err, uint32_t r,
                                            bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
-                                           uint32_t top_k, HeapEnt* __restrict__ heaps,
+                                           uint32_t top_k, HeapEnt* heap /* this lane's top_k slots (LDS) */,
+                                           Candidate* __restrict__ ranked,
                                            uint32_t* __restrict__ heap_n, uint32_t* __restrict__ defer_count,
                                            uint32_t* __restrict__ defer_list, uint32_t& n_probe,
                                            uint32_t& n_verified, uint32_t& n_big, uint32_t& len_out) {
@@ -48,7 +77,6 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
   uint32_t defer_iter = 0;
-  HeapEnt* heap = heaps + (uint64_t)(valid ? r : 0) * top_k;
   uint32_t hsize = 0;
 
   for (uint32_t fi = 0; fi < 2; ++fi) {
@@ -109,32 +137,49 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
           o_mk[w] = bcast(mk[w], owner);
         }
         const uint32_t o_l = bcast(reg.l, owner), o_size = bcast(size, owner), o_len = bcast(lr.len, owner);
-        for (uint32_t base = 0; base < o_size; base += 64) {
-          uint32_t k = base + lane;
-          uint32_t mm = 0xFFFFFFFFu, gp = 0;
-          if (k < o_size) {
-            uint32_t pos = sv.ent[o_l + k].pos, m;
-            if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, o_len, o_rd, o_mk, gp, m)) {
-              mm = m;
-              ++n_verified;
-            }
+        // kCoopUnroll x 64 candidates per step: the slot loads of a step are independent, then the genome
+        // windows are, so a step costs two memory round trips instead of 2 x kCoopUnroll (a listed read
+        // owns its wave, nothing else hides the latency); pushes stay in slot order.
+        for (uint32_t base = 0; base < o_size; base += 64 * kCoopUnroll) {
+          uint32_t cpos[kCoopUnroll], cgp[kCoopUnroll], cmm[kCoopUnroll];
+#pragma unroll
+          for (uint32_t u = 0; u < kCoopUnroll; ++u) {
+            const uint32_t k = base + u * 64 + lane;
+            cpos[u] = sv.ent[o_l + (k < o_size ? k : o_size - 1)].pos;
           }
-          // candidates that can still enter the owner's heap, judged against the
-          // heap state at the start of this chunk (top only decreases, so this
-          // never drops a candidate TopCandidates::Push would have accepted)
-          const uint32_t o_hsize = bcast(hsize, owner);
-          uint32_t o_top = 0xFFFFFFFFu;
-          if ((int)lane == owner && hsize) o_top = heap_mm(heap[0]);
-          o_top = bcast(o_top, owner);
-          const bool o_full = o_hsize >= top_k;
-          unsigned long long push = __ballot(mm <= max_mm && (!o_full || mm < o_top));
-          while (push) {
-            const int src = (int)__ffsll((long long)push) - 1;
-            push &= push - 1;
-            const uint32_t c_gp = bcast(gp, src), c_mm = bcast(mm, src);
-            if ((int)lane == owner) {
-              HeapEnt e; e.pos = c_gp; e.mms = c_mm | (fi << 31);
-              topk_push(heap, hsize, top_k, e);
+#pragma unroll
+          for (uint32_t u = 0; u < kCoopUnroll; ++u) {
+            const uint32_t k = base + u * 64 + lane;
+            const uint32_t chr = chrom_id(si, n_chrom, cpos[u]);
+            const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+            const uint32_t g = cpos[u] - seed_i;
+            const bool ok = k < o_size && (cpos[u] - c_lo >= seed_i) && (g + o_len < c_hi);  // paired.cpp:166-171
+            cgp[u] = ok ? g : 0u;
+            const uint32_t m = count_mismatch<NW>(sv.g2, cgp[u], o_rd, o_mk);
+            cmm[u] = ok ? m : 0xFFFFFFFFu;
+            n_verified += ok ? 1u : 0u;
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < kCoopUnroll; ++u) {
+            if (base + u * 64 >= o_size) break;
+            const uint32_t mm = cmm[u], gp = cgp[u];
+            // candidates that can still enter the owner's heap, judged against the
+            // heap state at the start of this chunk (top only decreases, so this
+            // never drops a candidate TopCandidates::Push would have accepted)
+            const uint32_t o_hsize = bcast(hsize, owner);
+            uint32_t o_top = 0xFFFFFFFFu;
+            if ((int)lane == owner && hsize) o_top = heap_mm(heap[0]);
+            o_top = bcast(o_top, owner);
+            const bool o_full = o_hsize >= top_k;
+            unsigned long long push = __ballot(mm <= max_mm && (!o_full || mm < o_top));
+            while (push) {
+              const int src = (int)__ffsll((long long)push) - 1;
+              push &= push - 1;
+              const uint32_t c_gp = bcast(gp, src), c_mm = bcast(mm, src);
+              if ((int)lane == owner) {
+                HeapEnt e; e.pos = c_gp; e.mms = c_mm | (fi << 31);
+                topk_push(heap, hsize, top_k, e);
+              }
             }
           }
         }
@@ -145,7 +190,15 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
   if (!LITERAL && deferred) {
     defer_list[atomicAdd(defer_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
   } else if (valid) {
+    // paired.cpp:685-692: pop everything; ranked[r][i] = i-th popped (descending mismatch)
     heap_n[r] = hsize;
+    Candidate* out = ranked + (uint64_t)r * top_k;
+    uint32_t i = 0;
+    while (hsize) {
+      const HeapEnt e = heap_pop(heap, hsize);
+      Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
+      out[i++] = c;
+    }
   }
 }
 
@@ -154,22 +207,152 @@ __device__ __forceinline__ void pe_flush(uint32_t shortv, uint32_t n_probe, uint
   block_flush_stats(shortv, n_probe, n_verified, n_big, shards);
 }
 
+// ---------------------------------------------------------------------------
+// pass 1 (see the header comment)
+// ---------------------------------------------------------------------------
+constexpr uint32_t kFastCands = 6;          // LDS heap slots per lane: 6 x 8 B x 256 lanes = 12 KB per block
+
+struct LdsHeap {  // entry i of this lane's heap; entries of one index are contiguous across lanes (no bank conflicts)
+  HeapEnt* base;
+  __device__ __forceinline__ HeapEnt& operator[](uint32_t i) const { return base[i * kBlock]; }
+};
+
 template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t* __restrict__ codes2,
-                                                     const uint64_t* __restrict__ offsets,
-                                                     uint32_t* __restrict__ err, uint32_t n,
-                                                     uint32_t strand_base,
-                                                     uint32_t max_mm, uint32_t b, uint32_t top_k,
-                                                     const uint32_t* __restrict__ mask_table,
-                                                     HeapEnt* __restrict__ heaps, uint32_t* __restrict__ heap_n,
-                                                     unsigned long long* __restrict__ stats,
-                                                     uint32_t* __restrict__ defer_count,
-                                                     uint32_t* __restrict__ defer_list) {
+__device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si, LdsHeap fast,
+                                                const uint32_t* __restrict__ codes2,
+                                                const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
+                                                uint32_t r, bool valid, uint32_t strand_base, uint32_t max_mm,
+                                                uint32_t b, uint32_t top_k, Candidate* __restrict__ ranked,
+                                                uint32_t* __restrict__ heap_n, uint32_t* __restrict__ bloom_count,
+                                                uint32_t* __restrict__ bloom_list, uint32_t* __restrict__ cplx_count,
+                                                uint32_t* __restrict__ cplx_list, uint32_t& n_probe,
+                                                uint32_t& n_verified, uint32_t& len_out) {
+  const uint32_t n_chrom = iv.n_chrom;
+  const uint32_t top_step = top_step_of(n_chrom);
+  const StrandView& svp = iv.s[strand_base];
+  const StrandView& svm = iv.s[strand_base + 1];
+  const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
+  LaneRead<NW> lr;
+  {
+    uint64_t o = 0, oe = 0;
+    if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
+    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err);
+  }
+  len_out = lr.len;
+  bool mappable = valid && lr.len >= kMinReadLen;
+  bool deferred = false, cplx = false;
+  uint32_t defer_iter = 0;
+  uint32_t hsize = 0;                                             // '+' candidates, pushed on arrival
+  uint32_t mp0 = 0, mp1 = 0, mp2 = 0, mm0 = 0, mm1 = 0, mm2 = 0;  // '-' candidates, pushed after seed 2
+  uint32_t n_minus = 0;
+
+#pragma unroll 1
+  for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+    bool need = mappable;
+    uint32_t care[kCareWords] = {0, 0, 0, 0};
+    uint32_t slot = 0, span = 0;
+    if (need) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
+    const bool bad_p = need && bloom_maybe(sh.bloom[0], bloom_key_of_care(care));
+    const bool bad_m = need && bloom_maybe(sh.bloom[1], bloom_key_of_care(care));
+    if (bad_p || bad_m) {
+      deferred = true;
+      mappable = false;
+      need = false;
+      defer_iter = seed_i + (bad_p ? 0u : 3u);
+    }
+    SlotProbe pp, pm;
+    uint32_t hi_p, hi_m;
+    probe_issue(svp, need, slot, span, pp.lo, hi_p);
+    probe_issue(svm, need, slot, span, pm.lo, hi_m);
+    pp.ne = (need && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
+    pm.ne = (need && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
+    probe_entries(svp, pp);
+    probe_entries(svm, pm);
+    Lookup lp, lm;
+    probe_resolve(svp, pp, care, lr.repeats, lp);
+    probe_resolve(svm, pm, care, lr.repeats, lm);
+    uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
+    uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
+    n_probe += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
+    if (size_p > b) size_p = 0;  // paired.cpp:161-163
+    if (size_m > b) size_m = 0;
+    if (size_p > kSmallRegion || size_m > kSmallRegion) {  // a large region: the sequential kernel's business
+      cplx = true;
+      mappable = false;
+      size_p = size_m = 0;
+    }
+    uint32_t mk[NW];
+    make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
+    const uint32_t kmax = size_p > size_m ? size_p : size_m;
+#pragma unroll 1
+    for (uint32_t k = 0; k < kmax; ++k) {
+      const bool act_p = k < size_p, act_m = k < size_m;
+      uint32_t pos_p = k == 0 ? lp.pos[0] : k == 1 ? lp.pos[1] : k == 2 ? lp.pos[2] : lp.pos[3];
+      uint32_t pos_m = k == 0 ? lm.pos[0] : k == 1 ? lm.pos[1] : k == 2 ? lm.pos[2] : lm.pos[3];
+      if (act_p && k >= lp.npos) pos_p = svp.ent[lp.reg.l + k].pos;
+      if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
+      bool ok_p, ok_m;
+      uint32_t gp_p, gp_m, mm_p, mm_m;
+      verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+      verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+      if (ok_p) {
+        ++n_verified;
+        if (mm_p <= max_mm) {  // paired.cpp:192-195
+          if (hsize < kFastCands) {
+            HeapEnt e; e.pos = gp_p; e.mms = mm_p;
+            heap_push(fast, hsize, e);
+          } else {
+            cplx = true;
+          }
+        }
+      }
+      if (ok_m) {
+        ++n_verified;
+        if (mm_m <= max_mm) {
+          if (n_minus == 0) { mp0 = gp_m; mm0 = mm_m; }
+          else if (n_minus == 1) { mp1 = gp_m; mm1 = mm_m; }
+          else if (n_minus == 2) { mp2 = gp_m; mm2 = mm_m; }
+          else cplx = true;
+          ++n_minus;
+        }
+      }
+    }
+  }
+  const uint32_t total = hsize + n_minus;
+  if (deferred) {
+    bloom_list[atomicAdd(bloom_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
+  } else if (valid && (cplx || total > kFastCands || total >= top_k)) {
+    cplx_list[atomicAdd(cplx_count, 1u)] = r;
+  } else if (valid) {
+    // the heap never fills: plain pushes in the reference's order, then the drain of paired.cpp:685-692
+    if (n_minus > 0) { HeapEnt e; e.pos = mp0; e.mms = mm0 | 0x80000000u; heap_push(fast, hsize, e); }
+    if (n_minus > 1) { HeapEnt e; e.pos = mp1; e.mms = mm1 | 0x80000000u; heap_push(fast, hsize, e); }
+    if (n_minus > 2) { HeapEnt e; e.pos = mp2; e.mms = mm2 | 0x80000000u; heap_push(fast, hsize, e); }
+    Candidate* out = ranked + (uint64_t)r * top_k;
+    uint32_t i = 0;
+    while (hsize) {
+      const HeapEnt e = heap_pop(fast, hsize);
+      Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
+      out[i++] = c;
+    }
+    heap_n[r] = total;
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_pe_topk_dual(
+    IndexView iv, const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
+    uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, uint32_t top_k,
+    const uint32_t* __restrict__ mask_table, Candidate* __restrict__ ranked, uint32_t* __restrict__ heap_n,
+    unsigned long long* __restrict__ stats, uint32_t* __restrict__ bloom_count, uint32_t* __restrict__ bloom_list,
+    uint32_t* __restrict__ cplx_count, uint32_t* __restrict__ cplx_list) {
   __shared__ BlockShared sh;
+  __shared__ HeapEnt s_fast[kFastCands][kBlock];
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
-  uint32_t n_probe = 0, n_verified = 0, n_big = 0, shortv = 0;
-  // each block walks its own contiguous slice of the batch (consecutive 256-read
-  // chunks share pages: a strided assignment made every load a TLB miss)
+  LdsHeap fast;
+  fast.base = &s_fast[0][threadIdx.x];
+  uint32_t n_probe = 0, n_verified = 0, shortv = 0;
+  // each block walks its own contiguous slice of the batch
   const uint64_t chunks = ((uint64_t)n + blockDim.x - 1) / blockDim.x;
   const uint64_t per_block = (chunks + gridDim.x - 1) / gridDim.x;
   const uint64_t c_lo = (uint64_t)blockIdx.x * per_block;
@@ -179,55 +362,56 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk(IndexView iv, const uint32_t
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    pe_process<NW, false>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b,
-                          top_k, heaps, heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
+    pe_process_dual<NW>(iv, sh, si, fast, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, ranked, heap_n,
+                        bloom_count, bloom_list, cplx_count, cplx_list, n_probe, n_verified, len);
     // paired.cpp:112-115: too_short once per strand pass
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
-  pe_flush(shortv, n_probe, n_verified, n_big, stats);
+  pe_flush(shortv, n_probe, n_verified, 0, stats);
 }
 
-template <int NW>
-__global__ __launch_bounds__(kBlock) void k_pe_topk_literal(IndexView iv, const uint32_t* __restrict__ codes2,
-                                                             const uint64_t* __restrict__ offsets,
-                                                             uint32_t* __restrict__ err, uint32_t strand_base,
-                                                             uint32_t max_mm,
-                                                             uint32_t b, uint32_t top_k,
-                                                             const uint32_t* __restrict__ mask_table,
-                                                             HeapEnt* __restrict__ heaps,
-                                                             uint32_t* __restrict__ heap_n,
-                                                             unsigned long long* __restrict__ stats,
-                                                             const uint32_t* __restrict__ defer_count,
-                                                             const uint32_t* __restrict__ defer_list) {
+constexpr uint32_t kListHeapSlots = 768;  // HeapEnt slots per wave (6 KB): 15 heaps of top_k = 50, 2 of top_k = 300
+
+// pass 2 / 3: the reads of a list, one per lane, strand-major with the reference's exits.
+// LITERAL = false: "complex" reads of pass 1 (key/directory search; a Bloom hit sends the
+// read on to the literal list).  LITERAL = true: literal search, handles everything.
+template <int NW, bool LITERAL>
+__global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uint32_t* __restrict__ codes2,
+                                                          const uint64_t* __restrict__ offsets,
+                                                          uint32_t* __restrict__ err, uint32_t strand_base,
+                                                          uint32_t max_mm, uint32_t b, uint32_t top_k,
+                                                          const uint32_t* __restrict__ mask_table,
+                                                          Candidate* __restrict__ ranked, uint32_t* __restrict__ heap_n,
+                                                          unsigned long long* __restrict__ stats,
+                                                          const uint32_t* __restrict__ list_count,
+                                                          const uint32_t* __restrict__ list,
+                                                          uint32_t* __restrict__ defer_count,
+                                                          uint32_t* __restrict__ defer_list) {
   __shared__ BlockShared sh;
+  __shared__ HeapEnt s_heap[kBlock / 64][kListHeapSlots];  // the heaps of the reads a wave is working on
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
-  const uint32_t count = *defer_count;
+  const uint32_t count = *list_count;
   uint32_t n_probe = 0, n_verified = 0, n_big = 0;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
-    const uint32_t i = base + threadIdx.x;
-    const bool valid = i < count;
-    const uint32_t r = valid ? defer_list[i] : 0;
+  // A short list is spread thin -- down to ONE read per wavefront: listed reads are the slow ones (large
+  // regions verified by the whole wave, long chains of heap updates, literal searches), and 64 of them in
+  // one wave run one after another.  rpw = reads per wave so that every wave of the grid has work.
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t total_waves = gridDim.x * waves_per_block;
+  const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+  uint32_t rpw = (count + total_waves - 1) / total_waves;
+  const uint32_t rpw_max = kListHeapSlots / top_k < 64 ? kListHeapSlots / top_k : 64;  // top_k <= 300: at least 2
+  rpw = rpw < 1 ? 1 : (rpw > rpw_max ? rpw_max : rpw);
+  HeapEnt* heap = &s_heap[threadIdx.x >> 6][(lane < rpw ? lane : 0) * top_k];
+  for (uint64_t base = (uint64_t)wave * rpw; base < count; base += (uint64_t)total_waves * rpw) {
+    const uint64_t i = base + lane;
+    const bool valid = lane < rpw && i < count;
+    const uint32_t r = valid ? list[i] : 0;
     uint32_t len;
-    pe_process<NW, true>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k,
-                         heaps, heap_n, nullptr, nullptr, n_probe, n_verified, n_big, len);
+    pe_process<NW, LITERAL>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, heap, ranked,
+                            heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
   }
   pe_flush(0, n_probe, n_verified, n_big, stats);
-}
-
-// paired.cpp:685-692: pop everything; ranked[r][i] = i-th popped (descending mismatch).
-__global__ void k_pe_drain(HeapEnt* __restrict__ heaps, const uint32_t* __restrict__ heap_n, uint32_t n,
-                           uint32_t top_k, Candidate* __restrict__ ranked) {
-  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  HeapEnt* heap = heaps + (uint64_t)r * top_k;
-  Candidate* out = ranked + (uint64_t)r * top_k;
-  uint32_t hsize = heap_n[r];
-  uint32_t i = 0;
-  while (hsize) {
-    HeapEnt e = heap_pop(heap, hsize);
-    Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
-    out[i++] = c;
-  }
 }
 
 // Pairs whose candidate lists span more than kLightCombos (i, j) combinations are
@@ -252,10 +436,50 @@ __global__ void k_pe_merge(IndexView iv, const Candidate* __restrict__ ranked1, 
   const uint32_t a = valid ? n1[r] : 0, b = valid ? n2[r] : 0;
   const bool heavy = a * b > kLightCombos;
   if (valid && !heavy) {
+    const Candidate* r1 = ranked1 + (uint64_t)r * top_k;
+    const Candidate* r2 = ranked2 + (uint64_t)r * top_k;
+    const uint32_t len1 = (uint32_t)(off1[r + 1] - off1[r]), len2 = (uint32_t)(off2[r + 1] - off2[r]);
     PairResult pr;
-    pair_merge(ranked1 + (uint64_t)r * top_k, (int)a, ranked2 + (uint64_t)r * top_k, (int)b,
-               (uint32_t)(off1[r + 1] - off1[r]), (uint32_t)(off2[r + 1] - off2[r]), starts, iv.n_chrom, frag_range,
-               max_mm, pr);
+    if (a <= 4 && b <= 4) {
+      // the common case (a unique read is found once per seed shift: three candidates): both lists are
+      // fetched in one round of independent loads and the 16 combinations run from registers, in the
+      // order of pair_merge (i and j descending; its `break` equals `continue`, see k_pe_merge_heavy)
+      Candidate A[4], B[4];
+      uint32_t cA[4], cB[4], sA[4], eA[4], sB[4], eB[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        A[k] = r1[k < (int)a ? k : 0];
+        B[k] = r2[k < (int)b ? k : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cA[k] = chrom_id(starts, iv.n_chrom, A[k].genome_pos);
+        cB[k] = chrom_id(starts, iv.n_chrom, B[k].genome_pos);
+        forward_pos(A[k].genome_pos, A[k].strand, cA[k], len1, starts, sA[k], eA[k]);
+        forward_pos(B[k].genome_pos, B[k].strand, cB[k], len2, starts, sB[k], eB[k]);
+      }
+      int bi = -1, bj = -1;
+      uint32_t min_mm = max_mm, best_times = 0, best_hi = 0, best_lo = 0;
+#pragma unroll
+      for (int i = 3; i >= 0; --i) {
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+          const uint32_t mm = A[i].mismatch + B[j].mismatch;
+          const int frag = A[i].strand == '+' ? (int)(eB[j] - sA[i]) : (int)(eA[i] - sB[j]);
+          const bool ok = i < (int)a && j < (int)b && A[i].strand != B[j].strand && mm <= min_mm && cA[i] == cB[j] &&
+                          frag > 0 && frag <= frag_range;
+          const bool differs = A[i].genome_pos != best_hi || B[j].genome_pos != best_lo;
+          if (ok && mm < min_mm) {
+            bi = i; bj = j; best_times = 1; min_mm = mm; best_hi = A[i].genome_pos; best_lo = B[j].genome_pos;
+          } else if (ok && differs) {  // mm == min_mm
+            bi = i; bj = j; best_times++;
+          }
+        }
+      }
+      pair_finish(r1, (int)a, r2, (int)b, len1, len2, starts, iv.n_chrom, max_mm, bi, bj, best_times, pr);
+    } else {
+      pair_merge(r1, (int)a, r2, (int)b, len1, len2, starts, iv.n_chrom, frag_range, max_mm, pr);
+    }
     out[r] = pr;
   }
   const unsigned long long hv = __ballot(heavy);
@@ -368,7 +592,6 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 struct PeWorkspace {
   uint32_t* err;
   unsigned long long* shards[2];
-  HeapEnt* heaps[2];
   uint32_t* heap_n[2];
   uint32_t* defer_list[2];
   uint32_t* codes2[2];
@@ -390,9 +613,8 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
   // [0..1] pack errors, [64 + 32 m ...] deferral control of mate m, [128] heavy-pair count of the merge
   w.err = reinterpret_cast<uint32_t*>(take(192 * sizeof(uint32_t)));
   for (int m = 0; m < 2; ++m) w.shards[m] = reinterpret_cast<unsigned long long*>(take(kStatShardBytes));
-  for (int m = 0; m < 2; ++m) w.heaps[m] = reinterpret_cast<HeapEnt*>(take((uint64_t)chunk * top_k * sizeof(HeapEnt) + 64));
   for (int m = 0; m < 2; ++m) w.heap_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)chunk * 4 + 64));
-  for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take(2 * w.stride * 4 + 64));
+  for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take(3 * w.stride * 4 + 64));  // literal list, its sorted copy, complex list
   for (int m = 0; m < 2; ++m) w.codes2[m] = reinterpret_cast<uint32_t*>(take(codes2_words((uint64_t)chunk * max_read_len) * 4 + 64));
   for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
   w.total_bytes = off;
@@ -402,17 +624,26 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
 template <int NW>
 static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
                           uint64_t stride, uint32_t n, uint32_t sb,
-                          uint32_t max_mm, uint32_t b, uint32_t top_k, HeapEnt* heaps, uint32_t* heap_n,
-                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list,
+                          uint32_t max_mm, uint32_t b, uint32_t top_k, uint32_t* heap_n,
+                          Candidate* ranked, unsigned long long* stats, uint32_t* ctl, uint32_t* defer_list,
                           hipStream_t stream) {
+  // ctl: [0] literal-list count, [8..23] its bins (launch_bin_deferred), [24] complex-list count
+  uint32_t* lit_count = ctl;
+  uint32_t* cplx_count = ctl + 24;
+  uint32_t* lit_list = defer_list;
+  uint32_t* lit_sorted = defer_list + stride;
+  uint32_t* cplx_list = defer_list + 2 * stride;
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
-  hipLaunchKernelGGL(k_pe_topk<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
-                     sb, max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_list);
-  uint32_t* defer_sorted = defer_list + stride;  // second half of the list area
-  launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
-  unsigned g2 = grid_for(n) < 1024u ? grid_for(n) : 1024u;
-  hipLaunchKernelGGL(k_pe_topk_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
-                     max_mm, b, top_k, idx->d_mask_table, heaps, heap_n, stats, defer_count, defer_sorted);
+  hipLaunchKernelGGL(k_pe_topk_dual<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n, sb,
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, cplx_count,
+                     cplx_list);
+  const unsigned g2 = 1536;  // x 4 waves: the list kernels size their per-wave share from the list length
+  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, cplx_count, cplx_list, lit_count,
+                     lit_list);
+  launch_bin_deferred(lit_count, lit_list, lit_sorted, stream);
+  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr);
   return WALT_OK;
 }
 
@@ -426,7 +657,18 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   const uint64_t* offs[2] = {d_off1, d_off2};
   // err words: [0..1] pack errors (kept across chunks), [64 + 32 m ..] deferral control block of mate m (per chunk)
   WALT_HIP(hipMemsetAsync(w.err + 64, 0, 128 * sizeof(uint32_t), stream));
+  // The two mates are independent until the merge; mate 2 runs on a second stream so that its
+  // throughput-bound pass 1 overlaps mate 1's list kernels (a few slow reads, mostly idle CUs) and vice versa.
+  if (!idx->pe_stream) {
+    WALT_HIP(hipStreamCreateWithFlags(&idx->pe_stream, hipStreamNonBlocking));
+    WALT_HIP(hipEventCreateWithFlags(&idx->pe_fork, hipEventDisableTiming));
+    WALT_HIP(hipEventCreateWithFlags(&idx->pe_join, hipEventDisableTiming));
+  }
+  WALT_HIP(hipEventRecord(idx->pe_fork, stream));
+  WALT_HIP(hipStreamWaitEvent(idx->pe_stream, idx->pe_fork, 0));
+  hipStream_t user_stream = stream;
   for (int m = 0; m < 2; ++m) {
+    stream = m ? idx->pe_stream : user_stream;
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
     unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;
@@ -434,17 +676,18 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], w.err, stream);
     int rc;
     switch (nw) {
-      case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
-      case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
-      case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
-      case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
-      default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heaps[m], w.heap_n[m], st, ctl, w.defer_list[m], stream); break;
+      case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
     }
     if (rc) return rc;
     launch_reduce_stats(w.shards[m], d_stats + 4 * m, stream);
-    hipLaunchKernelGGL(k_pe_drain, dim3(grid_for(n)), dim3(kBlock), 0, stream, w.heaps[m], w.heap_n[m], n, top_k,
-                       w.ranked[m]);
   }
+  stream = user_stream;
+  WALT_HIP(hipEventRecord(idx->pe_join, idx->pe_stream));
+  WALT_HIP(hipStreamWaitEvent(stream, idx->pe_join, 0));
   // both mates are mapped: mate 1's deferral list area is free and holds the heavy-pair list of the merge
   uint32_t* heavy_count = w.err + 128;
   uint32_t* heavy_list = w.defer_list[0];
@@ -477,7 +720,7 @@ extern "C" {
 size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
-  uint32_t chunk = n < kPeChunk ? n : kPeChunk;
+  uint32_t chunk = pe_chunk_pairs(n, top_k);
   return (size_t)carve_pe(nullptr, chunk, nw, top_k, max_read_len).total_bytes;
 }
 
@@ -491,7 +734,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
   if (n == 0) return WALT_OK;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WALT_HIP(hipSetDevice(idx->device));
-  const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
+  const uint32_t chunk = pe_chunk_pairs(n, top_k);
   PeWorkspace w = carve_pe(d_workspace, chunk, nw, top_k, max_read_len);
   WALT_HIP(hipMemsetAsync(w.err, 0, 128 * sizeof(uint32_t), stream));
   for (int m = 0; m < 2; ++m) WALT_HIP(hipMemsetAsync(w.shards[m], 0, kStatShardBytes, stream));
@@ -542,7 +785,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     if ((e = hipMemcpy(d_bases[m], bases[m] + offs[m][0], nbytes, hipMemcpyHostToDevice)) != hipSuccess) break;
     e = hipMemcpy(d_off[m], rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
   }
-  const uint32_t chunk = n < kPeChunk ? n : kPeChunk;
+  const uint32_t chunk = pe_chunk_pairs(n, top_k);
   const size_t ws_bytes = carve_pe(nullptr, chunk, nw, top_k, max_len).total_bytes;
   if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * sizeof(walt_pair_result));
   if (e == hipSuccess) e = hipMalloc(&d_stats, 2 * sizeof(walt_batch_stats));

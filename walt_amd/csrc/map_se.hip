@@ -282,93 +282,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 //     so the result is identical; unused speculative probes are only extra work.
 // A lane whose probe lands in a BAD bucket is deferred to the literal pass.
 // ---------------------------------------------------------------------------
-struct SlotProbe {
-  uint32_t lo, ne;      // slot range [lo, lo+ne) of the directory lookup (ne == 0: nothing)
-  Ent e[kScan];         // its first entries (clamped indices, independent loads)
-};
-
-// directory pair of a probe: dir[slot] (start) and dir[slot - span] (end).  span is 1
-// for every seed of >= dir_bits code bits, so the pair is ONE 8-byte load of
-// dir[slot-1 .. slot]; short seeds (span > 1) fetch the far end separately.
-__device__ __forceinline__ void probe_issue(const StrandView& sv, bool need, uint32_t slot, uint32_t span,
-                                            uint32_t& lo, uint32_t& hi) {
-  const uint32_t s0 = need ? slot : 1u, sp = need ? span : 1u;  // slot >= 1 whenever a seed exists
-  const uint32_t* p = sv.dir + (s0 - 1);
-  uint32_t pair[2];
-  __builtin_memcpy(pair, p, 8);
-  hi = pair[0];
-  lo = pair[1];
-  if (sp != 1) hi = sv.dir[s0 - sp];
-}
-__device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p) {
-#pragma unroll
-  for (uint32_t j = 0; j < kScan; ++j) {
-    const uint32_t k = p.ne ? p.lo + (j < p.ne ? j : p.ne - 1) : 0u;  // ent[] has index_size + 1 slots
-    p.e[j] = sv.ent[k];
-  }
-}
-// region + leading candidate positions from a probed slot (core.h seed_lookup_ex, scan branch)
-__device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotProbe& p, const uint32_t* care,
-                                              uint32_t seed_len, Lookup& out) {
-  out.npos = 0;
-  out.reg = empty_region();
-  if (p.ne == 0) return;
-  const uint32_t n = seed_len - kKeyWeight;
-  const uint32_t nk = n < kKeyChars ? n : kKeyChars;
-  const uint64_t M = key_mask(nk);
-  const uint64_t T = target_key(care) & M;
-  uint32_t a, u;
-  if (p.ne <= kScan) {
-    uint32_t n_lt = 0, n_eq = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kScan; ++j) {
-      const uint64_t k = ent_key(p.e[j]) & M;
-      n_lt += (j < p.ne && k < T) ? 1u : 0u;
-      n_eq += (j < p.ne && k == T) ? 1u : 0u;
-    }
-    if (n_eq == 0) return;
-    a = p.lo + n_lt;
-    u = a + n_eq - 1;
-    out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
-#pragma unroll
-    for (uint32_t i = 0; i < kLookupPos; ++i) {
-      uint32_t q = 0;
-#pragma unroll
-      for (uint32_t j = 0; j < kScan; ++j) q = (n_lt + i == j) ? p.e[j].pos : q;
-      out.pos[i] = q;
-    }
-  } else {
-    if (!slot_binary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
-  }
-  if (n > kKeyChars) {
-    out.npos = 0;
-    out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
-    return;
-  }
-  out.reg.l = a; out.reg.u = u;
-}
-
-// branch-free candidate check: the genome window is always loaded (from position
-// 0 when the edge filters of mapping.cpp:280-286 reject the candidate)
-template <int NW>
-__device__ __forceinline__ void verify_nobranch(const StrandView& sv, const BlockShared& sh, const uint32_t* si,
-                                                uint32_t n_chrom, uint32_t top_step, bool active, uint32_t slot_pos,
-                                                uint32_t seed_i, uint32_t len, const uint32_t* rd,
-                                                const uint32_t* mk, bool& ok, uint32_t& gp, uint32_t& mm) {
-  // chromosome starts from LDS when they fit (ds_read), else from HBM; uniform branch
-  uint32_t c_lo, c_hi;
-  if (n_chrom <= kLdsChroms) {
-    const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, slot_pos);
-    c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
-  } else {
-    const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, slot_pos);
-    c_lo = si[chr]; c_hi = si[chr + 1];
-  }
-  const uint32_t g = slot_pos - seed_i;
-  ok = active && (slot_pos - c_lo >= seed_i) && (g + len < c_hi);
-  gp = ok ? g : 0u;
-  mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
-}
+// SlotProbe / probe_issue / probe_entries / probe_resolve / verify_nobranch live in map_common.h (shared with map_pe.hip)
 
 template <int NW, bool DIAG>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si,
