@@ -98,7 +98,7 @@ def test_gpu_pe_ranked_lists_and_pairs_equal_oracle(wa, g1_db, g1_dev, pe_chunk,
         assert_best_equal(got["m2"], want["m2"], "m2")
 
 
-@pytest.mark.parametrize("seed,n_chrom", [(11, 80), (12, 300), (13, 10)])
+@pytest.mark.parametrize("seed,n_chrom", [(11, 80), (12, 300), (13, 10), (14, 1500)])  # 1500 > LDS chromosome table
 def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
     seqs, db = make_random_case(seed, n_chrom, scratch)
     rng = random.Random(seed * 31)
@@ -128,6 +128,11 @@ def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
                     for j in range(len(reads_ct)):
                         assert np.array_equal(gr[j][:no[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), (k, j)
                         assert np.array_equal(gr[j][:no[j]]["mismatch"], ro[j][:no[j]]["mismatch"]), (k, j)
+                want, _, _ = refio.oracle_pe(db, reads_ct, reads_ct, max_mm=6, b=5000, top_k=k, frag_range=1000)
+                for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"):
+                    assert np.array_equal(res[f], want[f]), (k, f)
+                assert_best_equal(res["m1"], want["m1"], "pair m1 k=%d" % k)
+                assert_best_equal(res["m2"], want["m2"], "pair m2 k=%d" % k)
         idx.close()
     assert any_bad > 0
 

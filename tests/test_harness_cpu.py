@@ -110,7 +110,7 @@ def sample_reads(rng, seqs, n, conv):
     return out
 
 
-@pytest.mark.parametrize("seed,n_chrom", [(1, 60), (2, 200), (3, 12)])
+@pytest.mark.parametrize("seed,n_chrom", [(1, 60), (2, 200), (3, 12), (4, 1100)])
 def test_harness_random_genomes_vs_oracle(scratch, seed, n_chrom):
     seqs, db = make_random_case(seed, n_chrom, scratch)
     rng = random.Random(seed * 77)
