@@ -238,7 +238,7 @@ static void process_se(const Options& o, const string& reads_file, const string&
   double t0 = now_s();
   walt_index* idx = nullptr;
   check(walt_index_open(o.index_file.c_str(), o.device, o.ag ? WALT_STRANDS_GA : WALT_STRANDS_CT, -1, &idx));
-  double t_index = now_s() - t0, t_load = 0, t_map = 0, t_out = 0;
+  double t_index = now_s() - t0, t_load = 0, t_map = 0, t_out = 0, t_write = 0;
   GenomeInfo g = genome_of(idx);
   hostio::FastqReader rd;
   rd.open(reads_file, T);
@@ -278,6 +278,8 @@ static void process_se(const Options& o, const string& reads_file, const string&
       for (int k = 0; k < kSinks; ++k) s[k].clear();
       SeCounts c;
       const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+      // one allocation per thread and batch instead of doubling: name + 2 x read + fixed fields per line
+      s[kMain].grow((bt.offsets[hi] - bt.offsets[lo]) * 2 + (size_t)(hi - lo) * 96);
       for (uint32_t j = lo; j < hi; ++j) {
         c.update(res[j].times);
         if (!o.sam) out_single_results(res[j], bt.name(j), bt.seq(j), bt.score(j), g, o.ag, side.out_amb, side.out_unm,
@@ -287,10 +289,12 @@ static void process_se(const Options& o, const string& reads_file, const string&
       acc[t] = c;
     }
     for (int t = 0; t < T; ++t) st.add(acc[t]);
+    t_out += now_s() - t0;
+    t0 = now_s();
     fout.write_sinks(sinks, kSinks, kMain, T);
     side.amb.write_sinks(sinks, kSinks, kAmb1, T);
     side.unm.write_sinks(sinks, kSinks, kUnm1, T);
-    t_out += now_s() - t0;
+    t_write += now_s() - t0;
     if (n < o.batch_size) break;
   }
   if (o.verbose)
@@ -304,8 +308,8 @@ static void process_se(const Options& o, const string& reads_file, const string&
   mapstats << st.tostring() << std::endl;
   walt_index_close(idx);
   if (o.verbose)
-    fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, output %.2f s]\n", T, t_index,
-            t_load, t_map, t_out);
+    fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, format %.2f s, write %.2f s]\n", T,
+            t_index, t_load, t_map, t_out, t_write);
 }
 
 // ---------------------------------------------------------------- paired-end writers
