@@ -174,19 +174,31 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
                                                      d_stats.data_ptr(), d_ws.data_ptr(), stream)
         assert rc == 0, walt_amd.lib().walt_last_error()
 
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
+    from walt_amd import dist as wdist
+    elapsed = wdist.allreduce_max(elapsed, device=dev)  # MAX over ranks
     ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last chunk (map_pe.hip carve_pe)
     log("last chunk: literal-list %d / %d, complex-list %d / %d (mate 1 / mate 2), heavy pairs %d" % (
         int(ctl[64]), int(ctl[96]), int(ctl[88]), int(ctl[120]), int(ctl[128])))
     res = d_out.view(torch.int32).view(n, 16)
     bt = res[:, 8]
+    # StatPairedReads pair counters (paired.hpp:96-105), summed over ranks: the only collective
+    pst = wdist.allreduce_stats(torch.stack([torch.tensor(n, device=dev), (bt == 1).sum(), (bt >= 2).sum(),
+                                             (bt == 0).sum()]).to(torch.int64))
+    pairs_t, uniq_t, amb_t, unp_t = [int(v) for v in pst.tolist()]
     out = {"metric": "mapped read pairs/sec (2 x %d bp paired-end, hg19-scale index, -m %d -k %d -L %d)" % (
                args.read_len, args.max_mismatches, args.top_k, args.frag_range),
            "value": world * n * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -194,8 +206,7 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
            "config": {"workload": "configs[2]: hg19-scale synthetic genome, %d pairs 2 x %d bp, fragment U[120,500]" % (
                n, args.read_len), "index_hbm_gb": round(idx.device_bytes / 1e9, 2)},
-           "mapping": {"pairs": n, "unique_pairs": int((bt == 1).sum()), "ambiguous_pairs": int((bt >= 2).sum()),
-                       "unpaired": int((bt == 0).sum())}}
+           "mapping": {"pairs": pairs_t, "unique_pairs": uniq_t, "ambiguous_pairs": amb_t, "unpaired": unp_t}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     idx.close()
@@ -255,8 +266,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("WALT_AMD_BENCH_SHARE_GPU"):
+            # rehearsal of the multi-rank path on a one-GPU box: every rank on GPU 0, gloo instead of RCCL
+            # (RCCL refuses two ranks on one device); not a measurement
+            local = 0
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if walt_amd.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the walt_amd hot path has no CPU fallback")
     torch.cuda.set_device(local)
