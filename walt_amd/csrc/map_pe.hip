@@ -796,8 +796,12 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
   }
   PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k, max_len);
-  hipMemset(w.err, 0, 128 * sizeof(uint32_t));
-  for (int m = 0; m < 2; ++m) hipMemset(w.shards[m], 0, kStatShardBytes);
+  e = hipMemset(w.err, 0, 128 * sizeof(uint32_t));
+  for (int m = 0; m < 2 && e == hipSuccess; ++m) e = hipMemset(w.shards[m], 0, kStatShardBytes);
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(WALT_EHIP, std::string("workspace setup failed: ") + hipGetErrorString(e));
+  }
   for (uint32_t start = 0; start < n && !rc; start += chunk) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases[0]), reinterpret_cast<const uint64_t*>(d_off[0]) + start,
@@ -808,16 +812,20 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     if (hipDeviceSynchronize() != hipSuccess) { rc = fail(WALT_EHIP, "paired-end kernels failed"); break; }
     walt_candidate* rk[2] = {ranked1, ranked2};
     uint32_t* rn[2] = {ranked_n1, ranked_n2};
-    for (int m = 0; m < 2; ++m) {
-      if (rk[m]) hipMemcpy(rk[m] + (size_t)start * top_k, w.ranked[m], (size_t)cnt * top_k * sizeof(walt_candidate), hipMemcpyDeviceToHost);
-      if (rn[m]) hipMemcpy(rn[m] + start, w.heap_n[m], (size_t)cnt * 4, hipMemcpyDeviceToHost);
+    for (int m = 0; m < 2 && !rc; ++m) {
+      if (rk[m] && hipMemcpy(rk[m] + (size_t)start * top_k, w.ranked[m], (size_t)cnt * top_k * sizeof(walt_candidate),
+                             hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(WALT_EHIP, "download of the ranked lists failed");
+      if (!rc && rn[m] && hipMemcpy(rn[m] + start, w.heap_n[m], (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(WALT_EHIP, "download of the ranked-list lengths failed");
     }
   }
   if (!rc) rc = check_read_errors(d_ws, nullptr);
   if (!rc) {
     if (hipMemcpy(out, d_out, (size_t)n * sizeof(walt_pair_result), hipMemcpyDeviceToHost) != hipSuccess)
       rc = fail(WALT_EHIP, "download failed");
-    if (!rc && stats) hipMemcpy(stats, d_stats, 2 * sizeof(walt_batch_stats), hipMemcpyDeviceToHost);
+    if (!rc && stats && hipMemcpy(stats, d_stats, 2 * sizeof(walt_batch_stats), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(WALT_EHIP, "download of the statistics failed");
   }
   cleanup();
   return rc;

@@ -656,8 +656,8 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
     g_ablate = ab ? (uint32_t)atoi(ab) : 0u;
     if (g_ablate) fprintf(stderr, "[walt_amd] WALT_AMD_ABLATE=%u: DIAGNOSTIC RUN, mapping results are not valid\n", g_ablate);
     if (getenv("WALT_AMD_STAMPS") && !g_stamps) {
-      hipMalloc(reinterpret_cast<void**>(&g_stamps), 16 * sizeof(unsigned long long));
-      hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long));
+      WALT_HIP(hipMalloc(reinterpret_cast<void**>(&g_stamps), 16 * sizeof(unsigned long long)));
+      WALT_HIP(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
     }
   }
   const int nw = nw_for_len(max_read_len);
