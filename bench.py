@@ -160,6 +160,10 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
     n = args.reads
     d1, d2, d_off = make_pairs(torch, dev, genome_ascii, n, args.read_len, seed=2000 + rank)
     torch.cuda.synchronize()
+    run_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    ns = min(args.cpu_sample // 4, n)  # paired-end costs ~3.4x single-end per read on the CPU
+    if run_cpu:
+        m1_host, m2_host = d1[:ns * args.read_len].cpu().numpy(), d2[:ns * args.read_len].cpu().numpy()
     del genome_ascii
     torch.cuda.empty_cache()
     d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
@@ -207,6 +211,17 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
            "config": {"workload": "configs[2]: hg19-scale synthetic genome, %d pairs 2 x %d bp, fragment U[120,500]" % (
                n, args.read_len), "index_hbm_gb": round(idx.device_bytes / 1e9, 2)},
            "mapping": {"pairs": pairs_t, "unique_pairs": uniq_t, "ambiguous_pairs": amb_t, "unpaired": unp_t}}
+    if run_cpu:
+        want, cpu_s, cores = cpu_baseline_pe(idx, m1_host, m2_host, args.read_len, ns, lens, args.max_mismatches,
+                                             args.bucket, args.top_k, args.frag_range)
+        got = d_out[:ns * 64].cpu().numpy().view(walt_amd.pair_result_dtype)
+        same = all(np.array_equal(got[f], want[f]) for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"))
+        for m in ("m1", "m2"):
+            same = same and all(np.array_equal(got[m][f], want[m][f]) for f in ("genome_pos", "times", "strand", "mismatch"))
+        out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": "first %d pairs, oracle restatement of PairEndMapping on both mates and "
+                                         "strands + pair merge, OpenMP; two strand indexes in host memory at a time" % ns,
+                               "bit_exact_vs_gpu": bool(same)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     idx.close()
@@ -237,6 +252,47 @@ def cpu_baseline(idx, reads_host, read_len, n_sample, lens, max_mm, b):
         elapsed += time.perf_counter() - t0
         del g, cnt, ix, x
     return out, work[0], elapsed, cores
+
+
+def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, frag_range):
+    """Oracle restatement of PairEndMapping + MergePairedEndResults on the host cores; the two strand
+    indexes of one mate are in host memory at a time."""
+    import refio
+    import walt_amd
+    cores = walt_amd.effective_cpus()
+    orc = refio.oracle()
+    offsets = (np.arange(n + 1, dtype=np.uint64) * read_len)
+    start = np.zeros(len(lens) + 1, dtype=np.uint32)
+    start[1:] = np.cumsum(lens, dtype=np.uint64).astype(np.uint32)
+    ranked, counts = [], []
+    elapsed = 0.0
+    for mate, bases in ((0, m1_host), (1, m2_host)):
+        keep = []
+        arr = (refio.OrcStrand * 2)()
+        for k in range(2):
+            g, cnt, ix = idx.export_strand(2 * mate + k)
+            keep.append((g, cnt, ix))
+            x = refio.make_orc_strand(g, cnt, ix, start)
+            for f, _ in refio.OrcStrand._fields_:
+                setattr(arr[k], f, getattr(x, f))
+        r = np.zeros((n, top_k), dtype=refio.cand_dtype)
+        c = np.zeros(n, dtype=np.uint32)
+        work = np.zeros(1, dtype=refio.work_dtype)
+        bases = np.ascontiguousarray(bases[:n * read_len])
+        t0 = time.perf_counter()
+        orc.orc_pe_topk_batch(ctypes.addressof(arr), bases.ctypes.data, offsets.ctypes.data, n, mate, max_mm, b, top_k,
+                              cores, r.ctypes.data, c.ctypes.data, work.ctypes.data)
+        elapsed += time.perf_counter() - t0
+        ranked.append(r)
+        counts.append(c)
+        del keep, arr
+    out = np.zeros(n, dtype=refio.pair_dtype)
+    t0 = time.perf_counter()
+    orc.orc_pe_merge_batch(ranked[0].ctypes.data, counts[0].ctypes.data, ranked[1].ctypes.data, counts[1].ctypes.data,
+                           top_k, offsets.ctypes.data, offsets.ctypes.data, n, start.ctypes.data, len(lens), frag_range,
+                           max_mm, out.ctypes.data)
+    elapsed += time.perf_counter() - t0
+    return out, elapsed, cores
 
 
 def main():
