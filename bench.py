@@ -192,6 +192,7 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    idx.check_batch(d_ws.data_ptr(), stream)  # no invalid read went unnoticed
     from walt_amd import dist as wdist
     elapsed = wdist.allreduce_max(elapsed, device=dev)  # MAX over ranks
     ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last chunk (map_pe.hip carve_pe)
@@ -296,6 +297,9 @@ def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, 
 
 
 def main():
+    # the paired-end path keeps several streams busy (two mates x two pipeline slots); the HIP runtime
+    # multiplexes streams onto 4 hardware queues unless told otherwise, before it initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -397,6 +401,7 @@ def main():
         map_ms.append(m_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    idx.check_batch(d_ws.data_ptr(), stream)  # no invalid read went unnoticed
     from walt_amd import dist as wdist
     elapsed = wdist.allreduce_max(elapsed, device=dev)  # MAX over ranks
 

@@ -140,6 +140,13 @@ int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d
                              uint32_t max_read_len, int ag_wildcard, uint32_t max_mismatches,
                              uint32_t b, void* d_out, void* d_stats, void* d_workspace, void* stream);
 
+/* The device-resident calls are asynchronous, so invalid input cannot come back as their status.
+ * walt_batch_check waits for `stream` and reports what the last call on `d_workspace` found:
+ * WALT_EBASE (a read holds a non-ACGT base: the reference's getBits exits, util.hpp:117-119; its
+ * record is left as initialised), WALT_EINVAL (a read longer than max_read_len), else WALT_OK.
+ * The host-buffer calls do this themselves. */
+int walt_batch_check(const void* d_workspace, void* stream);
+
 /* ---- paired-end: replaces PairEndMapping over both mates and strands
  *      (paired.cpp:642-672 / 106-201), the heap drain (685-692) and the pair
  *      search of MergePairedEndResults (474-545) ----------------------------- */

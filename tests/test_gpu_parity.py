@@ -201,6 +201,50 @@ def test_gpu_device_pointer_api_with_torch(wa, g1_db, g1_dev):
     want, work = refio.oracle_se(g1_db, seqs)
     assert_best_equal(got, want, "device api")
     assert int(d_stats[0]) == int(work["too_short"])
+    idx.check_batch(d_ws.data_ptr(), stream)
+    # an invalid base cannot come back as the status of the asynchronous call: walt_batch_check reports it
+    bad = bases.copy()
+    bad[offsets[5] + 3] = ord("N")
+    d_bad = torch.from_numpy(bad).to(dev)
+    idx.map_se_batch_device(d_bad.data_ptr(), d_off.data_ptr(), n, max_len, d_out.data_ptr(), d_stats.data_ptr(),
+                            d_ws.data_ptr(), stream=stream)
+    with pytest.raises(wa.WaltError) as ei:
+        idx.check_batch(d_ws.data_ptr(), stream)
+    assert ei.value.code == wa.WALT_EBASE
+
+
+def test_gpu_pe_device_api_pipelined_passes(wa, g1_db, g1_dev, monkeypatch):
+    """Device-resident paired-end call forced through many passes: they alternate between the two pipeline
+    slots (own workspace and streams) and must give the oracle's pair records."""
+    import torch
+    monkeypatch.setenv("WALT_AMD_PE_CHUNK", "257")
+    idx = g1_dev[-1]
+    _, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 10 ** 7))
+    _, s2, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_2.fastq"), 10 ** 7))
+    b1, o1 = wa.pack_reads(s1)
+    b2, o2 = wa.pack_reads(s2)
+    n = len(s1)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d1, d2 = t(b1), t(b2)
+    do1, do2 = t(o1.astype(np.int64)), t(o2.astype(np.int64))
+    max_len = int(max((o1[1:] - o1[:-1]).max(), (o2[1:] - o2[:-1]).max()))
+    for k, m in ((50, 6), (3, 6), (300, 10)):
+        want, _, _ = refio.oracle_pe(g1_db, s1, s2, max_mm=m, b=5000, top_k=k, frag_range=1000)
+        d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+        d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+        d_ws = torch.empty(wa.lib().walt_pe_workspace_bytes(n, max_len, k), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):  # twice: slot state (events, streams) is reused across calls
+            idx.map_pe_batch_device(d1.data_ptr(), do1.data_ptr(), d2.data_ptr(), do2.data_ptr(), n, max_len,
+                                    d_out.data_ptr(), d_stats.data_ptr(), d_ws.data_ptr(), stream=stream,
+                                    max_mismatches=m, top_k=k)
+            idx.check_batch(d_ws.data_ptr(), stream)
+            got = d_out.cpu().numpy().view(wa.pair_result_dtype)
+            for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"):
+                assert np.array_equal(got[f], want[f]), (k, f)
+            assert_best_equal(got["m1"], want["m1"], "m1 k=%d" % k)
+            assert_best_equal(got["m2"], want["m2"], "m2 k=%d" % k)
 
 
 def test_gpu_crowded_chromosome_ends(wa, scratch):

@@ -59,6 +59,10 @@ assert best_match_dtype.itemsize == 16 and candidate_dtype.itemsize == 12
 assert pair_result_dtype.itemsize == 64 and batch_stats_dtype.itemsize == 32
 
 
+# status codes of include/walt_amd.h
+WALT_OK, WALT_EINVAL, WALT_EIO, WALT_EHIP, WALT_EBASE, WALT_ENOMEM, WALT_EFORMAT = 0, -1, -2, -3, -4, -5, -6
+
+
 class WaltError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("walt_amd error %d: %s" % (code, msg))
@@ -129,6 +133,7 @@ def lib():
     L.walt_se_workspace_bytes.argtypes = [u32, u32]
     L.walt_se_workspace_bytes.restype = c.c_size_t
     L.walt_map_se_batch_device.argtypes = [vp, vp, vp, u32, u32, ci, u32, u32, vp, vp, vp, vp]
+    L.walt_batch_check.argtypes = [vp, vp]
     L.walt_map_pe_batch.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, ci, vp, vp, vp, vp, vp, vp]
     L.walt_pe_workspace_bytes.argtypes = [u32, u32, u32]
     L.walt_pe_workspace_bytes.restype = c.c_size_t
@@ -316,6 +321,17 @@ class Index:
         _check(lib().walt_map_se_batch_device(self._h, d_bases, d_offsets, int(n), int(max_read_len),
                                               int(bool(ag_wildcard)), int(max_mismatches), int(b), d_out, d_stats,
                                               d_workspace, stream))
+
+    @staticmethod
+    def check_batch(d_workspace, stream=0):
+        """Waits for `stream`; raises if the last device-resident call on this workspace met an invalid read."""
+        _check(lib().walt_batch_check(d_workspace, stream))
+
+    def map_pe_batch_device(self, d_bases1, d_offsets1, d_bases2, d_offsets2, n, max_read_len, d_out, d_stats,
+                            d_workspace, stream=0, max_mismatches=6, b=5000, top_k=50, frag_range=1000):
+        _check(lib().walt_map_pe_batch_device(self._h, d_bases1, d_offsets1, d_bases2, d_offsets2, int(n),
+                                              int(max_read_len), int(max_mismatches), int(b), int(top_k),
+                                              int(frag_range), d_out, d_stats, d_workspace, stream))
 
     # -- paired-end -----------------------------------------------------------
     def map_pe_batch(self, bases1, offsets1, bases2, offsets2, max_mismatches=6, b=5000, top_k=50,

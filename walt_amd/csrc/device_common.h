@@ -34,9 +34,11 @@ struct walt_index {
   bool profile = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before pack, before map, after map
   bool ev_valid = false;
-  // paired-end: mate 2's kernels run on this second stream beside mate 1's (created on first use)
-  hipStream_t pe_stream = nullptr;
-  hipEvent_t pe_fork = nullptr, pe_join = nullptr;
+  // paired-end (created on first use): two pipeline slots, each with a stream for mate 1 + merge (A, unused in
+  // slot 0 of a single-pass call: the caller's stream plays that role) and one for mate 2 (B)
+  hipStream_t pe_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipEvent_t pe_fork[2] = {nullptr, nullptr}, pe_join[2] = {nullptr, nullptr}, pe_done[2] = {nullptr, nullptr};
+  hipEvent_t pe_start = nullptr;
 };
 
 namespace walt {

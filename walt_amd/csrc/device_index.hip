@@ -620,9 +620,14 @@ void walt_index_close(walt_index* idx) {
   for (void* p : idx->allocs) hipFree(p);
   for (int i = 0; i < 3; ++i)
     if (idx->ev[i]) hipEventDestroy(idx->ev[i]);
-  if (idx->pe_fork) hipEventDestroy(idx->pe_fork);
-  if (idx->pe_join) hipEventDestroy(idx->pe_join);
-  if (idx->pe_stream) hipStreamDestroy(idx->pe_stream);
+  for (int k = 0; k < 2; ++k) {
+    if (idx->pe_fork[k]) hipEventDestroy(idx->pe_fork[k]);
+    if (idx->pe_join[k]) hipEventDestroy(idx->pe_join[k]);
+    if (idx->pe_done[k]) hipEventDestroy(idx->pe_done[k]);
+    for (int j = 0; j < 2; ++j)
+      if (idx->pe_stream[k][j]) hipStreamDestroy(idx->pe_stream[k][j]);
+  }
+  if (idx->pe_start) hipEventDestroy(idx->pe_start);
   delete idx;
 }
 

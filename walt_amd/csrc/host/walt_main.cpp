@@ -583,6 +583,7 @@ int main(int argc, const char** argv) {
       return EXIT_SUCCESS;
     }
     Options o = parse(argc, argv);
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);  // paired-end keeps several streams busy; read by the HIP runtime at start-up
     static const char* sfx[5] = {"", "_CT00", "_CT01", "_GA10", "_GA11"};  // validate_index_file, walt.cpp:67-85
     for (const char* s : sfx) if (!exists(o.index_file + s)) die("index file missing: " + o.index_file + s);
     vector<string> se = split_csv(o.se_csv), p1 = split_csv(o.pe1_csv), p2 = split_csv(o.pe2_csv);

@@ -647,47 +647,56 @@ static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const u
   return WALT_OK;
 }
 
-// one chunk (n <= chunk capacity of the workspace)
+static int pe_streams(walt_index* idx) {
+  if (idx->pe_start) return WALT_OK;
+  for (int k = 0; k < 2; ++k) {
+    for (int j = 0; j < 2; ++j) WALT_HIP(hipStreamCreateWithFlags(&idx->pe_stream[k][j], hipStreamNonBlocking));
+    WALT_HIP(hipEventCreateWithFlags(&idx->pe_fork[k], hipEventDisableTiming));
+    WALT_HIP(hipEventCreateWithFlags(&idx->pe_join[k], hipEventDisableTiming));
+    WALT_HIP(hipEventCreateWithFlags(&idx->pe_done[k], hipEventDisableTiming));
+  }
+  WALT_HIP(hipEventCreateWithFlags(&idx->pe_start, hipEventDisableTiming));
+  return WALT_OK;
+}
+
+// one pass (n <= pass capacity of the workspace) in pipeline slot `slot`; `stream` carries mate 1 and the merge
 static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_off1, const uint8_t* d_bases2,
                     const uint64_t* d_off2, uint32_t n, int nw, uint32_t max_read_len, uint32_t max_mm, uint32_t b,
                     uint32_t top_k,
                     int frag_range, PairResult* d_out, unsigned long long* d_stats, const PeWorkspace& w,
-                    hipStream_t stream) {
+                    uint32_t* pack_err, int slot, hipStream_t stream) {
   const uint8_t* bases[2] = {d_bases1, d_bases2};
   const uint64_t* offs[2] = {d_off1, d_off2};
-  // err words: [0..1] pack errors (kept across chunks), [64 + 32 m ..] deferral control block of mate m (per chunk)
+  // err words of the slot's workspace: [64 + 32 m ..] deferral control block of mate m, [128] heavy-pair count
+  // (per pass); pack_err[0..1] = invalid-read counters of the whole call
   WALT_HIP(hipMemsetAsync(w.err + 64, 0, 128 * sizeof(uint32_t), stream));
   // The two mates are independent until the merge; mate 2 runs on a second stream so that its
   // throughput-bound pass 1 overlaps mate 1's list kernels (a few slow reads, mostly idle CUs) and vice versa.
-  if (!idx->pe_stream) {
-    WALT_HIP(hipStreamCreateWithFlags(&idx->pe_stream, hipStreamNonBlocking));
-    WALT_HIP(hipEventCreateWithFlags(&idx->pe_fork, hipEventDisableTiming));
-    WALT_HIP(hipEventCreateWithFlags(&idx->pe_join, hipEventDisableTiming));
-  }
-  WALT_HIP(hipEventRecord(idx->pe_fork, stream));
-  WALT_HIP(hipStreamWaitEvent(idx->pe_stream, idx->pe_fork, 0));
+  hipStream_t stream_b = idx->pe_stream[slot][1];
+  WALT_HIP(hipEventRecord(idx->pe_fork[slot], stream));
+  WALT_HIP(hipStreamWaitEvent(stream_b, idx->pe_fork[slot], 0));
   hipStream_t user_stream = stream;
   for (int m = 0; m < 2; ++m) {
-    stream = m ? idx->pe_stream : user_stream;
+    stream = m ? stream_b : user_stream;
     // mate 1: C->T on _CT00/_CT01; mate 2: G->A on _GA10/_GA11 (paired.cpp:643,589-593)
     unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;
     uint32_t* ctl = w.err + 64 + 32 * m;
-    launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], w.err, stream);
+    launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], pack_err, stream);
     int rc;
     switch (nw) {
-      case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], w.err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
     }
     if (rc) return rc;
     launch_reduce_stats(w.shards[m], d_stats + 4 * m, stream);
   }
   stream = user_stream;
-  WALT_HIP(hipEventRecord(idx->pe_join, idx->pe_stream));
-  WALT_HIP(hipStreamWaitEvent(stream, idx->pe_join, 0));
+  WALT_HIP(hipEventRecord(idx->pe_join[slot], stream_b));
+  WALT_HIP(hipStreamWaitEvent(stream, idx->pe_join[slot], 0));
   // both mates are mapped: mate 1's deferral list area is free and holds the heavy-pair list of the merge
   uint32_t* heavy_count = w.err + 128;
   uint32_t* heavy_list = w.defer_list[0];
@@ -721,7 +730,8 @@ size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
   uint32_t chunk = pe_chunk_pairs(n, top_k);
-  return (size_t)carve_pe(nullptr, chunk, nw, top_k, max_read_len).total_bytes;
+  // a call of several passes keeps two of them in flight (two workspaces)
+  return (size_t)carve_pe(nullptr, chunk, nw, top_k, max_read_len).total_bytes * (n > chunk ? 2 : 1);
 }
 
 int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* d_offsets1, const void* d_bases2,
@@ -735,17 +745,36 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WALT_HIP(hipSetDevice(idx->device));
   const uint32_t chunk = pe_chunk_pairs(n, top_k);
-  PeWorkspace w = carve_pe(d_workspace, chunk, nw, top_k, max_read_len);
-  WALT_HIP(hipMemsetAsync(w.err, 0, 128 * sizeof(uint32_t), stream));
-  for (int m = 0; m < 2; ++m) WALT_HIP(hipMemsetAsync(w.shards[m], 0, kStatShardBytes, stream));
-  for (uint32_t start = 0; start < n; start += chunk) {
+  if ((rc = pe_streams(idx))) return rc;
+  // Passes alternate between two pipeline slots (own workspace and streams), so the latency-bound list
+  // kernels and the merge of one pass run beside the throughput-bound pass 1 of the next.
+  const bool two = n > chunk;
+  PeWorkspace w[2];
+  w[0] = carve_pe(d_workspace, chunk, nw, top_k, max_read_len);
+  w[1] = two ? carve_pe(static_cast<uint8_t*>(d_workspace) + w[0].total_bytes, chunk, nw, top_k, max_read_len) : w[0];
+  WALT_HIP(hipMemsetAsync(w[0].err, 0, 128 * sizeof(uint32_t), stream));
+  for (int k = 0; k < (two ? 2 : 1); ++k)
+    for (int m = 0; m < 2; ++m) WALT_HIP(hipMemsetAsync(w[k].shards[m], 0, kStatShardBytes, stream));
+  if (two) {
+    WALT_HIP(hipEventRecord(idx->pe_start, stream));
+    for (int k = 0; k < 2; ++k) WALT_HIP(hipStreamWaitEvent(idx->pe_stream[k][0], idx->pe_start, 0));
+  }
+  uint32_t pass = 0;
+  for (uint32_t start = 0; start < n; start += chunk, ++pass) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;
+    const int slot = two ? (int)(pass & 1) : 0;
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases1), reinterpret_cast<const uint64_t*>(d_offsets1) + start,
                   reinterpret_cast<const uint8_t*>(d_bases2), reinterpret_cast<const uint64_t*>(d_offsets2) + start, cnt,
                   nw, max_read_len, max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
-                  reinterpret_cast<unsigned long long*>(d_stats), w, stream);
+                  reinterpret_cast<unsigned long long*>(d_stats), w[slot], w[0].err, slot,
+                  two ? idx->pe_stream[slot][0] : stream);
     if (rc) return rc;
   }
+  if (two)
+    for (int k = 0; k < 2; ++k) {
+      WALT_HIP(hipEventRecord(idx->pe_done[k], idx->pe_stream[k][0]));
+      WALT_HIP(hipStreamWaitEvent(stream, idx->pe_done[k], 0));
+    }
   return WALT_OK;
 }
 
@@ -796,6 +825,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
   }
   PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k, max_len);
+  if ((rc = pe_streams(idx))) { cleanup(); return rc; }
   e = hipMemset(w.err, 0, 128 * sizeof(uint32_t));
   for (int m = 0; m < 2 && e == hipSuccess; ++m) e = hipMemset(w.shards[m], 0, kStatShardBytes);
   if (e != hipSuccess) {
@@ -807,7 +837,7 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases[0]), reinterpret_cast<const uint64_t*>(d_off[0]) + start,
                   reinterpret_cast<const uint8_t*>(d_bases[1]), reinterpret_cast<const uint64_t*>(d_off[1]) + start, cnt, nw,
                   max_len, max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
-                  reinterpret_cast<unsigned long long*>(d_stats), w, nullptr);
+                  reinterpret_cast<unsigned long long*>(d_stats), w, w.err, 0, nullptr);
     if (rc) break;
     if (hipDeviceSynchronize() != hipSuccess) { rc = fail(WALT_EHIP, "paired-end kernels failed"); break; }
     walt_candidate* rk[2] = {ranked1, ranked2};

@@ -713,6 +713,11 @@ using namespace walt;
 
 extern "C" {
 
+int walt_batch_check(const void* d_workspace, void* stream) {
+  if (!d_workspace) return fail(WALT_EINVAL, "walt_batch_check: bad argument");
+  return check_read_errors(d_workspace, reinterpret_cast<hipStream_t>(stream));
+}
+
 int walt_profile_enable(walt_index* idx, int on) {
   if (!idx) return fail(WALT_EINVAL, "null index");
   WALT_HIP(hipSetDevice(idx->device));
