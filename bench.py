@@ -426,7 +426,8 @@ def main():
     value = world * n * args.steps / elapsed
     if rank == 0:
         out = {
-            "metric": "mapped reads/sec (100 bp single-end, hg19-scale index, -m 6 -b 5000)",
+            "metric": "mapped reads/sec (%d bp single-end, hg19-scale index, -m %d -b %d)" % (
+                args.read_len, args.max_mismatches, args.bucket),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",

@@ -138,7 +138,7 @@ def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
 
 
 def test_gpu_long_reads_all_word_widths(wa, scratch):
-    """Reads of 300/600/1000 bp take the 32- and 64-word kernel instances."""
+    """Reads of 129..1000 bp take the 10-, 16-, 32- and 64-word kernel instances."""
     rng = random.Random(5)
     g = "".join(rng.choice("ACGT") for _ in range(20000))
     fa = os.path.join(scratch, "long.fa")
@@ -148,7 +148,7 @@ def test_gpu_long_reads_all_word_widths(wa, scratch):
     wa.makedb(fa, path, threads=2)
     db = refio.DbIndex(path)
     idx = wa.Index.open(path, device=0, strands=wa.STRANDS_CT)
-    for L in (129, 256, 257, 300, 512, 600, 998):
+    for L in (129, 150, 160, 161, 256, 257, 300, 512, 600, 998):
         reads = []
         for _ in range(64):
             p = rng.randrange(0, len(g) - L)

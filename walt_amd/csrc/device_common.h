@@ -48,10 +48,11 @@ constexpr uint32_t kG2PadWords = 96;  // slack behind the packed genome for wind
 
 inline unsigned grid_for(uint64_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
 
-// words per packed read for a maximum read length (template instances 7/8/16/32/64)
+// words per packed read for a maximum read length (template instances 7/8/10/16/32/64)
 inline int nw_for_len(uint32_t max_len) {
   if (max_len <= 112) return 7;  // 100 bp reads: 7 words, genome window of exactly two 16-byte loads
   if (max_len <= 128) return 8;
+  if (max_len <= 160) return 10;  // 150 bp reads: 10 words instead of 16 keeps three waves per SIMD
   if (max_len <= 256) return 16;
   if (max_len <= 512) return 32;
   if (max_len <= 1024) return 64;

@@ -340,7 +340,7 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
 }
 
 template <int NW>
-__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_pe_topk_dual(
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_pe_topk_dual(
     IndexView iv, const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
     uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, uint32_t top_k,
     const uint32_t* __restrict__ mask_table, Candidate* __restrict__ ranked, uint32_t* __restrict__ heap_n,
@@ -687,6 +687,7 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     switch (nw) {
       case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 10: rc = launch_pe_topk<10>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;

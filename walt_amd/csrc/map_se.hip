@@ -526,7 +526,7 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 
 // pass 1: every read of the batch, one per lane
 template <int NW, bool DIAG>
-__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : 1)) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
                                                     const uint64_t* __restrict__ offsets,
                                                     uint32_t* __restrict__ err,
                                                     uint32_t n, uint32_t strand_base,
@@ -683,6 +683,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   switch (nw) {
     case 7: rc = launch_map_se<7>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 8: rc = launch_map_se<8>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 10: rc = launch_map_se<10>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 16: rc = launch_map_se<16>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 32: rc = launch_map_se<32>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     default: rc = launch_map_se<64>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
