@@ -173,6 +173,12 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
  * files.  Byte-identical to the reference makedb for N-free FASTA. */
 int walt_makedb(const char* fasta_path, const char* out_dbindex_path, int threads);
 
+/* The same files from the GPU builder (walt_index_build_device + walt_index_write): seconds
+ * instead of hours at 3 Gbp.  Identical to the host builder except for the order of entries
+ * whose 60 compared characters are all equal (ascending position here, whatever std::sort
+ * leaves in the reference, reference.cpp:296-298); one N fill serves all four strands. */
+int walt_makedb_device(const char* fasta_path, const char* out_dbindex_path, int device);
+
 /* GPU builder: d_genome_ascii is the concatenated genome (upper-case ACGT, no N)
  * in HBM on `device`; builds the selected strand indexes there and leaves them
  * resident (BuildIndex, makedb.cpp:46-85).  Same result as the reference makedb

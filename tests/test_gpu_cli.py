@@ -189,3 +189,31 @@ def test_cli_pbat_is_the_mate_swapped_run_put_back_in_user_order(cli_index, scra
     a = _run_cli(os.path.join(scratch, "pbat_se_a"), ["-i", cli_index, "-o", "o.sam", "-A", "-r", ga, "-sam", "-a", "-u"])
     b = _run_cli(os.path.join(scratch, "pbat_se_p"), ["-i", cli_index, "-o", "o.sam", "-P", "-r", ga, "-sam", "-a", "-u"])
     assert a == b and len(a["o.sam"]) > 1000
+
+
+def test_cli_makedb_on_gpu_writes_files_the_reference_binary_maps_from(scratch):
+    """`makedb -g 0`: FASTA -> GPU builder -> .dbindex files.  The golden genome has entries whose 60 compared
+    characters tie, so the index may differ from the reference's in the order of those entries only: head,
+    genome and counter sections must be identical to the host builder's files, and both binaries must produce
+    the same SAM from the GPU-built files."""
+    fa = os.path.join(refio.GOLDEN, "g1.fa")
+    host, dev = os.path.join(scratch, "mk_host.dbindex"), os.path.join(scratch, "mk_dev.dbindex")
+    env = dict(os.environ, WALT_MAKEDB_SEED="1")
+    subprocess.run([MAKEDB_BIN, "-c", fa, "-o", host, "-t", "4"], check=True, env=env, stderr=subprocess.DEVNULL)
+    subprocess.run([MAKEDB_BIN, "-c", fa, "-o", dev, "-g", "0"], check=True, env=env, stderr=subprocess.DEVNULL)
+    assert open(host, "rb").read() == open(dev, "rb").read()
+    a, b = refio.DbIndex(host), refio.DbIndex(dev)
+    for s in range(4):
+        assert (a.genome[s] == b.genome[s]).all() and (a.counter[s] == b.counter[s]).all()
+        assert sorted(a.index[s].tolist()) == sorted(b.index[s].tolist())
+    if not os.path.exists(refio.REF_WALT):
+        pytest.skip("oracle/_ref/walt not built")
+    outs = []
+    for who, binary in (("gpu", WALT_BIN), ("ref", refio.REF_WALT)):
+        o = os.path.join(scratch, "mk_%s.sam" % who)
+        if os.path.exists(o):
+            os.remove(o)
+        subprocess.run([binary, "-i", dev, "-r", os.path.join(refio.GOLDEN, "se_ct.fastq"), "-o", o, "-sam", "-a", "-u"],
+                       check=True, stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        outs.append(open(o, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000

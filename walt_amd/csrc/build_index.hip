@@ -338,4 +338,34 @@ int walt_index_write(const walt_index* idx, const char* dbindex_path) {
   return write_index_head(dbindex_path, head);
 }
 
+// makedb on the GPU: FASTA -> resident index -> the five .dbindex files
+int walt_makedb_device(const char* fasta_path, const char* out_path, int device) {
+  if (!fasta_path || !out_path) return fail(WALT_EINVAL, "null path");
+  std::vector<std::string> names;
+  std::vector<uint32_t> lengths;
+  std::vector<uint8_t> seq;
+  int rc = read_fasta_genome(fasta_path, names, lengths, seq);
+  if (rc) return rc;
+  if (lengths.empty()) return fail(WALT_EFORMAT, "no sequence in " + std::string(fasta_path));
+  WALT_HIP(hipSetDevice(device));
+  void* d_genome = nullptr;
+  hipError_t e = hipMalloc(&d_genome, seq.size() + 16);
+  if (e != hipSuccess) return fail(WALT_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  if ((e = hipMemcpy(d_genome, seq.data(), seq.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+    hipFree(d_genome);
+    return fail(WALT_EHIP, std::string("hipMemcpy failed: ") + hipGetErrorString(e));
+  }
+  std::vector<uint8_t>().swap(seq);
+  std::vector<const char*> cn;
+  for (const std::string& s : names) cn.push_back(s.c_str());
+  walt_index* idx = nullptr;
+  rc = walt_index_build_device(d_genome, (uint32_t)lengths.size(), lengths.data(), cn.data(), device, WALT_STRANDS_ALL, -1,
+                               &idx);
+  hipFree(d_genome);
+  if (rc) return rc;
+  rc = walt_index_write(idx, out_path);
+  walt_index_close(idx);
+  return rc;
+}
+
 }  // extern "C"

@@ -26,6 +26,10 @@ struct IndexHead {
   uint32_t genome_len = 0;
   uint32_t max_index_size = 0;
 };
+// ReadGenome (reference.cpp:79-129) of a FASTA file or directory: names, lengths and the concatenated
+// upper-case sequence with non-ACGT characters replaced by rand()%4 (seeded like walt_makedb)
+int read_fasta_genome(const char* fasta_path, std::vector<std::string>& names, std::vector<uint32_t>& lengths,
+                      std::vector<uint8_t>& seq);
 int read_index_head(const std::string& path, IndexHead& head);
 int write_index_head(const std::string& path, const IndexHead& head);
 

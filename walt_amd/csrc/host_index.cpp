@@ -358,6 +358,22 @@ static int build_strand(HostGenome& g, int indicator, int threads, StrandFile& s
   return WALT_OK;
 }
 
+int read_fasta_genome(const char* fasta_path, std::vector<std::string>& names, std::vector<uint32_t>& lengths,
+                      std::vector<uint8_t>& seq) {
+  if (!fasta_path) return fail(WALT_EINVAL, "null path");
+  const char* seed_env = getenv("WALT_MAKEDB_SEED");
+  srand(seed_env ? (unsigned)atoi(seed_env) : (unsigned)time(NULL));
+  std::vector<std::string> files;
+  int rc = list_chrom_files(fasta_path, files);
+  if (rc) return rc;
+  HostGenome g;
+  if ((rc = read_genome(files, g))) return rc;
+  names.swap(g.names);
+  lengths.swap(g.lengths);
+  seq.swap(g.seq);
+  return WALT_OK;
+}
+
 }  // namespace walt
 
 using namespace walt;
