@@ -365,6 +365,71 @@ WALT_HD bool slot_binary_search(const StrandView& sv, uint32_t lo, uint32_t hi, 
   return true;
 }
 
+// The same narrowing for care chars >= 44 on a key-equal range of at most kLookupPos slots whose
+// genome positions are already in registers (the usual case for reads longer than ~134 bp: one
+// candidate).  lit_region would fetch, per character, the slot and then the genome word -- ten
+// dependent loads for five characters; here each candidate's two genome words holding chars
+// 44..seed_len-1 (at most 15 bases apart) are loaded at once and the reference's
+// LowerBound / UpperBound loops run on them in registers.  Same algorithm on the same data.
+// char p of candidate k (0..3) from its two-word genome window; scalars by value so that the
+// selects stay selects (a struct here was turned into an indexed load from scratch memory)
+WALT_HD int small_char(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint64_t b0, uint64_t b1, uint64_t b2,
+                       uint64_t b3, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint64_t genome_len,
+                       uint32_t k, uint32_t p) {
+  uint64_t wk = w3, bk = b3;
+  uint32_t pk = p3;
+  if (k == 2) { wk = w2; bk = b2; pk = p2; }
+  if (k == 1) { wk = w1; bk = b1; pk = p1; }
+  if (k == 0) { wk = w0; bk = b0; pk = p0; }
+  const uint64_t q = (uint64_t)pk + care_pos(p);
+  if (q >= genome_len) return -1;
+  return (int)((wk >> (2 * (uint32_t)(q - bk))) & 3u);
+}
+WALT_HD Region lit_region_small(const StrandView& sv, const uint32_t* care, uint32_t seed_len, uint32_t a,
+                                uint32_t size, uint32_t* pos /*[kLookupPos], in/out*/, uint32_t& npos) {
+  const uint32_t pc = care_pos(kKeyWeight + kKeyChars);
+  const uint32_t p0 = pos[0];
+  const uint32_t p1 = size > 1 ? pos[1] : p0;
+  const uint32_t p2 = size > 2 ? pos[2] : p0;
+  const uint32_t p3 = size > 3 ? pos[3] : p0;
+  // g2 carries kG2PadWords of slack behind the genome, so the two-word window is always readable
+  const uint64_t x0 = ((uint64_t)p0 + pc) >> 4, x1 = ((uint64_t)p1 + pc) >> 4;
+  const uint64_t x2 = ((uint64_t)p2 + pc) >> 4, x3 = ((uint64_t)p3 + pc) >> 4;
+  const uint32_t a0 = sv.g2[x0], a1 = sv.g2[x0 + 1], c0 = sv.g2[x1], c1 = sv.g2[x1 + 1];
+  const uint32_t d0 = sv.g2[x2], d1 = sv.g2[x2 + 1], e0 = sv.g2[x3], e1 = sv.g2[x3 + 1];
+  const uint64_t w0 = (uint64_t)a0 | ((uint64_t)a1 << 32), b0 = x0 << 4;
+  const uint64_t w1 = (uint64_t)c0 | ((uint64_t)c1 << 32), b1 = x1 << 4;
+  const uint64_t w2 = (uint64_t)d0 | ((uint64_t)d1 << 32), b2 = x2 << 4;
+  const uint64_t w3 = (uint64_t)e0 | ((uint64_t)e1 << 32), b3 = x3 << 4;
+  const uint64_t glen = sv.genome_len;
+  uint32_t l = 0, u = size - 1;
+  for (uint32_t p = kKeyWeight + kKeyChars; p < seed_len; ++p) {
+    const int ch = (int)care_char(care, p);
+    uint32_t lo = l, hi = u;
+    while (lo < hi) {  // LowerBound, mapping.cpp:166-180
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (small_char(w0, w1, w2, w3, b0, b1, b2, b3, p0, p1, p2, p3, glen, mid, p) >= ch) hi = mid; else lo = mid + 1;
+    }
+    l = lo;
+    hi = u;
+    while (lo < hi) {  // UpperBound, mapping.cpp:182-196
+      const uint32_t mid = lo + (hi - lo + 1) / 2;
+      if (small_char(w0, w1, w2, w3, b0, b1, b2, b3, p0, p1, p2, p3, glen, mid, p) <= ch) lo = mid; else hi = mid - 1;
+    }
+    u = lo;
+    if (l == u && ch != small_char(w0, w1, w2, w3, b0, b1, b2, b3, p0, p1, p2, p3, glen, l, p)) { npos = 0; return empty_region(); }
+  }
+  if (l > u) { npos = 0; return empty_region(); }
+  // surviving slots keep their positions: the verification does not have to load them again
+  const uint32_t q0 = l == 0 ? p0 : l == 1 ? p1 : l == 2 ? p2 : p3;
+  const uint32_t q1 = l == 0 ? p1 : l == 1 ? p2 : p3;
+  const uint32_t q2 = l == 0 ? p2 : p3;
+  const uint32_t q3 = p3;
+  pos[0] = q0; pos[1] = q1; pos[2] = q2; pos[3] = q3;
+  npos = u - l + 1;
+  Region r; r.l = a + l; r.u = a + u; return r;
+}
+
 struct Lookup {
   Region reg;
   uint32_t npos;              // pos[0..npos) are the genome positions of slots reg.l, reg.l+1, ...
@@ -429,8 +494,13 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     if (!slot_binary_search(sv, lo, hi, T, M, a, u)) return;
   }
   if (n > kKeyChars) {
-    out.npos = 0;
-    out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+    const uint32_t size = u - a + 1;
+    if (size <= kLookupPos && out.npos == size) {
+      out.reg = lit_region_small(sv, care, seed_len, a, size, out.pos, out.npos);
+    } else {
+      out.npos = 0;
+      out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+    }
     return;
   }
   out.reg.l = a; out.reg.u = u;

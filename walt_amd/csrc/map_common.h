@@ -275,8 +275,13 @@ __device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p
   }
 }
 // region + leading candidate positions from a probed slot (core.h seed_lookup_ex, scan branch)
+// LONG_SEED: instances for reads above 128 bp, whose seeds can exceed the 32 key characters
+// tail_check: set when a single key-equal candidate still has to pass the care characters behind the key
+// (>= 44); the caller tests them on the genome words its verification loads anyway (tail_care_ok).
+template <bool LONG_SEED>
 __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotProbe& p, const uint32_t* care,
-                                              uint32_t seed_len, Lookup& out) {
+                                              uint32_t seed_len, Lookup& out, bool& tail_check) {
+  tail_check = false;
   out.npos = 0;
   out.reg = empty_region();
   if (p.ne == 0) return;
@@ -308,11 +313,37 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
     if (!slot_binary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
   }
   if (n > kKeyChars) {
-    out.npos = 0;
-    out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+    const uint32_t size = u - a + 1;
+    if (LONG_SEED && size == 1 && out.npos == 1) {
+      // IndexRegion on one slot (mapping.cpp:206-211): it survives iff every remaining care char matches
+      tail_check = true;
+      out.reg.l = a; out.reg.u = a;
+    } else if (LONG_SEED && size <= kLookupPos && out.npos == size) {
+      out.reg = lit_region_small(sv, care, seed_len, a, size, out.pos, out.npos);
+    } else {
+      out.npos = 0;
+      out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+    }
     return;
   }
   out.reg.l = a; out.reg.u = u;
+}
+
+// care chars [44, seed_len) of the slot at slot_pos against the read's (ent_char semantics: a position at or
+// beyond the genome end matches nothing).  The two words read here lie inside the window that
+// verify_nobranch loads for the same candidate, so this costs no extra memory round trip.
+__device__ __forceinline__ bool tail_care_ok(const StrandView& sv, uint32_t slot_pos, const uint32_t* care,
+                                             uint32_t seed_len) {
+  const uint64_t q0 = (uint64_t)slot_pos + care_pos(kKeyWeight + kKeyChars);
+  const uint64_t w = q0 >> 4;
+  const uint64_t win = (uint64_t)sv.g2[w] | ((uint64_t)sv.g2[w + 1] << 32);
+  bool ok = true;
+  for (uint32_t p = kKeyWeight + kKeyChars; p < seed_len; ++p) {
+    const uint64_t q = (uint64_t)slot_pos + care_pos(p);
+    const uint32_t c = (uint32_t)((win >> (2 * (uint32_t)(q - (w << 4)))) & 3u);
+    ok = ok && q < sv.genome_len && c == care_char(care, p);
+  }
+  return ok;
 }
 
 // branch-free candidate check: the genome window is always loaded (from position

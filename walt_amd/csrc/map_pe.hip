@@ -269,8 +269,9 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     probe_entries(svp, pp);
     probe_entries(svm, pm);
     Lookup lp, lm;
-    probe_resolve(svp, pp, care, lr.repeats, lp);
-    probe_resolve(svm, pm, care, lr.repeats, lm);
+    bool tail_p, tail_m;
+    probe_resolve<(NW > 8)>(svp, pp, care, lr.repeats, lp, tail_p);
+    probe_resolve<(NW > 8)>(svm, pm, care, lr.repeats, lm, tail_m);
     uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
     uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
     n_probe += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
@@ -295,6 +296,12 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
       uint32_t gp_p, gp_m, mm_p, mm_m;
       verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
       verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+      if (NW > 8) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
+        // inactive lanes carry no valid position: read from 0 like verify_nobranch does
+        const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, lr.repeats), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, lr.repeats);
+        ok_p = ok_p && (!tail_p || t_p);
+        ok_m = ok_m && (!tail_m || t_m);
+      }
       if (ok_p) {
         ++n_verified;
         if (mm_p <= max_mm) {  // paired.cpp:192-195
