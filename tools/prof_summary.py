@@ -42,6 +42,14 @@ if rd:
     meta = {"hbm_bytes_per_launch": rd * 128 + wr * 1024, "read_requests_128B": rd, "write_kb": wr,
             "kernels": [nm for nm in vals if "k_map_se" in nm], "reads_per_launch": 50000000, "genome_bp": 3095677412,
             "source": out}
+    # keep the per-read algorithmic counters bench.py's N>1 runs rely on (profiles/traffic.json)
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    try:
+        old = json.load(open(here))
+        if "algorithmic_per_read" in old:
+            meta["algorithmic_per_read"] = old["algorithmic_per_read"]
+    except (OSError, ValueError):
+        pass
     with open(os.path.join(out, "traffic.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("traffic.json:", json.dumps(meta))
