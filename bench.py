@@ -44,9 +44,12 @@ def log(msg):
         print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def make_genome(torch, dev, scale, seed):
+def make_genome(torch, dev, scale, seed, contigs=0):
     """ASCII genome on the GPU: iid bases + repeat families (deterministic per seed)."""
     lens = [max(1000, int(l * scale)) for l in HG19]
+    if contigs:  # same bases cut into equal contigs: an assembly of many scaffolds (chromosome-end handling)
+        total = sum(lens)
+        lens = [total // contigs] * (contigs - 1) + [total - (total // contigs) * (contigs - 1)]
     L = sum(lens)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -311,6 +314,7 @@ def main():
     ap.add_argument("--max-mismatches", type=int, default=6)
     ap.add_argument("--bucket", type=int, default=5000)
     ap.add_argument("--dir-bits", type=int, default=-1)
+    ap.add_argument("--contigs", type=int, default=0, help="cut the genome into this many equal contigs (default: hg19's 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["se", "pe"], default="se", help="se = configs[1] (headline), pe = configs[2]")
     ap.add_argument("--top-k", type=int, default=50)
@@ -342,7 +346,8 @@ def main():
 
     scale = args.genome_mbp * 1e6 / sum(HG19)
     t0 = time.perf_counter()
-    genome_ascii, lens = make_genome(torch, dev, scale, seed=2)
+    genome_ascii, lens = make_genome(torch, dev, scale, seed=2, contigs=args.contigs)
+    names = HG19_NAMES if not args.contigs else ["ctg%d" % i for i in range(len(lens))]
     torch.cuda.synchronize()
     t_genome = time.perf_counter() - t0
     log("genome: %d bp in %d chromosomes (%.1f s)" % (sum(lens), len(lens), t_genome))
@@ -354,7 +359,7 @@ def main():
             dist.destroy_process_group()
         return
     t0 = time.perf_counter()
-    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, HG19_NAMES, device=local,
+    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local,
                                       strands=walt_amd.STRANDS_CT, dir_bits=args.dir_bits)
     t_index = time.perf_counter() - t0
     log("index: CT00 %d + CT01 %d entries, dir_bits %d, %.1f GB in HBM, outliers %d/%d, bad buckets %d/%d (%.1f s)" % (

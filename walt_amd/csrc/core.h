@@ -76,7 +76,8 @@ struct StrandView {
   uint32_t genome_len;
   uint32_t ga;  // 0: C->T strand (letters A,G,T)  1: G->A strand (letters A,C,T)
   uint32_t n_outl;
-  const uint32_t* bloom;  // kBloomBits-bit Bloom filter over the buckets that hold outliers / are BAD
+  const uint64_t* bloom;  // blocked Bloom filter (64-bit blocks) over the probes that can be dangerous
+  uint32_t bloom_mask;    // number of blocks - 1 (a power of two, sized by the number of keys)
   const struct Outlier* outl;  // chromosome-end entries, sorted by bucket (see probe_is_dangerous)
 };
 
@@ -262,42 +263,51 @@ WALT_HD uint64_t key_mask(uint32_t nk) { return nk >= 32 ? ~0ull : ~(~0ull >> (2
 
 WALT_HD bool bucket_is_bad(const StrandView& sv, uint32_t h) { return (sv.bad[h >> 5] >> (h & 31)) & 1u; }
 
-// Pass 1 of the mapping kernels must decide "might this probe be dangerous?"
-// without any extra memory round trip (a slow path taken by even 1 % of the lanes
-// stalls nearly every wavefront), so it tests a Bloom filter held in LDS and
-// defers the read on a hit; the exact test (probe_is_dangerous) runs in pass 2.
-// Filter key = (bucket, care characters 12 and 13): an outlier with q >= 14 inserts
-// its own pair, q == 13 inserts every second character, q == 12 (and a BAD bucket)
-// every pair -- so only probes that agree with an outlier on the characters it
-// really has can hit.
-constexpr uint32_t kBloomBits = 1u << 16;  // 8 KB of LDS per strand
-constexpr uint32_t kBloomWords = kBloomBits / 32;
-WALT_HD uint32_t bloom_key(uint32_t h, uint32_t c12, uint32_t c13) { return (h << 4) | (c12 << 2) | c13; }
-WALT_HD uint32_t bloom_hash(uint32_t key, uint32_t i) {
-  const uint32_t m = i == 0 ? 0x9E3779B1u : i == 1 ? 0x85EBCA6Bu : 0xC2B2AE35u;
-  uint32_t x = (key + i) * m;
+// Pass 1 of the mapping kernels must decide "might this probe be dangerous?" without an extra
+// DEPENDENT memory round trip (a slow path taken by even 1 % of the lanes stalls nearly every
+// wavefront).  It tests a blocked Bloom filter: one 64-bit block per key, four bits in it, so the
+// test is ONE 8-byte load that is issued together with the directory loads of the probe and hits L2
+// (the filter is sized at >= 128 bits per key: 64 KB for hg19's 24 chromosomes, a few MB for an
+// assembly of thousands of contigs -- an LDS-resident filter of fixed size saturates there and sends
+// every read to the slow pass).  On a hit the read is deferred; the exact test
+// (probe_is_dangerous) runs in pass 2.
+// Filter key = (bucket, care characters 12..15) = the first 16 care characters = care[0]: an
+// outlier with q >= 16 inserts its own four characters; one with q < 16 inserts every value of the
+// characters from q on (a dangerous probe agrees with it on the characters before q, which are real
+// on both sides; whatever the probe holds from q on, zero padding of a short seed included, is
+// among the inserted values); a BAD bucket inserts all 256.  Two characters were not enough: in the
+// 3-letter, T-heavy converted alphabet 1 % of the reads shared (bucket, 2 chars) with some
+// chromosome end.
+constexpr uint32_t kBloomMinBlocks = 1u << 10, kBloomMaxBlocks = 1u << 20;  // 8 KB .. 8 MB
+WALT_HD uint32_t bloom_blocks_for(uint64_t n_keys) {  // >= 2 blocks (128 bits) per key, power of two
+  uint64_t want = 2 * n_keys;
+  uint32_t b = kBloomMinBlocks;
+  while (b < want && b < kBloomMaxBlocks) b <<= 1;
+  return b;
+}
+constexpr uint32_t kBloomChars = 4;  // care characters 12..15 in the key
+WALT_HD uint32_t bloom_key(uint32_t h, uint32_t chars12_15) { return (h << 8) | chars12_15; }
+WALT_HD uint32_t bloom_block(uint32_t key, uint32_t mask) {
+  uint32_t x = key * 0x9E3779B1u;
   x ^= x >> 15;
   x *= 0x2C1B3C6Du;
-  return x >> 16;
+  x ^= x >> 13;
+  return x & mask;
 }
-WALT_HD bool bloom_maybe(const uint32_t* bloom, uint32_t key) {
-  uint32_t hit = 1;
-  for (uint32_t i = 0; i < 3; ++i) {
-    const uint32_t a = bloom_hash(key, i);
-    hit &= bloom[a >> 5] >> (a & 31);
-  }
-  return (hit & 1u) != 0;
+WALT_HD uint64_t bloom_bits(uint32_t key) {
+  uint32_t y = (key ^ 0x85EBCA6Bu) * 0xC2B2AE35u;
+  y ^= y >> 16;
+  y *= 0x27D4EB2Fu;
+  y ^= y >> 15;
+  return (1ull << (y & 63)) | (1ull << ((y >> 6) & 63)) | (1ull << ((y >> 12) & 63)) | (1ull << ((y >> 18) & 63));
 }
-WALT_HD void bloom_insert(uint32_t* bloom, uint32_t key) {
-  for (uint32_t i = 0; i < 3; ++i) {
-    const uint32_t a = bloom_hash(key, i);
-    bloom[a >> 5] |= 1u << (a & 31);
-  }
+WALT_HD bool bloom_hit(uint64_t block, uint32_t key) {
+  const uint64_t b = bloom_bits(key);
+  return (block & b) == b;
 }
-// key of a probe: bucket and care characters 12, 13 of its (zero padded) care string
-WALT_HD uint32_t bloom_key_of_care(const uint32_t* care) {
-  return bloom_key(care[0] >> 8, (care[0] >> 6) & 3u, (care[0] >> 4) & 3u);
-}
+WALT_HD void bloom_insert(uint64_t* bloom, uint32_t mask, uint32_t key) { bloom[bloom_block(key, mask)] |= bloom_bits(key); }
+// key of a probe: bucket and care characters 12..15 of its (zero padded) care string
+WALT_HD uint32_t bloom_key_of_care(const uint32_t* care) { return care[0]; }
 WALT_HD uint64_t key_mask(uint32_t nk);
 WALT_HD uint64_t target_key(const uint32_t* care);
 

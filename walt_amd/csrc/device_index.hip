@@ -187,11 +187,11 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   const uint32_t Bd = idx->view.dir_bits;
   const uint32_t slots = idx->view.dir_slots;
   StrandView& sv = idx->view.s[strand];
-  uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr, *bloom = nullptr;
+  uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr;
+  uint64_t* bloom = nullptr;
+  uint32_t bloom_blocks = 0;
   Ent* ent = nullptr;
   int rc;
-  if ((rc = dev_alloc(idx, &bloom, kBloomWords))) return rc;
-  WALT_HIP(hipMemsetAsync(bloom, 0, kBloomWords * 4, stream));
   if ((rc = dev_alloc(idx, &cnt, (uint64_t)kNumBuckets + 1))) return rc;
   if ((rc = dev_alloc(idx, &bad, kNumBuckets / 32))) return rc;
   if ((rc = dev_alloc(idx, &dir, (uint64_t)slots + 1))) return rc;
@@ -263,7 +263,6 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   if (herr[3] > outl_cap) return fail(WALT_EFORMAT, "more chromosome-end entries than a makedb index can hold");
   {
     std::vector<Outlier> ho(n_outl);
-    std::vector<uint32_t> hb(kBloomWords, 0);
     if (n_outl) WALT_HIP(hipMemcpy(ho.data(), outl, n_outl * sizeof(Outlier), hipMemcpyDeviceToHost));
     std::sort(ho.begin(), ho.end(), [](const Outlier& x, const Outlier& y) {
       if (x.h != y.h) return x.h < y.h;
@@ -271,28 +270,36 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       if (x.key_hi != y.key_hi) return x.key_hi < y.key_hi;
       return x.key_lo < y.key_lo;
     });
+    // filter keys: see core.h; the filter is sized by their number
+    std::vector<uint32_t> keys;
     for (const Outlier& o : ho) {
-      const uint32_t c12 = o.key_hi >> 30, c13 = (o.key_hi >> 28) & 3u;
-      for (uint32_t a = 0; a < 4; ++a)
-        for (uint32_t b = 0; b < 4; ++b)
-          if ((o.q <= kKeyWeight || a == c12) && (o.q <= kKeyWeight + 1 || b == c13)) bloom_insert(hb.data(), bloom_key(o.h, a, b));
+      const uint32_t own = o.key_hi >> (32 - 2 * kBloomChars);  // care characters 12..15, MSB first
+      // characters from q on take every value (q == 12 + j: the low 2 * (kBloomChars - j) bits are free)
+      const uint32_t real = o.q <= kKeyWeight ? 0u : (o.q - kKeyWeight < kBloomChars ? o.q - kKeyWeight : kBloomChars);
+      const uint32_t free_bits = 2 * (kBloomChars - real);
+      const uint32_t fixed = free_bits >= 8 ? 0u : (own >> free_bits) << free_bits;
+      for (uint32_t v = 0; v < (1u << free_bits); ++v) keys.push_back(bloom_key(o.h, fixed | v));
     }
     if (nbad) {  // buckets with unexplained disorder: every probe into them is dangerous
       std::vector<uint32_t> bm(kNumBuckets / 32);
       WALT_HIP(hipMemcpy(bm.data(), bad, kNumBuckets / 8, hipMemcpyDeviceToHost));
       for (uint32_t w = 0; w < kNumBuckets / 32; ++w)
-        for (uint32_t bit = 0; bm[w] >> bit; ++bit)
+        for (uint32_t bit = 0; bit < 32; ++bit)
           if ((bm[w] >> bit) & 1u)
-            for (uint32_t ab = 0; ab < 16; ++ab) bloom_insert(hb.data(), bloom_key(w * 32 + bit, ab >> 2, ab & 3u));
+            for (uint32_t v = 0; v < (1u << (2 * kBloomChars)); ++v) keys.push_back(bloom_key(w * 32 + bit, v));
     }
+    bloom_blocks = bloom_blocks_for(keys.size());
+    std::vector<uint64_t> hb(bloom_blocks, 0);
+    for (uint32_t k : keys) bloom_insert(hb.data(), bloom_blocks - 1, k);
+    if ((rc = dev_alloc(idx, &bloom, (uint64_t)bloom_blocks))) return rc;
     if (n_outl) WALT_HIP(hipMemcpy(outl, ho.data(), n_outl * sizeof(Outlier), hipMemcpyHostToDevice));
-    WALT_HIP(hipMemcpy(bloom, hb.data(), kBloomWords * 4, hipMemcpyHostToDevice));
+    WALT_HIP(hipMemcpy(bloom, hb.data(), (size_t)bloom_blocks * 8, hipMemcpyHostToDevice));
   }
   idx->bad_buckets[strand] = nbad;
   idx->outliers[strand] = n_outl;
   sv.outl = outl; sv.n_outl = n_outl;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
-  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom;
+  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1;
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }

@@ -16,7 +16,6 @@ constexpr uint32_t kSmallRegion = 4;   // regions up to this size are verified b
 struct BlockShared {
   uint32_t mask_table[kMaskTableWords];
   uint32_t start_index[kLdsChroms + 1];
-  uint32_t bloom[2][kBloomWords];  // BAD-bucket filters of the two strands this launch maps against
   uint16_t pcode4[256];            // prefix code of 4 care chars: bits | len << 8 (core.h pcode_*)
 };
 
@@ -26,10 +25,6 @@ __device__ __forceinline__ const uint32_t* block_prologue(BlockShared& sh, const
                                                           const uint32_t* __restrict__ mask_table,
                                                           uint32_t strand_base) {
   for (uint32_t i = threadIdx.x; i < kMaskTableWords; i += blockDim.x) sh.mask_table[i] = mask_table[i];
-  for (uint32_t fi = 0; fi < 2; ++fi) {
-    const uint32_t* __restrict__ bl = iv.s[strand_base + fi].bloom;
-    for (uint32_t i = threadIdx.x; i < kBloomWords; i += blockDim.x) sh.bloom[fi][i] = bl[i];
-  }
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {  // 4 chars, first char in bits 7..6
     uint32_t bits = 0, len = 0;
     for (uint32_t k = 0; k < 4; ++k) {

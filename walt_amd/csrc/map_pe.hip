@@ -96,7 +96,8 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         uint32_t care[kCareWords];
         uint32_t slot, span;
         seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
-        if (!LITERAL && bloom_maybe(sh.bloom[fi], bloom_key_of_care(care))) {
+        const uint32_t bk = bloom_key_of_care(care);
+        if (!LITERAL && bloom_hit(sv.bloom[bloom_block(bk, sv.bloom_mask)], bk)) {
           deferred = true;
           mappable = false;
           defer_iter = fi * 3 + seed_i;
@@ -252,18 +253,22 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     uint32_t care[kCareWords] = {0, 0, 0, 0};
     uint32_t slot = 0, span = 0;
     if (need) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
-    const bool bad_p = need && bloom_maybe(sh.bloom[0], bloom_key_of_care(care));
-    const bool bad_m = need && bloom_maybe(sh.bloom[1], bloom_key_of_care(care));
+    // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
+    const uint32_t bkey = bloom_key_of_care(care);
+    const uint64_t bw_p = svp.bloom[need ? bloom_block(bkey, svp.bloom_mask) : 0u];
+    const uint64_t bw_m = svm.bloom[need ? bloom_block(bkey, svm.bloom_mask) : 0u];
+    SlotProbe pp, pm;
+    uint32_t hi_p, hi_m;
+    probe_issue(svp, need, slot, span, pp.lo, hi_p);
+    probe_issue(svm, need, slot, span, pm.lo, hi_m);
+    const bool bad_p = need && bloom_hit(bw_p, bkey);
+    const bool bad_m = need && bloom_hit(bw_m, bkey);
     if (bad_p || bad_m) {
       deferred = true;
       mappable = false;
       need = false;
       defer_iter = seed_i + (bad_p ? 0u : 3u);
     }
-    SlotProbe pp, pm;
-    uint32_t hi_p, hi_m;
-    probe_issue(svp, need, slot, span, pp.lo, hi_p);
-    probe_issue(svm, need, slot, span, pm.lo, hi_m);
     pp.ne = (need && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
     pm.ne = (need && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
     probe_entries(svp, pp);

@@ -192,7 +192,10 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         if (act) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
         stamp(st, 1);
         bool is_bad = false;
-        if (act && !LITERAL) is_bad = bloom_maybe(sh.bloom[fi], bloom_key_of_care(care));
+        if (act && !LITERAL) {
+          const uint32_t bk = bloom_key_of_care(care);
+          is_bad = bloom_hit(sv.bloom[bloom_block(bk, sv.bloom_mask)], bk);
+        }
         stamp(st, 2);
         if (act) {
           if (is_bad) {
@@ -326,8 +329,16 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     uint32_t slot = 0, span = 0;
     if (need_p || need_m) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
     stamp(st, 1);
-    const bool bad_p = need_p && bloom_maybe(sh.bloom[0], bloom_key_of_care(care));
-    const bool bad_m = need_m && bloom_maybe(sh.bloom[1], bloom_key_of_care(care));
+    // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
+    const uint32_t bkey = bloom_key_of_care(care);
+    const uint64_t bw_p = svp.bloom[need_p ? bloom_block(bkey, svp.bloom_mask) : 0u];
+    const uint64_t bw_m = svm.bloom[need_m ? bloom_block(bkey, svm.bloom_mask) : 0u];
+    SlotProbe pp, pm;
+    uint32_t hi_p, hi_m;
+    probe_issue(svp, need_p, slot, span, pp.lo, hi_p);
+    probe_issue(svm, need_m, slot, span, pm.lo, hi_m);
+    const bool bad_p = need_p && bloom_hit(bw_p, bkey);
+    const bool bad_m = need_m && bloom_hit(bw_m, bkey);
     if (bad_p || bad_m) {
       deferred = true;
       mappable = false;
@@ -335,12 +346,6 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       defer_iter = seed_i + (bad_p ? 0u : 3u);
     }
     stamp(st, 2);
-
-    // directory pairs of both strands, then both slots' entries: independent loads
-    SlotProbe pp, pm;
-    uint32_t hi_p, hi_m;
-    probe_issue(svp, need_p, slot, span, pp.lo, hi_p);
-    probe_issue(svm, need_m, slot, span, pm.lo, hi_m);
     pp.ne = (need_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
     pm.ne = (need_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
     if (ablate & 2u) pp.ne = pm.ne = 0;
