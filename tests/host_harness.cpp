@@ -22,6 +22,7 @@ struct HStrand {
   std::vector<uint32_t> g2, cnt, bad, dir;
   std::vector<Ent> ent;
   std::vector<Outlier> outl;
+  std::vector<uint32_t> outl_dir;
   StrandView view;
 };
 struct HIndex {
@@ -118,7 +119,9 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
     if (s.dir[k - 1] < s.dir[k]) s.dir[k] = s.dir[k - 1];
   s.view.g2 = s.g2.data(); s.view.cnt = s.cnt.data(); s.view.bad = s.bad.data(); s.view.dir = s.dir.data();
   s.view.ent = s.ent.data(); s.view.index_size = index_size; s.view.genome_len = genome_len; s.view.ga = ga;
-  s.view.bloom = nullptr; s.view.outl = s.outl.data(); s.view.n_outl = (uint32_t)s.outl.size();
+  s.view.bloom = nullptr; s.view.bloom_mask = 0; s.view.outl = s.outl.data(); s.view.n_outl = (uint32_t)s.outl.size();
+  s.view.outl_dir_mask = build_outlier_dir(s.outl.data(), s.view.n_outl, s.outl_dir) - 1;
+  s.view.outl_dir = s.outl_dir.data();
   h->view.s[strand] = s.view;
   h->view.start_index = h->start.data();
   h->present[strand] = true;

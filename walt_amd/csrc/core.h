@@ -79,6 +79,8 @@ struct StrandView {
   const uint64_t* bloom;  // blocked Bloom filter (64-bit blocks) over the probes that can be dangerous
   uint32_t bloom_mask;    // number of blocks - 1 (a power of two, sized by the number of keys)
   const struct Outlier* outl;  // chromosome-end entries, sorted by bucket (see probe_is_dangerous)
+  const uint32_t* outl_dir;    // open-addressing table bucket -> first outlier: pairs {bucket + 1 (0 = free), index}
+  uint32_t outl_dir_mask;      // pairs - 1 (power of two); outl_dir == nullptr: binary search
 };
 
 // An index entry whose care positions run over the end of its chromosome before
@@ -312,13 +314,28 @@ WALT_HD uint64_t key_mask(uint32_t nk);
 WALT_HD uint64_t target_key(const uint32_t* care);
 
 // Does this probe have to take the literal LowerBound/UpperBound search?
+WALT_HD uint32_t outl_dir_hash(uint32_t h) {
+  uint32_t x = h * 0x9E3779B1u;
+  return x ^ (x >> 15);
+}
 WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
   const uint32_t h = care[0] >> 8;
   if (bucket_is_bad(sv, h)) return true;
   uint32_t lo = 0, hi = sv.n_outl;  // first outlier of bucket h
-  while (lo < hi) {
-    uint32_t mid = lo + ((hi - lo) >> 1);
-    if (sv.outl[mid].h < h) lo = mid + 1; else hi = mid;
+  if (sv.outl_dir) {
+    // one or two loads instead of log2(n_outl) dependent ones (this test runs for every probe of pass 2)
+    uint32_t slot = outl_dir_hash(h) & sv.outl_dir_mask;
+    for (;;) {
+      const uint32_t tag = sv.outl_dir[2 * slot];
+      if (tag == 0) return false;  // no outlier in this bucket
+      if (tag == h + 1) { lo = sv.outl_dir[2 * slot + 1]; break; }
+      slot = (slot + 1) & sv.outl_dir_mask;
+    }
+  } else {
+    while (lo < hi) {
+      uint32_t mid = lo + ((hi - lo) >> 1);
+      if (sv.outl[mid].h < h) lo = mid + 1; else hi = mid;
+    }
   }
   const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
   const uint64_t T = target_key(care);

@@ -294,6 +294,13 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     if ((rc = dev_alloc(idx, &bloom, (uint64_t)bloom_blocks))) return rc;
     if (n_outl) WALT_HIP(hipMemcpy(outl, ho.data(), n_outl * sizeof(Outlier), hipMemcpyHostToDevice));
     WALT_HIP(hipMemcpy(bloom, hb.data(), (size_t)bloom_blocks * 8, hipMemcpyHostToDevice));
+    std::vector<uint32_t> od;
+    const uint32_t pairs = build_outlier_dir(ho.data(), n_outl, od);
+    uint32_t* d_od = nullptr;
+    if ((rc = dev_alloc(idx, &d_od, (uint64_t)od.size()))) return rc;
+    WALT_HIP(hipMemcpy(d_od, od.data(), od.size() * 4, hipMemcpyHostToDevice));
+    sv.outl_dir = d_od;
+    sv.outl_dir_mask = pairs - 1;
   }
   idx->bad_buckets[strand] = nbad;
   idx->outliers[strand] = n_outl;

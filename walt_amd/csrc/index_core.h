@@ -102,5 +102,24 @@ WALT_HD bool pack_read(const uint8_t* bases, uint32_t len, uint32_t ga, uint32_t
   return ok;
 }
 
+// Host side: the bucket -> first-outlier table of StrandView::outl_dir for outliers sorted by bucket.
+// Returns the number of {tag, index} pairs (a power of two, at most half full).
+template <class Vec>
+inline uint32_t build_outlier_dir(const Outlier* outl, uint32_t n_outl, Vec& dir) {
+  uint32_t distinct = 0;
+  for (uint32_t i = 0; i < n_outl; ++i) distinct += (i == 0 || outl[i].h != outl[i - 1].h) ? 1u : 0u;
+  uint32_t pairs = 16;
+  while (pairs < 2 * distinct) pairs <<= 1;
+  dir.assign((size_t)pairs * 2, 0u);
+  for (uint32_t i = 0; i < n_outl; ++i) {
+    if (i && outl[i].h == outl[i - 1].h) continue;
+    uint32_t slot = outl_dir_hash(outl[i].h) & (pairs - 1);
+    while (dir[2 * slot]) slot = (slot + 1) & (pairs - 1);
+    dir[2 * slot] = outl[i].h + 1;
+    dir[2 * slot + 1] = i;
+  }
+  return pairs;
+}
+
 }  // namespace walt
 #endif  // WALT_AMD_INDEX_CORE_H_
