@@ -254,19 +254,22 @@ struct SlotProbe {
 // dir[slot-1 .. slot]; short seeds (span > 1) fetch the far end separately.
 __device__ __forceinline__ void probe_issue(const StrandView& sv, bool need, uint32_t slot, uint32_t span,
                                             uint32_t& lo, uint32_t& hi) {
-  const uint32_t s0 = need ? slot : 1u, sp = need ? span : 1u;  // slot >= 1 whenever a seed exists
-  const uint32_t* p = sv.dir + (s0 - 1);
-  uint32_t pair[2];
-  __builtin_memcpy(pair, p, 8);
-  hi = pair[0];
-  lo = pair[1];
-  if (sp != 1) hi = sv.dir[s0 - sp];
+  hi = lo = 0;
+  if (need) {  // idle lanes issue no load (see verify_nobranch)
+    const uint32_t* p = sv.dir + (slot - 1);  // slot >= 1 whenever a seed exists
+    uint32_t pair[2];
+    __builtin_memcpy(pair, p, 8);
+    hi = pair[0];
+    lo = pair[1];
+    if (span != 1) hi = sv.dir[slot - span];
+  }
 }
 __device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p) {
 #pragma unroll
   for (uint32_t j = 0; j < kScan; ++j) {
-    const uint32_t k = p.ne ? p.lo + (j < p.ne ? j : p.ne - 1) : 0u;  // ent[] has index_size + 1 slots
-    p.e[j] = sv.ent[k];
+    Ent z; z.key_hi = z.key_lo = z.pos = 0;
+    p.e[j] = z;
+    if (j < p.ne) p.e[j] = sv.ent[p.lo + j];
   }
 }
 // region + leading candidate positions from a probed slot (core.h seed_lookup_ex, scan branch)
@@ -285,7 +288,7 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
   const uint64_t M = key_mask(nk);
   const uint64_t T = target_key(care) & M;
   uint32_t a, u;
-  if (p.ne <= kScan) {
+  if (p.ne <= kScanMax) {
     uint32_t n_lt = 0, n_eq = 0;
 #pragma unroll
     for (uint32_t j = 0; j < kScan; ++j) {
@@ -293,10 +296,6 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
       n_lt += (j < p.ne && k < T) ? 1u : 0u;
       n_eq += (j < p.ne && k == T) ? 1u : 0u;
     }
-    if (n_eq == 0) return;
-    a = p.lo + n_lt;
-    u = a + n_eq - 1;
-    out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
 #pragma unroll
     for (uint32_t i = 0; i < kLookupPos; ++i) {
       uint32_t q = 0;
@@ -304,6 +303,11 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
       for (uint32_t j = 0; j < kScan; ++j) q = (n_lt + i == j) ? p.e[j].pos : q;
       out.pos[i] = q;
     }
+    if (p.ne > kScan) slot_scan_more(sv, p.lo, p.ne, T, M, n_lt, n_eq, out.pos);  // one round trip per 4 more entries
+    if (n_eq == 0) return;
+    a = p.lo + n_lt;
+    u = a + n_eq - 1;
+    out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
   } else {
     if (!slot_binary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
   }
@@ -360,7 +364,10 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const Bloc
   const uint32_t g = slot_pos - seed_i;
   ok = active && (slot_pos - c_lo >= seed_i) && (g + len < c_hi);
   gp = ok ? g : 0u;
-  mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
+  mm = 0;
+  // only lanes with a candidate touch memory: the mapping kernels are bound by the number of per-lane
+  // accesses the L1 (TCP) processes, not by instruction issue, so an idle lane's dummy load is not free
+  if (ok) mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
 }
 
 // Deferred reads are tagged with the (strand, seed) iteration of their first BAD

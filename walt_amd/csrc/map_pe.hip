@@ -255,8 +255,11 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     if (need) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
     // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
     const uint32_t bkey = bloom_key_of_care(care);
-    const uint64_t bw_p = svp.bloom[need ? bloom_block(bkey, svp.bloom_mask) : 0u];
-    const uint64_t bw_m = svm.bloom[need ? bloom_block(bkey, svm.bloom_mask) : 0u];
+    uint64_t bw_p = 0, bw_m = 0;
+    if (need) {
+      bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
+      bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
+    }
     SlotProbe pp, pm;
     uint32_t hi_p, hi_m;
     probe_issue(svp, need, slot, span, pp.lo, hi_p);

@@ -331,8 +331,9 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     stamp(st, 1);
     // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
     const uint32_t bkey = bloom_key_of_care(care);
-    const uint64_t bw_p = svp.bloom[need_p ? bloom_block(bkey, svp.bloom_mask) : 0u];
-    const uint64_t bw_m = svm.bloom[need_m ? bloom_block(bkey, svm.bloom_mask) : 0u];
+    uint64_t bw_p = 0, bw_m = 0;
+    if (need_p) bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
+    if (need_m) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
     SlotProbe pp, pm;
     uint32_t hi_p, hi_m;
     probe_issue(svp, need_p, slot, span, pp.lo, hi_p);
