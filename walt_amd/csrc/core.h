@@ -78,6 +78,7 @@ struct StrandView {
   uint32_t n_outl;
   const uint64_t* bloom;  // blocked Bloom filter (64-bit blocks) over the probes that can be dangerous
   uint32_t bloom_mask;    // number of blocks - 1 (a power of two, sized by the number of keys)
+  const uint32_t* pre;    // kPreBits-bit prefilter of the same keys, copied into LDS by the pass-1 kernels
   const struct Outlier* outl;  // chromosome-end entries, sorted by bucket (see probe_is_dangerous)
   const uint32_t* outl_dir;    // open-addressing table bucket -> first outlier: pairs {bucket + 1 (0 = free), index}
   uint32_t outl_dir_mask;      // pairs - 1 (power of two); outl_dir == nullptr: binary search
@@ -308,6 +309,14 @@ WALT_HD bool bloom_hit(uint64_t block, uint32_t key) {
   return (block & b) == b;
 }
 WALT_HD void bloom_insert(uint64_t* bloom, uint32_t mask, uint32_t key) { bloom[bloom_block(key, mask)] |= bloom_bits(key); }
+// Prefilter in front of the Bloom filter: one bit per key in a kPreBits-bit set that the pass-1 kernels
+// hold in LDS (8 KB per strand).  The mapping kernels are bound by the per-lane accesses the L1 serves,
+// and the Bloom block is one of ~4 per probe; with hg19's 24 chromosomes the prefilter is ~10 % full, so
+// nine probes in ten skip that load.  No false negatives (superset of the Bloom filter's keys): the set
+// of deferred reads is unchanged.  An assembly of thousands of contigs fills it and every probe goes on
+// to the Bloom filter as before.
+constexpr uint32_t kPreBits = 1u << 16;
+WALT_HD uint32_t pre_hash(uint32_t key) { return (key * 0x9E3779B1u) >> 16; }
 // key of a probe: bucket and care characters 12..15 of its (zero padded) care string
 WALT_HD uint32_t bloom_key_of_care(const uint32_t* care) { return care[0]; }
 WALT_HD uint64_t key_mask(uint32_t nk);

@@ -189,6 +189,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   StrandView& sv = idx->view.s[strand];
   uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr;
   uint64_t* bloom = nullptr;
+  uint32_t* pre = nullptr;
   uint32_t bloom_blocks = 0;
   Ent* ent = nullptr;
   int rc;
@@ -292,6 +293,10 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     std::vector<uint64_t> hb(bloom_blocks, 0);
     for (uint32_t k : keys) bloom_insert(hb.data(), bloom_blocks - 1, k);
     if ((rc = dev_alloc(idx, &bloom, (uint64_t)bloom_blocks))) return rc;
+    std::vector<uint32_t> hp(kPreBits / 32, 0);
+    for (uint32_t k : keys) hp[pre_hash(k) >> 5] |= 1u << (pre_hash(k) & 31);
+    if ((rc = dev_alloc(idx, &pre, (uint64_t)kPreBits / 32))) return rc;
+    WALT_HIP(hipMemcpy(pre, hp.data(), kPreBits / 8, hipMemcpyHostToDevice));
     if (n_outl) WALT_HIP(hipMemcpy(outl, ho.data(), n_outl * sizeof(Outlier), hipMemcpyHostToDevice));
     WALT_HIP(hipMemcpy(bloom, hb.data(), (size_t)bloom_blocks * 8, hipMemcpyHostToDevice));
     std::vector<uint32_t> od;
@@ -306,7 +311,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   idx->outliers[strand] = n_outl;
   sv.outl = outl; sv.n_outl = n_outl;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
-  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1;
+  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1; sv.pre = pre;
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }

@@ -41,6 +41,21 @@ __device__ __forceinline__ const uint32_t* block_prologue(BlockShared& sh, const
   return fits ? sh.start_index : iv.start_index;
 }
 
+// LDS copy of the two strands' Bloom prefilters (core.h pre_hash); filled before block_prologue's barrier
+struct PreFilter {
+  uint32_t bits[2][kPreBits / 32];
+};
+__device__ __forceinline__ void prefilter_stage(PreFilter& pf, const IndexView& iv, uint32_t strand_base) {
+  for (uint32_t i = threadIdx.x; i < kPreBits / 32; i += blockDim.x) {
+    pf.bits[0][i] = iv.s[strand_base].pre[i];
+    pf.bits[1][i] = iv.s[strand_base + 1].pre[i];
+  }
+}
+__device__ __forceinline__ bool prefilter_hit(const PreFilter& pf, uint32_t fi, uint32_t key) {
+  const uint32_t h = pre_hash(key);
+  return (pf.bits[fi][h >> 5] >> (h & 31)) & 1u;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -111,9 +126,19 @@ __device__ __forceinline__ void lane_load_read(LaneRead<NW>& lr, const uint32_t*
   const uint64_t rel = valid ? o - o0 : 0;  // dense array starts at the first read of the batch
   const uint32_t* p = codes2 + (rel >> 4);
   const uint32_t sh = 2 * (uint32_t)(rel & 15);
+  // 16-byte loads (the address is only 4-byte aligned, which global loads allow): a quarter of the per-lane
+  // L1 accesses of word loads.  A group is fetched when the read reaches into it; it may run up to
+  // three words past the read's last word, which the array's slack covers (codes2_words).
   uint32_t raw[NW + 1];
 #pragma unroll
-  for (int w = 0; w <= NW; ++w) raw[w] = (16u * w < lr.len + 16u) ? p[w] : 0u;  // never past the array's slack
+  for (int w = 0; w <= NW; w += 4) {
+    constexpr int kAll = NW + 1;
+    const int cnt = kAll - w < 4 ? kAll - w : 4;
+    uint32_t q[4] = {0, 0, 0, 0};
+    if (16u * w < lr.len + 16u) __builtin_memcpy(q, p + w, 4 * cnt);
+#pragma unroll
+    for (int j = 0; j < cnt; ++j) raw[w + j] = q[j];
+  }
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     uint32_t v = funnel_r(raw[w], raw[w + 1], sh);
@@ -125,7 +150,7 @@ __device__ __forceinline__ void lane_load_read(LaneRead<NW>& lr, const uint32_t*
 
 void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t* d_codes2,
                           uint32_t* d_err, hipStream_t stream);
-inline uint64_t codes2_words(uint64_t total_bytes) { return total_bytes / 16 + 4; }
+inline uint64_t codes2_words(uint64_t total_bytes) { return total_bytes / 16 + 10; }  // >= 8 words of slack behind the last word (zeroed by k_ascii_to_2bit)
 
 // Care string (chars at read offsets seed_i + 1 + 3 i, MSB first) of a seed shift
 // and its directory range, from the packed read in registers.  The prefix code is

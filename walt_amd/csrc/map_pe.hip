@@ -219,7 +219,7 @@ struct LdsHeap {  // entry i of this lane's heap; entries of one index are conti
 };
 
 template <int NW>
-__device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si, LdsHeap fast,
+__device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si, LdsHeap fast,
                                                 const uint32_t* __restrict__ codes2,
                                                 const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
                                                 uint32_t r, bool valid, uint32_t strand_base, uint32_t max_mm,
@@ -256,10 +256,8 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
     const uint32_t bkey = bloom_key_of_care(care);
     uint64_t bw_p = 0, bw_m = 0;
-    if (need) {
-      bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
-      bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
-    }
+    if (need && prefilter_hit(pf, 0, bkey)) bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
+    if (need && prefilter_hit(pf, 1, bkey)) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
     SlotProbe pp, pm;
     uint32_t hi_p, hi_m;
     probe_issue(svp, need, slot, span, pp.lo, hi_p);
@@ -363,6 +361,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
     uint32_t* __restrict__ cplx_count, uint32_t* __restrict__ cplx_list) {
   __shared__ BlockShared sh;
   __shared__ HeapEnt s_fast[kFastCands][kBlock];
+  __shared__ PreFilter pf;
+  prefilter_stage(pf, iv, strand_base);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   LdsHeap fast;
   fast.base = &s_fast[0][threadIdx.x];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
     const bool valid = r64 < n;
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
-    pe_process_dual<NW>(iv, sh, si, fast, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, ranked, heap_n,
+    pe_process_dual<NW>(iv, sh, pf, si, fast, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, ranked, heap_n,
                         bloom_count, bloom_list, cplx_count, cplx_list, n_probe, n_verified, len);
     // paired.cpp:112-115: too_short once per strand pass
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;

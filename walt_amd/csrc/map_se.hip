@@ -57,7 +57,7 @@ static __global__ __launch_bounds__(kBlock) void k_ascii_to_2bit(const uint8_t* 
   }
   bad_total = wave_sum_u32(bad_total);
   if ((threadIdx.x & 63) == 0 && bad_total) atomicAdd(err, bad_total);
-  if (blockIdx.x == 0 && threadIdx.x < 4) codes2[nwords + threadIdx.x] = 0;  // slack read by the last lanes
+  if (blockIdx.x == 0 && threadIdx.x < 8) codes2[nwords + threadIdx.x] = 0;  // slack read by the last lanes
 }
 void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t* d_codes2,
                           uint32_t* d_err, hipStream_t stream) {
@@ -288,7 +288,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 // SlotProbe / probe_issue / probe_entries / probe_resolve / verify_nobranch live in map_common.h (shared with map_pe.hip)
 
 template <int NW, bool DIAG>
-__device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const uint32_t* si,
+__device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
                                                 const uint32_t* __restrict__ codes2, uint64_t o_first,
                                                 uint64_t o_read, uint64_t oe_read, uint32_t* __restrict__ err,
                                                 uint32_t r,
@@ -332,8 +332,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
     const uint32_t bkey = bloom_key_of_care(care);
     uint64_t bw_p = 0, bw_m = 0;
-    if (need_p) bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
-    if (need_m) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
+    if (need_p && prefilter_hit(pf, 0, bkey)) bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
+    if (need_m && prefilter_hit(pf, 1, bkey)) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
     SlotProbe pp, pm;
     uint32_t hi_p, hi_m;
     probe_issue(svp, need_p, slot, span, pp.lo, hi_p);
@@ -551,6 +551,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
                                                     uint32_t* __restrict__ defer_list, uint32_t ablate,
                                                     unsigned long long* __restrict__ stamps) {
   __shared__ BlockShared sh;
+  __shared__ PreFilter pf;
+  prefilter_stage(pf, iv, strand_base);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   // persistent blocks: the LDS prologue (mask table, chromosome starts, Bloom
   // filters: ~25 KB) is paid once per block, not once per 256 reads
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
       oe_nx = offsets[r64 + blockDim.x + 1];
     }
     uint32_t len;
-    se_process_dual<NW, DIAG>(iv, sh, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
+    se_process_dual<NW, DIAG>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
                               out, defer_count, defer_list, ctr, len, ablate, st);
     // too_short is counted once per strand pass (mapping.cpp:230-233)
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
