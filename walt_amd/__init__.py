@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwalt_amd.so")
+# WALT_AMD_LIB: another build of the same library (A/B timing of two builds on one GPU box; diagnostic)
+LIB_PATH = os.environ.get("WALT_AMD_LIB") or os.path.join(_HERE, "lib", "libwalt_amd.so")
 
 WALT_OK = 0
 STRAND_CT00, STRAND_CT01, STRAND_GA10, STRAND_GA11 = 1, 2, 4, 8
