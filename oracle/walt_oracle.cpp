@@ -28,49 +28,73 @@
 extern "C" {
 
 // ---------------------------------------------------------------------------
-// Seed pattern 3 tables (src/walt/seedpattern.hpp:355-456).
-//   F2SEEDKEYWEIGHT = 12 (seedpattern.hpp:361), SEEDPATTERNLEN = 3 (356),
-//   MINIMALREADLEN = 38 (359), MINIMALSEEDLEN = 36 (360).
-//   F2CAREDPOSITION[i] = 1 + 3 i (424-430).
-//   F2NOCAREDPOSITION[s] = ascending positions that are not care positions of
-//   the seed shifted by s (431-455), with four literal deviations:
+// Seed pattern tables (src/walt/seedpattern.hpp), selected at compile time like the reference's
+// -D SEEDPATTERN3 / 5 / 7 (src/walt/Makefile:34): -DORC_PAT=3 (default), 5 or 7.
+//   pattern 3 (355-456): (0 1 0)*,         MINIMALREADLEN 38, MINIMALSEEDLEN 36, 60 care positions 1 + 3 i,
+//                        no-care rows [3][150] with 121/121/122 explicit values
+//   pattern 5 (226-352): (1 0 1 0 0)*,     32, 30, 56 care positions {0,2} + 5 r, rows [5][90], 84 + s explicit
+//   pattern 7 (29-223):  (1 1 1 0 1 0 0)*, 23, 21, 80 care positions {0,1,2,4} + 7 r, rows [7][70], 60 + s explicit
+//   F2SEEDKEYWEIGHT = 12 in all three.
+//   F2NOCAREDPOSITION[s] = ascending positions that are not care positions of the seed shifted by s;
+//   the rest of a row is 0 (C++ zero fill).  Patterns 5 and 7 follow the formula exactly; pattern 3 has
+//   four literal deviations:
 //     row 0 idx 118: 178 (formula 177)  seedpattern.hpp:439  (unreachable)
 //     row 2 idx  47:  60 (formula  70)  seedpattern.hpp:451  (reachable)
 //     row 2 idx  95: 141 (formula 142)  seedpattern.hpp:454  (reachable)
 //     row 2 idx 115: 171 (formula 172)  seedpattern.hpp:455  (unreachable)
-//   Rows hold 121/121/122 explicit values, the rest of the 150 slots are 0.
+//   (tests/golden/seedpattern{3,5,7}.json are data dumps of the header's tables.)
+// The reference caps the repeats at 50 for every pattern (mapping.cpp:238); with patterns 5 / 7 a read of
+// more than 148 / 152 bases then indexes both tables past their ends (undefined behaviour).  The oracle
+// keeps the cap and must not be given such reads.
 // ---------------------------------------------------------------------------
-enum { ORC_KEYW = 12, ORC_NCARE = 60, ORC_NNOCARE = 150, ORC_MINREAD = 38,
-       ORC_MINSEED = 36, ORC_MAXREP = 50 };
+#ifndef ORC_PAT
+#define ORC_PAT 3
+#endif
+enum { ORC_KEYW = 12, ORC_PATLEN = ORC_PAT,
+       ORC_CAREW = ORC_PAT == 3 ? 1 : (ORC_PAT == 5 ? 2 : 4), ORC_NOCAREW = ORC_PAT - ORC_CAREW,
+       ORC_NCARE = ORC_PAT == 3 ? 60 : (ORC_PAT == 5 ? 56 : 80),
+       ORC_NNOCARE = ORC_PAT == 3 ? 150 : (ORC_PAT == 5 ? 90 : 70),
+       ORC_MINREAD = ORC_PAT == 3 ? 38 : (ORC_PAT == 5 ? 32 : 23),
+       ORC_MINSEED = ORC_PAT == 3 ? 36 : (ORC_PAT == 5 ? 30 : 21),
+       ORC_EXIT1 = ORC_PAT == 7 ? 4 : 2,  // mapping.cpp:253-262
+       ORC_MAXREP = 50 };
 
 static uint32_t g_care[ORC_NCARE];
-static uint32_t g_nocare[3][ORC_NNOCARE];
+static uint32_t g_nocare[ORC_PATLEN][ORC_NNOCARE];
 static int g_tab_ready = 0;
 
 static void orc_tables_init(void) {
   if (g_tab_ready) return;
-  for (int i = 0; i < ORC_NCARE; ++i) g_care[i] = 1 + 3 * i;
-  static const int explicit_len[3] = {121, 121, 122};
-  for (int s = 0; s < 3; ++s) {
+  static const uint32_t off3[1] = {1}, off5[2] = {0, 2}, off7[4] = {0, 1, 2, 4};
+  const uint32_t* off = ORC_PAT == 3 ? off3 : (ORC_PAT == 5 ? off5 : off7);
+  for (int i = 0; i < ORC_NCARE; ++i) g_care[i] = (i / ORC_CAREW) * ORC_PATLEN + off[i % ORC_CAREW];
+  for (int s = 0; s < ORC_PATLEN; ++s) {
+    const int explicit_len = ORC_PAT == 3 ? (s == 2 ? 122 : 121) : (ORC_PAT == 5 ? 84 + s : 60 + s);
     int n = 0;
-    for (uint32_t p = 0; n < explicit_len[s]; ++p) {
-      int is_care = (p >= (uint32_t)(s + 1)) && ((p - s - 1) % 3 == 0);
+    for (uint32_t p = 0; n < explicit_len; ++p) {
+      int is_care = 0;
+      if (p >= (uint32_t)s)
+        for (int k = 0; k < ORC_CAREW; ++k) is_care |= ((p - s) % ORC_PATLEN == off[k]);
       if (!is_care) g_nocare[s][n++] = p;
     }
     for (; n < ORC_NNOCARE; ++n) g_nocare[s][n] = 0;
   }
-  g_nocare[0][118] = 178;
-  g_nocare[2][47] = 60;
-  g_nocare[2][95] = 141;
-  g_nocare[2][115] = 171;
+  if (ORC_PAT == 3) {
+    g_nocare[0][118] = 178;
+    g_nocare[2][47] = 60;
+    g_nocare[2][95] = 141;
+    g_nocare[2][115] = 171;
+  }
   g_tab_ready = 1;
 }
 
+int orc_pattern(void) { return ORC_PAT; }
+
 // Exposed so tests can compare the generated tables with the golden dump.
-void orc_get_tables(uint32_t* care60, uint32_t* nocare3x150) {
+void orc_get_tables(uint32_t* care /*60 | 56 | 80*/, uint32_t* nocare /*3x150 | 5x90 | 7x70*/) {
   orc_tables_init();
-  memcpy(care60, g_care, sizeof(g_care));
-  memcpy(nocare3x150, g_nocare, sizeof(g_nocare));
+  memcpy(care, g_care, sizeof(g_care));
+  memcpy(nocare, g_nocare, sizeof(g_nocare));
 }
 
 // ---------------------------------------------------------------------------
@@ -205,10 +229,10 @@ static void orc_convert(const char* in, uint32_t len, int ag, char* out) {
 
 // Seed geometry, mapping.cpp:235-239.
 static inline void orc_seed_geom(uint32_t read_len, uint32_t* repeats, uint32_t* seed_len) {
-  uint32_t r = (read_len - 3 + 1) / 3;
+  uint32_t r = (read_len - ORC_PATLEN + 1) / ORC_PATLEN;
   if (r > ORC_MAXREP) r = ORC_MAXREP;
   *repeats = r;
-  *seed_len = r;  // SEEDPATTERNCAREDWEIGHT == 1
+  *seed_len = r * ORC_CAREW;
 }
 
 // Mismatch count, mapping.cpp:288-304 (limit = best_match.mismatch there,
@@ -217,12 +241,12 @@ static uint32_t orc_count_mm(const orc_strand* x, const char* read, uint32_t rea
                              uint32_t genome_pos, uint32_t seed_i, uint32_t repeats,
                              uint32_t limit) {
   uint32_t mm = 0;
-  uint32_t n_nocare = repeats * 2 + seed_i;
+  uint32_t n_nocare = repeats * ORC_NOCAREW + seed_i;
   for (uint32_t p = 0; p < n_nocare && mm <= limit; ++p) {
     uint32_t q = g_nocare[seed_i][p];
     if (gat(x, (uint64_t)genome_pos + q) != (uint8_t)read[q]) ++mm;
   }
-  for (uint32_t p = repeats * 3 + seed_i; p < read_len && mm <= limit; ++p) {
+  for (uint32_t p = repeats * ORC_PATLEN + seed_i; p < read_len && mm <= limit; ++p) {
     if (gat(x, (uint64_t)genome_pos + p) != (uint8_t)read[p]) ++mm;
   }
   return mm;
@@ -239,9 +263,9 @@ void orc_se_map_read(const orc_strand* x, const char* org_read, uint32_t read_le
   char* read = buf.data();
   orc_convert(org_read, read_len, ag_wildcard, read);
 
-  for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+  for (uint32_t seed_i = 0; seed_i < ORC_PATLEN; ++seed_i) {
     if (best->mismatch == 0 && seed_i) break;          // mapping.cpp:250-251
-    if (best->mismatch == 1 && seed_i >= 2) break;     // mapping.cpp:253-257
+    if (best->mismatch == 1 && seed_i >= ORC_EXIT1) break;  // mapping.cpp:253-262
     const char* seed = read + seed_i;                  // read.substr(seed_i), 265
     uint32_t h = orc_hash(seed);
     uint32_t first = x->counter[h], second = x->counter[h + 1];
@@ -358,9 +382,9 @@ static void orc_pe_map_read(const orc_strand* x, const char* org_read, uint32_t 
   orc_convert(org_read, read_len, ag_wildcard, read);
 
   uint32_t cur_max = max_mm;
-  for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+  for (uint32_t seed_i = 0; seed_i < ORC_PATLEN; ++seed_i) {
     if (!top->pq.empty() && top->Full() && top->pq.top().mismatch == 0 && seed_i) break;      // 133-135
-    if (!top->pq.empty() && top->Full() && top->pq.top().mismatch == 1 && seed_i >= 2) break; // 139-141
+    if (!top->pq.empty() && top->Full() && top->pq.top().mismatch == 1 && seed_i >= ORC_EXIT1) break; // 137-149
     const char* seed = read + seed_i;
     uint32_t h = orc_hash(seed);
     uint32_t first = x->counter[h], second = x->counter[h + 1];

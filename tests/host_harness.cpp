@@ -149,7 +149,7 @@ int hh_map_se(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, 
   *too_short = 0;
   for (uint32_t r = 0; r < n; ++r) {
     uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
-    if (len > 1024) return -1;
+    if (len > kMaxReadLen) return -1;
     if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_bits, NW,
                    rec.data(), 1))
       return -2;
@@ -161,12 +161,12 @@ int hh_map_se(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, 
       uint32_t repeats = seed_repeats(len);
       for (uint32_t fi = 0; fi < 2; ++fi) {
         const StrandView& sv = iv.s[(ag ? 2 : 0) + fi];
-        for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+        for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
           if (best.mismatch == 0 && seed_i) break;
-          if (best.mismatch == 1 && seed_i >= 2) break;
+          if (best.mismatch == 1 && seed_i >= kExitOneMismatch) break;
           const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
           Lookup lk;
-          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], repeats, lk);
+          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len_of(repeats), lk);
           const Region reg = lk.reg;
           uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
           if (size == 0 || size > b) continue;
@@ -196,7 +196,7 @@ int hh_pe_topk(void* hp, const char* bases, const uint64_t* offsets, uint32_t n,
   *too_short = 0;
   for (uint32_t r = 0; r < n; ++r) {
     uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
-    if (len > 1024) return -1;
+    if (len > kMaxReadLen) return -1;
     if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_bits, NW,
                    rec.data(), 1))
       return -2;
@@ -208,12 +208,12 @@ int hh_pe_topk(void* hp, const char* bases, const uint64_t* offsets, uint32_t n,
       uint32_t repeats = seed_repeats(len);
       for (uint32_t fi = 0; fi < 2; ++fi) {
         const StrandView& sv = iv.s[(ag ? 2 : 0) + fi];
-        for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+        for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
           bool full = hsize >= top_k;
           if (full && heap_mm(heap[0]) == 0 && seed_i) break;        // paired.cpp:133-135
-          if (full && heap_mm(heap[0]) == 1 && seed_i >= 2) break;   // paired.cpp:139-141
+          if (full && heap_mm(heap[0]) == 1 && seed_i >= kExitOneMismatch) break;   // paired.cpp:137-149
           const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
-          Region reg = seed_lookup(iv, sv, care, care[kCareWords], care[kCareWords + 1], repeats);
+          Region reg = seed_lookup(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len_of(repeats));
           uint32_t size = reg.l <= reg.u ? reg.u - reg.l + 1 : 0;
           if (size == 0 || size > b) continue;
           uint32_t mk[NW];
@@ -266,8 +266,9 @@ int hh_pack(const char* bases, const uint64_t* offsets, uint32_t n, int ga, uint
 }
 
 // expose the literal tables for tests/test_seedtab.py
-void hh_get_nocare(uint32_t* out3x150) {
-  for (int s = 0; s < 3; ++s) memcpy(out3x150 + 150 * s, nocare_row(s), 150 * sizeof(uint32_t));
+int hh_pattern() { return (int)kPat; }
+void hh_get_nocare(uint32_t* out /* kPat x 150 */) {
+  for (uint32_t s = 0; s < kPat; ++s) memcpy(out + 150 * s, nocare_row((int)s), 150 * sizeof(uint32_t));
 }
 
 }  // extern "C"

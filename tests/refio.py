@@ -41,25 +41,56 @@ def _newer(target, sources):
     return all(os.path.getmtime(s) <= t for s in sources)
 
 
-def build_oracle(force=False):
-    if not force and _newer(ORACLE_SO, [ORACLE_SRC]):
-        return ORACLE_SO
-    os.makedirs(os.path.dirname(ORACLE_SO), exist_ok=True)
-    subprocess.run(["g++", "-O3", "-fopenmp", "-shared", "-fPIC", "-std=c++11", "-o", ORACLE_SO, ORACLE_SRC],
-                   check=True)
-    return ORACLE_SO
+# Seed pattern the helpers below work with: 3 (the reference's default build) or 5 / 7 (the reference rebuilt
+# with -D SEEDPATTERN5 / 7).  It selects the oracle / harness builds (-DORC_PAT / -DWALT_SEEDPATTERN), the
+# golden case set (cases_sp5.json, out_sp5/ ...) and MINIMALREADLEN in the mapstats text.
+PATTERN = 3
+MIN_READ_LEN = {3: 38, 5: 32, 7: 23}
+MAX_READ_LEN = {3: 1024, 5: 148, 7: 152}
 
 
-def build_harness(force=False):
+def set_pattern(p):
+    global PATTERN
+    assert p in (3, 5, 7)
+    PATTERN = p
+
+
+def _sfx(p=None):
+    p = PATTERN if p is None else p
+    return "" if p == 3 else "_sp%d" % p
+
+
+def ref_walt(p=None):
+    return REF_WALT + _sfx(p)
+
+
+def ref_makedb(p=None):
+    return REF_MAKEDB + _sfx(p)
+
+
+def build_oracle(force=False, pattern=None):
+    pattern = PATTERN if pattern is None else pattern
+    so = ORACLE_SO.replace(".so", _sfx(pattern) + ".so")
+    if not force and _newer(so, [ORACLE_SRC]):
+        return so
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.run(["g++", "-O3", "-fopenmp", "-shared", "-fPIC", "-std=c++11", "-DORC_PAT=%d" % pattern, "-o", so,
+                    ORACLE_SRC], check=True)
+    return so
+
+
+def build_harness(force=False, pattern=None):
+    pattern = PATTERN if pattern is None else pattern
+    so = HARNESS_SO.replace(".so", _sfx(pattern) + ".so")
     csrc = os.path.join(ROOT, "walt_amd", "csrc")
     srcs = [os.path.join(HERE, "host_harness.cpp"), os.path.join(csrc, "host_index.cpp"),
             os.path.join(csrc, "core.h"), os.path.join(csrc, "index_core.h"), os.path.join(csrc, "host_common.h")]
-    if not force and _newer(HARNESS_SO, srcs):
-        return HARNESS_SO
-    os.makedirs(os.path.dirname(HARNESS_SO), exist_ok=True)
-    subprocess.run(["g++", "-O2", "-fopenmp", "-shared", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas", "-o",
-                    HARNESS_SO, srcs[0], srcs[1]], check=True)
-    return HARNESS_SO
+    if not force and _newer(so, srcs):
+        return so
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-fopenmp", "-shared", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas",
+                    "-DWALT_SEEDPATTERN=%d" % pattern, "-o", so, srcs[0], srcs[1]], check=True)
+    return so
 
 
 HOSTIO_SO = os.path.join(HERE, "build", "libhostio_harness.so")
@@ -75,8 +106,8 @@ def build_hostio_harness(force=False):
     return HOSTIO_SO
 
 
-_oracle = None
-_harness = None
+_oracle = {}
+_harness = {}
 _hostio = None
 
 
@@ -91,9 +122,9 @@ def hostio_harness():
 
 
 def oracle():
-    global _oracle
-    if _oracle is None:
+    if PATTERN not in _oracle:
         L = ctypes.CDLL(build_oracle())
+        assert L.orc_pattern() == PATTERN
         vp, u32, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
         L.orc_get_tables.argtypes = [vp, vp]
         L.orc_hash.argtypes = [ctypes.c_char_p]
@@ -103,14 +134,14 @@ def oracle():
         L.orc_se_map_strand.argtypes = [vp, ctypes.c_char, vp, vp, u32, ci, u32, ci, vp, vp]
         L.orc_pe_topk_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, u32, ci, vp, vp, vp]
         L.orc_pe_merge_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32, vp, u32, ci, u32, vp]
-        _oracle = L
-    return _oracle
+        _oracle[PATTERN] = L
+    return _oracle[PATTERN]
 
 
 def harness():
-    global _harness
-    if _harness is None:
+    if PATTERN not in _harness:
         L = ctypes.CDLL(build_harness())
+        assert L.hh_pattern() == PATTERN
         vp, u32, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
         L.hh_index_new.argtypes = [u32, vp, ci]
         L.hh_index_new.restype = vp
@@ -125,8 +156,8 @@ def harness():
         L.hh_pack.argtypes = [vp, vp, u32, ci, u32, u32, vp, ctypes.c_uint64]
         L.walt_makedb.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci]
         L.walt_last_error.restype = ctypes.c_char_p
-        _harness = L
-    return _harness
+        _harness[PATTERN] = L
+    return _harness[PATTERN]
 
 
 # ---------------------------------------------------------------------------
@@ -448,8 +479,9 @@ def _pct(a, b):
 def se_mapstats(total, unique, ambiguous, unmapped, too_short, tabs=0):  # StatSingleReads::tostring, mapping.cpp:47-63
     t = "    " * tabs
     return ("%stotal_reads: %d\n%smapped:\n%s    unique: %d\n%s    percent_unique: %s\n%s    ambiguous: %d\n"
-            "%sunmapped: %d\n%smin_read_length: 38\n%stoo_short: %d") % (
-                t, total, t, t, unique, t, _pct(unique, total), t, ambiguous, t, unmapped, t, t, too_short)
+            "%sunmapped: %d\n%smin_read_length: %d\n%stoo_short: %d") % (
+                t, total, t, t, unique, t, _pct(unique, total), t, ambiguous, t, unmapped, t, MIN_READ_LEN[PATTERN], t,
+                too_short)
 
 
 # ---------------------------------------------------------------------------
@@ -579,13 +611,13 @@ def pe_mapstats(pairs, s1, s2, hist):  # StatPairedReads::tostring, paired.cpp:5
 # ---------------------------------------------------------------------------
 # golden fixtures
 # ---------------------------------------------------------------------------
-def golden_meta():
-    with open(os.path.join(GOLDEN, "cases.json")) as f:
+def golden_meta(pattern=None):
+    with open(os.path.join(GOLDEN, "cases%s.json" % _sfx(pattern))) as f:
         return json.load(f)
 
 
-def golden_file(case, name):
-    with gzip.open(os.path.join(GOLDEN, "out", case, name + ".gz"), "rb") as f:
+def golden_file(case, name, pattern=None):
+    with gzip.open(os.path.join(GOLDEN, "out" + _sfx(pattern), case, name + ".gz"), "rb") as f:
         return f.read().decode()
 
 

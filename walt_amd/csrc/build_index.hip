@@ -100,16 +100,17 @@ __device__ __forceinline__ uint32_t marked_char(const uint32_t* g2, uint32_t p, 
   uint32_t c = g2_code(g2, (uint64_t)p + cp);
   return c == 0 ? 1u : c == 3 ? 3u : 2u;
 }
-// pass A: care chars 28..59
+// pass A: care chars [q_lo, q_hi), at most 32 of them (28..59 for pattern 3; pattern 7's 28..79 take two passes)
 __global__ void k_keys_low(const uint32_t* __restrict__ g2, const uint32_t* __restrict__ start, uint32_t n_chrom,
-                           const uint32_t* __restrict__ pos, uint32_t n, unsigned long long* __restrict__ keys) {
+                           const uint32_t* __restrict__ pos, uint32_t n, uint32_t q_lo, uint32_t q_hi,
+                           unsigned long long* __restrict__ keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t p = pos[i];
   uint32_t chr = chrom_id(start, n_chrom, p);
   uint32_t room = start[chr + 1] - p;
   unsigned long long k = 0;
-  for (uint32_t q = 28; q < 60; ++q) k = (k << 2) | marked_char(g2, p, room, q);
+  for (uint32_t q = q_lo; q < q_hi; ++q) k = (k << 2) | marked_char(g2, p, room, q);
   keys[i] = k;
 }
 // pass B: (bucket << 32) | care chars 12..27
@@ -215,10 +216,15 @@ static int build_one_strand(walt_index* idx, int strand, const uint8_t* d_ascii,
     WALT_HIPB(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, vals, (size_t)index_size, 0u, 64u, stream));
     DevBuf sort_tmp;
     WALT_HIPB(sort_tmp.alloc(sort_bytes));
-    // pass A: least significant 32 care chars
-    hipLaunchKernelGGL(k_keys_low, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, d_start, n_chrom,
-                       vals.current(), index_size, keys.current());
-    WALT_HIPB(rocprim::radix_sort_pairs(sort_tmp.p, sort_bytes, keys, vals, (size_t)index_size, 0u, 64u, stream));
+    // pass A (stable LSD passes): care chars 28 .. kNumCare-1, the least significant 32 first
+    for (uint32_t q_hi = kNumCare; q_hi > 28;) {
+      const uint32_t q_lo = q_hi > 28 + 32 ? q_hi - 32 : 28;
+      hipLaunchKernelGGL(k_keys_low, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, d_start, n_chrom,
+                         vals.current(), index_size, q_lo, q_hi, keys.current());
+      WALT_HIPB(rocprim::radix_sort_pairs(sort_tmp.p, sort_bytes, keys, vals, (size_t)index_size, 0u,
+                                          2u * (q_hi - q_lo), stream));
+      q_hi = q_lo;
+    }
     // pass B (stable): bucket + first 16 care chars
     hipLaunchKernelGGL(k_keys_high, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, d_start, n_chrom,
                        vals.current(), index_size, keys.current());

@@ -46,13 +46,31 @@
 
 namespace walt {
 
-// seedpattern.hpp:355-361, 424
+// Seed pattern: a compile-time choice like the reference's -D SEEDPATTERN3 / 5 / 7 (src/walt/Makefile:34,
+// FAQ.md:5-13).  The default build is pattern 3 (0,1,0)*; -DWALT_SEEDPATTERN=5 / 7 give the libraries
+// libwalt_amd_sp5.so / _sp7.so, whose indexes are, like the reference's, specific to their pattern.
+//   pattern 3: seedpattern.hpp:355-361,424    (0 1 0)*          care offsets {1} of each 3
+//   pattern 5: seedpattern.hpp:226-232,264    (1 0 1 0 0)*      care offsets {0, 2} of each 5
+//   pattern 7: seedpattern.hpp:29-35,59       (1 1 1 0 1 0 0)*  care offsets {0, 1, 2, 4} of each 7
+#ifndef WALT_SEEDPATTERN
+#define WALT_SEEDPATTERN 3
+#endif
+static_assert(WALT_SEEDPATTERN == 3 || WALT_SEEDPATTERN == 5 || WALT_SEEDPATTERN == 7, "seed pattern 3, 5 or 7");
+constexpr uint32_t kPat = WALT_SEEDPATTERN;                          // SEEDPATTERNLEN
+constexpr uint32_t kCareW = kPat == 3 ? 1 : (kPat == 5 ? 2 : 4);     // SEEDPATTERNCAREDWEIGHT
+constexpr uint32_t kNoCareW = kPat - kCareW;                         // SEEDPATTERNNOCAREDWEIGHT
 constexpr uint32_t kKeyWeight = 12;     // F2SEEDKEYWEIGHT
-constexpr uint32_t kNumCare = 60;       // F2CAREDPOSITION_SIZE
-constexpr uint32_t kMinReadLen = 38;    // MINIMALREADLEN
-constexpr uint32_t kMinSeedLen = 36;    // MINIMALSEEDLEN
-constexpr uint32_t kMaxRepeats = 50;    // cap at mapping.cpp:238
-constexpr uint32_t kMinRepeats = 12;    // (38 - 2) / 3
+constexpr uint32_t kNumCare = kPat == 3 ? 60 : (kPat == 5 ? 56 : 80);    // F2CAREDPOSITION_SIZE
+constexpr uint32_t kMinReadLen = kPat == 3 ? 38 : (kPat == 5 ? 32 : 23);  // MINIMALREADLEN
+constexpr uint32_t kMinSeedLen = kPat == 3 ? 36 : (kPat == 5 ? 30 : 21);  // MINIMALSEEDLEN
+// Repeats of the pattern inside a read: the reference caps them at 50 (mapping.cpp:238), which for
+// patterns 5 and 7 lets a read of more than 148 / 152 bases index F2CAREDPOSITION (56 / 80 entries) and
+// F2NOCAREDPOSITION (84+s / 60+s explicit entries) beyond their ends -- undefined behaviour there,
+// a refused read here (kMaxReadLen).  Pattern 3's tables cover its 50 repeats.
+constexpr uint32_t kMaxRepeats = kPat == 3 ? 50 : (kPat == 5 ? 28 : 20);
+constexpr uint32_t kMinRepeats = (kMinReadLen - kPat + 1) / kPat;    // 12 / 5 / 2
+constexpr uint32_t kMaxReadLen = kPat == 3 ? 1024 : kPat * kMaxRepeats + 2 * kPat - 2;  // 1024 / 148 / 152
+constexpr uint32_t kExitOneMismatch = kPat == 7 ? 4 : 2;  // mapping.cpp:253-262: stop once best mm == 1 and seed_i >= this
 constexpr uint32_t kKeyChars = 32;      // care chars 12..43 held in Ent::key
 constexpr uint32_t kMaskWords = 10;     // 160 bases of table-driven compare mask
 constexpr uint32_t kNumBuckets = 1u << 24;
@@ -60,7 +78,12 @@ constexpr uint32_t kMinDirBits = 24;    // directory prefixes always cover the 1
 constexpr uint32_t kMaxDirBits = 31;
 constexpr uint32_t kEraseBucket = 500000;  // reference.cpp:211
 
-WALT_HD uint32_t care_pos(uint32_t i) { return 1 + 3 * i; }  // F2CAREDPOSITION[i]
+// F2CAREDPOSITION[i] (the tables of all three patterns follow their formula exactly; tests/golden/seedpattern*.json)
+WALT_HD constexpr uint32_t care_pos(uint32_t i) {
+  return kPat == 3 ? 1 + 3 * i
+       : kPat == 5 ? (i / 2) * 5 + (i % 2) * 2
+                   : (i / 4) * 7 + ((i % 4) == 3 ? 4u : (i % 4));
+}
 
 struct Ent {
   uint32_t key_hi, key_lo, pos;
@@ -120,9 +143,9 @@ struct BestMatch {
 //   slot[s], span[s]  the entries whose care characters start like this seed's
 //                  are dir[slot[s]] .. dir[slot[s] - span[s]] (reversed directory)
 // kept in SoA form in HBM: field f of read r at base[f * stride + r].
-constexpr uint32_t kCareWords = 4;
+constexpr uint32_t kCareWords = (kNumCare + 15) / 16;  // 4 / 4 / 5
 constexpr uint32_t kPerSeedWords = kCareWords + 2;
-WALT_HD uint32_t packed_fields(uint32_t nw) { return 1 + nw + 3 * kPerSeedWords; }
+WALT_HD uint32_t packed_fields(uint32_t nw) { return 1 + nw + kPat * kPerSeedWords; }
 // field 0: length; 1..nw: words; then per seed: care[4], slot, span
 
 // ---------------------------------------------------------------------------
@@ -136,9 +159,10 @@ WALT_HD uint32_t pow3(uint32_t e) {
 
 // seed geometry, mapping.cpp:235-239
 WALT_HD uint32_t seed_repeats(uint32_t read_len) {
-  uint32_t r = (read_len - 2) / 3;
+  uint32_t r = (read_len - kPat + 1) / kPat;
   return r < kMaxRepeats ? r : kMaxRepeats;
 }
+WALT_HD uint32_t seed_len_of(uint32_t repeats) { return repeats * kCareW; }  // mapping.cpp:239
 
 // 2-bit code of a sanitised base; 4 = not ACGT (getBits would exit, util.hpp:117-119)
 WALT_HD uint32_t base_code(uint8_t c) {
@@ -178,7 +202,8 @@ WALT_HD uint64_t ent_key(const Ent& e) { return ((uint64_t)e.key_hi << 32) | e.k
 WALT_HD uint32_t care_char(const uint32_t* care, uint32_t p) {
   const uint32_t c0 = care[0], c1 = care[1], c2 = care[2], c3 = care[3];
   const uint32_t w = p >> 4;
-  uint32_t v = c3;
+  uint32_t v = kCareWords > 4 ? care[kCareWords - 1] : c3;
+  v = (kCareWords > 4 && w == 3) ? c3 : v;
   v = w == 2 ? c2 : v;
   v = w == 1 ? c1 : v;
   v = w == 0 ? c0 : v;
@@ -328,6 +353,9 @@ WALT_HD uint32_t outl_dir_hash(uint32_t h) {
   return x ^ (x >> 15);
 }
 WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
+  // patterns 5 and 7 always take the literal LowerBound/UpperBound search (the directory/key search and
+  // its exactness argument, DESIGN.md section 4, are built for pattern 3, the reference's default)
+  if (kPat != 3) return true;
   const uint32_t h = care[0] >> 8;
   if (bucket_is_bad(sv, h)) return true;
   uint32_t lo = 0, hi = sv.n_outl;  // first outlier of bucket h
@@ -638,14 +666,14 @@ WALT_HD uint32_t tail_mask_word(uint32_t w, uint32_t lo, uint32_t hi) {
   uint32_t below = ((1u << (2 * na)) - 1u);
   return m & ~below;
 }
-// mask_table layout: [3][kMaxRepeats - kMinRepeats + 1][kMaskWords]
+// mask_table layout: [kPat][kMaxRepeats - kMinRepeats + 1][kMaskWords]
 WALT_HD uint32_t mask_table_index(uint32_t seed_i, uint32_t repeats, uint32_t w) {
   return (seed_i * (kMaxRepeats - kMinRepeats + 1) + (repeats - kMinRepeats)) * kMaskWords + w;
 }
 WALT_HD uint32_t compare_mask_word(const uint32_t* mask_table, uint32_t seed_i, uint32_t repeats,
                                    uint32_t read_len, uint32_t w) {
   uint32_t t = w < kMaskWords ? mask_table[mask_table_index(seed_i, repeats, w)] : 0u;
-  return t | tail_mask_word(w, 3 * repeats + seed_i, read_len);
+  return t | tail_mask_word(w, kPat * repeats + seed_i, read_len);
 }
 
 // ---------------------------------------------------------------------------

@@ -34,41 +34,47 @@ const char* last_error_cstr() { return g_err.c_str(); }
 // zeros up to 150 slots.  tests/test_seedtab.py checks them against a golden
 // dump of the reference header.
 // ---------------------------------------------------------------------------
-static uint32_t g_nocare[3][150];
+static uint32_t g_nocare[kPat][150];
 static std::vector<uint32_t> g_mask_table;
 static bool g_tables_ready = false;
 
 static void init_tables() {
   if (g_tables_ready) return;
-  static const int explicit_len[3] = {121, 121, 122};
-  for (int s = 0; s < 3; ++s) {
+  // explicit values per row in the reference header: pattern 3: 121/121/122 of 150 (seedpattern.hpp:431-455),
+  // pattern 5: 84+s of 90 (281-351), pattern 7: 60+s of 70 (82-222); C++ zero-fills the rest of a row
+  for (uint32_t s = 0; s < kPat; ++s) {
+    const int explicit_len = kPat == 3 ? (s == 2 ? 122 : 121) : (kPat == 5 ? 84 + (int)s : 60 + (int)s);
     int n = 0;
-    for (uint32_t p = 0; n < explicit_len[s]; ++p) {
-      bool is_care = p >= (uint32_t)(s + 1) && (p - s - 1) % 3 == 0;
+    for (uint32_t p = 0; n < explicit_len; ++p) {
+      bool is_care = false;
+      if (p >= s)
+        for (uint32_t k = 0; k < kCareW; ++k) is_care = is_care || (p - s) % kPat == care_pos(k);
       if (!is_care) g_nocare[s][n++] = p;
     }
     for (; n < 150; ++n) g_nocare[s][n] = 0;
   }
-  g_nocare[0][118] = 178;
-  g_nocare[2][47] = 60;
-  g_nocare[2][95] = 141;
-  g_nocare[2][115] = 171;
+  if (kPat == 3) {  // the four literal deviations of the pattern-3 table (patterns 5 and 7 follow the formula)
+    g_nocare[0][118] = 178;
+    g_nocare[2][47] = 60;
+    g_nocare[2][95] = 141;
+    g_nocare[2][115] = 171;
+  }
 
   // compare masks: for (seed_i, repeats) the offsets F2NOCAREDPOSITION[seed_i][p],
-  // p < 2*repeats + seed_i (mapping.cpp:290-298), one bit per base at bit 2k.
+  // p < kNoCareW*repeats + seed_i (mapping.cpp:290-298), one bit per base at bit 2k.
   const uint32_t nrep = kMaxRepeats - kMinRepeats + 1;
-  g_mask_table.assign(3 * nrep * kMaskWords, 0);
-  for (uint32_t s = 0; s < 3; ++s) {
+  g_mask_table.assign(kPat * nrep * kMaskWords, 0);
+  for (uint32_t s = 0; s < kPat; ++s) {
     for (uint32_t rep = kMinRepeats; rep <= kMaxRepeats; ++rep) {
-      uint32_t n_nocare = 2 * rep + s;
+      uint32_t n_nocare = kNoCareW * rep + s;
       for (uint32_t p = 0; p < n_nocare; ++p) {
         uint32_t q = g_nocare[s][p];
         // The single-mask formulation needs every listed offset to be distinct
-        // and below the tail start 3*rep+s; true for all reachable prefixes
+        // and below the tail start kPat*rep+s; true for all reachable prefixes
         // (checked here so a table change cannot silently break it).
         uint32_t& word = g_mask_table[mask_table_index(s, rep, q >> 4)];
         uint32_t bit = 1u << (2 * (q & 15));
-        if (q >= 3 * rep + s || (word & bit)) {
+        if (q >= kPat * rep + s || (word & bit)) {
           fprintf(stderr, "walt_amd: seed table invariant broken (s=%u rep=%u p=%u)\n", s, rep, p);
           abort();
         }
@@ -265,13 +271,15 @@ static inline uint32_t hash_bytes(const uint8_t* s) {  // getHashValue, util.hpp
 
 struct SortRec {
   uint64_t k0;   // care chars 12..43, 2 bits each, 0 = beyond the chromosome end
-  uint32_t k1;   // care chars 44..59
+  uint64_t k1;   // care chars 44..75 (pattern 3: ..59, pattern 5: ..55)
+  uint32_t k2;   // care chars 76..79 (pattern 7)
   uint32_t pos;
 };
 struct SortRecLess {  // SortHashTableBucketCMP, reference.cpp:258-288, on precomputed keys
   bool operator()(const SortRec& a, const SortRec& b) const {
     if (a.k0 != b.k0) return a.k0 < b.k0;
-    return a.k1 < b.k1;
+    if (a.k1 != b.k1) return a.k1 < b.k1;
+    return a.k2 < b.k2;
   }
 };
 
@@ -339,15 +347,18 @@ static int build_strand(HostGenome& g, int indicator, int threads, StrandFile& s
         uint32_t p = sf.index[j];
         uint32_t chr = chrom_id(start, n_chrom, p);
         uint32_t room = start[chr + 1] - p;  // l1 / l2 of the comparator
-        uint64_t k0 = 0;
-        uint32_t k1 = 0;
+        uint64_t k0 = 0, k1 = 0;
+        uint32_t k2 = 0;
         for (uint32_t q = kKeyWeight; q < kNumCare; ++q) {
           uint32_t cp = care_pos(q);
           uint32_t v = cp >= room ? 0u : (seq[p + cp] == 'A' ? 1u : seq[p + cp] == 'T' ? 3u : 2u);
-          if (q < kKeyWeight + 32) k0 = (k0 << 2) | v; else k1 = (k1 << 2) | v;
+          if (q < kKeyWeight + 32) k0 = (k0 << 2) | v;
+          else if (q < kKeyWeight + 64) k1 = (k1 << 2) | v;
+          else k2 = (k2 << 2) | v;
         }
         recs[j - lo].k0 = k0;
         recs[j - lo].k1 = k1;
+        recs[j - lo].k2 = k2;
         recs[j - lo].pos = p;
       }
       std::sort(recs.begin(), recs.end(), SortRecLess());

@@ -40,8 +40,14 @@ WALT_HD Ent make_ent(const uint32_t* g2, uint32_t genome_len, uint32_t pos, bool
 // first care character index (>= 12) of an entry that lies at or beyond the end of
 // its chromosome; room = chromosome end - pos.  kNumCare when every character fits.
 WALT_HD uint32_t first_beyond(uint32_t room) {
-  // care_pos(q) = 1 + 3 q >= room  <=>  q >= (room - 1) / 3 rounded up
-  const uint32_t q = room <= 1 ? 0u : (room - 1 + 2) / 3;
+  uint32_t q;
+  if (kPat == 3) {
+    // care_pos(q) = 1 + 3 q >= room  <=>  q >= (room - 1) / 3 rounded up
+    q = room <= 1 ? 0u : (room - 1 + 2) / 3;
+  } else {
+    q = 0;
+    while (q < kNumCare && care_pos(q) < room) ++q;
+  }
   return q < kKeyWeight ? kKeyWeight : q;
 }
 
@@ -82,9 +88,9 @@ WALT_HD bool pack_read(const uint8_t* bases, uint32_t len, uint32_t ga, uint32_t
     }
     out[(1 + w) * stride] = v;
   }
-  uint32_t seed_len = len >= kMinReadLen ? seed_repeats(len) : 0;
-  for (uint32_t s = 0; s < 3; ++s) {
-    uint32_t care[kCareWords] = {0, 0, 0, 0};
+  uint32_t seed_len = len >= kMinReadLen ? seed_len_of(seed_repeats(len)) : 0;
+  for (uint32_t s = 0; s < kPat; ++s) {
+    uint32_t care[kCareWords] = {};
     for (uint32_t p = 0; p < seed_len; ++p) {
       uint32_t i = s + care_pos(p);  // < len, see DESIGN.md
       uint32_t c = base_code(bases[i]);

@@ -8,7 +8,7 @@
 
 namespace walt {
 
-constexpr uint32_t kMaskTableWords = 3 * (kMaxRepeats - kMinRepeats + 1) * kMaskWords;  // 1170
+constexpr uint32_t kMaskTableWords = kPat * (kMaxRepeats - kMinRepeats + 1) * kMaskWords;  // 1170 for pattern 3
 constexpr uint32_t kLdsChroms = 1023;  // start_index entries staged in LDS when they fit
 constexpr unsigned kPersistentGrid = 256 * 8;  // blocks of the persistent mapping kernels (256 CUs x 8)
 constexpr uint32_t kSmallRegion = 4;   // regions up to this size are verified by their own lane
@@ -157,24 +157,33 @@ inline uint64_t codes2_words(uint64_t total_bytes) { return total_bytes / 16 + 1
 // accumulated four characters at a time through the LDS table pcode4; characters
 // beyond seed_len are zero, whose code bits are zeros, which is exactly the zero
 // padding dir_range() applies to short seeds.
+// number of care characters (of at most kMaxRepeats repeats) whose read offset, counted from the first
+// care character, lies below `bases`
+constexpr int care_chars_within(int bases) {
+  int n = 0;
+  while (n < (int)(kMaxRepeats * kCareW) && (int)(care_pos((uint32_t)n) - care_pos(0)) < bases) ++n;
+  return n;
+}
+
 template <int NW>
 __device__ __forceinline__ void seed_query(const uint32_t* rd, uint32_t seed_len, uint32_t seed_i, uint32_t ga,
                                            uint32_t Bd, const uint16_t* pcode4, uint32_t* care, uint32_t& slot,
                                            uint32_t& span) {
   constexpr int NS = NW < 10 ? NW : 10;                       // 50 care chars reach base 3*49 + 3 = 150
-  constexpr int NC = (16 * NS - 1) / 3 + 1 < (int)kMaxRepeats ? (16 * NS - 1) / 3 + 1 : (int)kMaxRepeats;
+  constexpr int NC = care_chars_within(16 * NS);              // care characters whose base lies in those words
   uint32_t shd[NS];
-  const uint32_t sh = 2 * (seed_i + 1);
+  const uint32_t sh = 2 * (seed_i + care_pos(0));             // the read shifted to the first care character
 #pragma unroll
   for (int w = 0; w < NS; ++w) shd[w] = funnel_r(rd[w], w + 1 < NW ? rd[w + 1] : 0u, sh);
-  care[0] = care[1] = care[2] = care[3] = 0;
+#pragma unroll
+  for (int w = 0; w < (int)kCareWords; ++w) care[w] = 0;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    const int q = 3 * i;  // compile-time offset in the shifted read
+    const int q = (int)(care_pos(i) - care_pos(0));  // compile-time offset in the shifted read
     care[i >> 4] |= ((shd[q >> 4] >> (2 * (q & 15))) & 3u) << (30 - 2 * (i & 15));
   }
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {  // zero the characters at and beyond seed_len
+  for (int w = 0; w < (int)kCareWords; ++w) {  // zero the characters at and beyond seed_len
     const uint32_t keep = seed_len > 16u * w ? seed_len - 16u * w : 0u;
     care[w] = keep >= 16 ? care[w] : (keep ? care[w] & ~(0xFFFFFFFFu >> (2 * keep)) : 0u);
   }

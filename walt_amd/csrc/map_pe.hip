@@ -82,27 +82,27 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
   for (uint32_t fi = 0; fi < 2; ++fi) {
     const StrandView& sv = iv.s[strand_base + fi];
 #pragma unroll 1
-    for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
-      // paired.cpp:133-141: stop once the heap is full of exact (seed >= 1) or
-      // one-mismatch (seed >= 2) candidates; top only decreases, so per-seed
+    for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
+      // paired.cpp:133-149: stop once the heap is full of exact (seed >= 1) or
+      // one-mismatch (seed >= 2; pattern 7: >= 4) candidates; top only decreases, so per-seed
       // predicates equal the reference's `break`.
       const bool full = hsize >= top_k;
       const uint32_t top_mm = hsize ? heap_mm(heap[0]) : 0xFFFFFFFFu;
-      bool act = mappable && !(full && top_mm == 0 && seed_i) && !(full && top_mm == 1 && seed_i >= 2);
+      bool act = mappable && !(full && top_mm == 0 && seed_i) && !(full && top_mm == 1 && seed_i >= kExitOneMismatch);
       Lookup lk;
       lk.npos = 0;
       lk.reg = empty_region();
       if (act) {
         uint32_t care[kCareWords];
         uint32_t slot, span;
-        seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
+        seed_query<NW>(lr.rd, seed_len_of(lr.repeats), seed_i, ga, Bd, sh.pcode4, care, slot, span);
         const uint32_t bk = bloom_key_of_care(care);
         if (!LITERAL && bloom_hit(sv.bloom[bloom_block(bk, sv.bloom_mask)], bk)) {
           deferred = true;
           mappable = false;
-          defer_iter = fi * 3 + seed_i;
+          defer_iter = fi * kPat + seed_i;
         } else {
-          seed_lookup_ex(iv, sv, care, slot, span, lr.repeats, lk, !LITERAL);
+          seed_lookup_ex(iv, sv, care, slot, span, seed_len_of(lr.repeats), lk, !LITERAL);
         }
       }
       const Region reg = lk.reg;
@@ -208,6 +208,7 @@ __device__ __forceinline__ void pe_flush(uint32_t shortv, uint32_t n_probe, uint
   block_flush_stats(shortv, n_probe, n_verified, n_big, shards);
 }
 
+#if WALT_SEEDPATTERN == 3  // pass 1 exists for the default pattern only (core.h probe_is_dangerous)
 // ---------------------------------------------------------------------------
 // pass 1 (see the header comment)
 // ---------------------------------------------------------------------------
@@ -385,6 +386,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   pe_flush(shortv, n_probe, n_verified, 0, stats);
 }
 
+#endif  // WALT_SEEDPATTERN == 3
+
 constexpr uint32_t kListHeapSlots = 768;  // HeapEnt slots per wave (6 KB): 15 heaps of top_k = 50, 2 of top_k = 300
 
 // pass 2 / 3: the reads of a list, one per lane, strand-major with the reference's exits.
@@ -401,12 +404,13 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uin
                                                           const uint32_t* __restrict__ list_count,
                                                           const uint32_t* __restrict__ list,
                                                           uint32_t* __restrict__ defer_count,
-                                                          uint32_t* __restrict__ defer_list) {
+                                                          uint32_t* __restrict__ defer_list, uint32_t all_reads) {
   __shared__ BlockShared sh;
   __shared__ HeapEnt s_heap[kBlock / 64][kListHeapSlots];  // the heaps of the reads a wave is working on
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
-  const uint32_t count = *list_count;
-  uint32_t n_probe = 0, n_verified = 0, n_big = 0;
+  // all_reads != 0 (seed patterns 5 and 7, which have no pass 1): every read 0 .. all_reads-1
+  const uint32_t count = all_reads ? all_reads : *list_count;
+  uint32_t n_probe = 0, n_verified = 0, n_big = 0, shortv = 0;
   // A short list is spread thin -- down to ONE read per wavefront: listed reads are the slow ones (large
   // regions verified by the whole wave, long chains of heap updates, literal searches), and 64 of them in
   // one wave run one after another.  rpw = reads per wave so that every wave of the grid has work.
@@ -421,12 +425,13 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uin
   for (uint64_t base = (uint64_t)wave * rpw; base < count; base += (uint64_t)total_waves * rpw) {
     const uint64_t i = base + lane;
     const bool valid = lane < rpw && i < count;
-    const uint32_t r = valid ? list[i] : 0;
+    const uint32_t r = valid ? (all_reads ? (uint32_t)i : list[i]) : 0;
     uint32_t len;
     pe_process<NW, LITERAL>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, heap, ranked,
                             heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
+    if (all_reads) shortv += (valid && len < kMinReadLen) ? 2u : 0u;  // paired.cpp:112-115, once per strand pass
   }
-  pe_flush(0, n_probe, n_verified, n_big, stats);
+  pe_flush(shortv, n_probe, n_verified, n_big, stats);
 }
 
 // Pairs whose candidate lists span more than kLightCombos (i, j) combinations are
@@ -648,6 +653,12 @@ static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const u
   uint32_t* lit_list = defer_list;
   uint32_t* lit_sorted = defer_list + stride;
   uint32_t* cplx_list = defer_list + 2 * stride;
+#if WALT_SEEDPATTERN != 3
+  (void)lit_sorted; (void)cplx_list; (void)cplx_count;
+  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(1536), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, nullptr, nullptr, n);
+  return WALT_OK;
+#else
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
   hipLaunchKernelGGL(k_pe_topk_dual<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, cplx_count,
@@ -655,11 +666,12 @@ static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const u
   const unsigned g2 = 1536;  // x 4 waves: the list kernels size their per-wave share from the list length
   hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, cplx_count, cplx_list, lit_count,
-                     lit_list);
+                     lit_list, 0u);
   launch_bin_deferred(lit_count, lit_list, lit_sorted, stream);
   hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
-                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr);
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr, 0u);
   return WALT_OK;
+#endif
 }
 
 static int pe_streams(walt_index* idx) {
@@ -702,10 +714,14 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     switch (nw) {
       case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+#if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
       case 10: rc = launch_pe_topk<10>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
       default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+#else
+      default: rc = launch_pe_topk<10>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+#endif
     }
     if (rc) return rc;
     launch_reduce_stats(w.shards[m], d_stats + 4 * m, stream);
@@ -733,6 +749,9 @@ static int pe_check_args(walt_index* idx, uint32_t top_k, uint32_t max_read_len,
   if (top_k < 2 || top_k > 300) return fail(WALT_EINVAL, "paired-end candidates must be in [2, 300]");  // walt.cpp:245-246
   *nw = nw_for_len(max_read_len);
   if (!*nw) return fail(WALT_EINVAL, "read length above 1024 is not supported");
+  if (max_read_len > kMaxReadLen)
+    return fail(WALT_EINVAL, "reads longer than " + std::to_string(kMaxReadLen) + " bases are outside the tables of seed pattern " +
+                                 std::to_string(kPat) + " (seedpattern.hpp)");
   return WALT_OK;
 }
 

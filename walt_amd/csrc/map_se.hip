@@ -179,17 +179,17 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
     const StrandView& sv = iv.s[strand_base + fi];
     const uint32_t strand_char = fi == 0 ? '+' : '-';
 #pragma unroll 1
-    for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
-      // mapping.cpp:250-257 (a `break` there leaves every later seed skipped too,
+    for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
+      // mapping.cpp:250-262 (a `break` there leaves every later seed skipped too,
       // which these per-seed predicates reproduce because best only improves)
-      bool act = mappable && !(best.mismatch == 0 && seed_i) && !(best.mismatch == 1 && seed_i >= 2);
+      bool act = mappable && !(best.mismatch == 0 && seed_i) && !(best.mismatch == 1 && seed_i >= kExitOneMismatch);
       Lookup lk;
       lk.npos = 0;
       lk.reg = empty_region();
       {
-        uint32_t care[kCareWords] = {0, 0, 0, 0};
+        uint32_t care[kCareWords] = {};
         uint32_t slot = 0, span = 0;
-        if (act) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
+        if (act) seed_query<NW>(lr.rd, seed_len_of(lr.repeats), seed_i, ga, Bd, sh.pcode4, care, slot, span);
         stamp(st, 1);
         bool is_bad = false;
         if (act && !LITERAL) {
@@ -201,13 +201,13 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
           if (is_bad) {
             deferred = true;
             mappable = false;
-            defer_iter = fi * 3 + seed_i;
+            defer_iter = fi * kPat + seed_i;
           } else if (ablate & 4u) {                       // diagnostic: no lookup at all
           } else if (ablate & 2u) {                       // diagnostic: directory only
             uint32_t lo = sv.dir[slot], hi = sv.dir[slot - span];
             if (lo > hi) lk.reg.l = 0;
           } else {
-            seed_lookup_ex(iv, sv, care, slot, span, lr.repeats, lk, !LITERAL);
+            seed_lookup_ex(iv, sv, care, slot, span, seed_len_of(lr.repeats), lk, !LITERAL);
           }
         }
         stamp(st, 3);
@@ -268,6 +268,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
   stamp(st, 7);
 }
 
+#if WALT_SEEDPATTERN == 3  // the seed-major pass-1 kernel is built for the default pattern (core.h probe_is_dangerous)
 // ---------------------------------------------------------------------------
 // Pass 1, seed-major: for each seed shift the '+' and '-' strand probes of a read
 // are issued TOGETHER (directory loads of both strands, then both slots' entries,
@@ -440,6 +441,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
   stamp(st, 7);
 }
 
+#endif  // WALT_SEEDPATTERN == 3
+
 __device__ __forceinline__ void flush_counters(const MapCounters& ctr, uint32_t shortv,
                                                unsigned long long* __restrict__ shards) {
   block_flush_stats(shortv, ctr.probes, ctr.verified, ctr.big, shards);
@@ -537,6 +540,7 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
   hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(kStatShards), 0, stream, d_shards, d_stats);
 }
 
+#if WALT_SEEDPATTERN == 3
 // pass 1: every read of the batch, one per lane
 template <int NW, bool DIAG>
 __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
@@ -592,6 +596,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   flush_counters(ctr, shortv, stats);
 }
 
+#endif  // WALT_SEEDPATTERN == 3
+
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
 template <int NW>
 __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
@@ -602,21 +608,26 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
                                                             BestMatch* __restrict__ out,
                                                             unsigned long long* __restrict__ stats,
                                                             const uint32_t* __restrict__ defer_count,
-                                                            const uint32_t* __restrict__ defer_list) {
+                                                            const uint32_t* __restrict__ defer_list,
+                                                            uint32_t all_reads) {
   __shared__ BlockShared sh;
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
-  const uint32_t count = *defer_count;
+  // all_reads != 0 (seed patterns 5 and 7, which have no pass 1): every read 0 .. all_reads-1
+  const uint32_t count = all_reads ? all_reads : *defer_count;
   MapCounters ctr = {0, 0, 0};
+  uint32_t shortv = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < count;
-    const uint32_t r = valid ? defer_list[i] : 0;
+    const uint32_t r = valid ? (all_reads ? i : defer_list[i]) : 0;
     uint32_t len;
     StampsT<false> st;
     se_process<NW, true, false>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, out, nullptr,
                                 nullptr, ctr, len, 0u, st);
+    // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 counts it when there is one
+    if (all_reads) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
-  flush_counters(ctr, 0, stats);
+  flush_counters(ctr, shortv, stats);
 }
 
 // ---------------------------------------------------------------------------
@@ -638,6 +649,13 @@ static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const ui
                          uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
                          hipStream_t stream) {
+#if WALT_SEEDPATTERN != 3
+  (void)defer_list; (void)stride;
+  const unsigned g2 = grid_for(n) < 4 * kLiteralGrid ? grid_for(n) : 4 * kLiteralGrid;
+  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, n);
+  return WALT_OK;
+#else
   unsigned pg = kPersistentGrid;
   if (const char* e = getenv("WALT_AMD_GRID")) pg = atoi(e) > 0 ? (unsigned)atoi(e) : grid_for(n);  // diagnostic knob
   const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
@@ -654,8 +672,9 @@ static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const ui
   else defer_sorted = defer_list;
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
   hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted);
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted, 0u);
   return WALT_OK;
+#endif
 }
 
 int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n, uint32_t max_read_len,
@@ -677,6 +696,9 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   }
   const int nw = nw_for_len(max_read_len);
   if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
+  if (max_read_len > kMaxReadLen)
+    return fail(WALT_EINVAL, "reads longer than " + std::to_string(kMaxReadLen) + " bases are outside the tables of seed pattern " +
+                                 std::to_string(kPat) + " (seedpattern.hpp)");
   WALT_HIP(hipSetDevice(idx->device));
   const uint64_t stride = se_stride(n);
   // workspace: [64 words: read errors, deferral control] [statistic shards] [deferred list] [sorted deferred
@@ -698,10 +720,14 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   switch (nw) {
     case 7: rc = launch_map_se<7>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 8: rc = launch_map_se<8>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+#if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
     case 10: rc = launch_map_se<10>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 16: rc = launch_map_se<16>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     case 32: rc = launch_map_se<32>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
     default: rc = launch_map_se<64>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+#else
+    default: rc = launch_map_se<10>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+#endif
   }
   if (rc) return rc;
   launch_reduce_stats(shards, reinterpret_cast<unsigned long long*>(d_stats), stream);
