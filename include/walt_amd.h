@@ -80,6 +80,18 @@ typedef struct walt_index walt_index;
 const char* walt_last_error(void);
 int walt_device_count(void);
 
+/* Seed pattern this library was compiled for.  The reference selects it at compile time
+ * (-D SEEDPATTERN3 / 5 / 7, src/walt/Makefile:34, FAQ.md:5-13; tables in seedpattern.hpp); here
+ * libwalt_amd.so is pattern 3 and libwalt_amd_sp5.so / libwalt_amd_sp7.so are the other two
+ * (make PAT=5 / PAT=7).  An index is specific to the pattern of the makedb that wrote it.
+ * walt_min_read_len() is MINIMALREADLEN (38 / 32 / 23; shorter reads count as too_short);
+ * walt_max_read_len() is the longest read a batch may hold: 1024, or 148 / 152 for patterns 5 / 7,
+ * beyond which the reference reads its seed tables out of bounds (mapping.cpp:238 caps the repeats
+ * at 50, the tables hold 28 / 20). */
+int walt_seed_pattern(void);
+uint32_t walt_min_read_len(void);
+uint32_t walt_max_read_len(void);
+
 /* Page-locked host memory for the read / result buffers a caller hands to
  * walt_map_se_batch / walt_map_pe_batch (the reference keeps them in
  * std::vector<std::string>, mapping.cpp:462-464); transfers from such buffers

@@ -14,13 +14,21 @@ def declared_functions():
     return sorted(set(names))
 
 
-def test_library_exports_every_declared_symbol():
+import pytest
+
+
+@pytest.mark.parametrize("pattern", [3, 5, 7])
+def test_library_exports_every_declared_symbol(pattern):
     import walt_amd
-    L = ctypes.CDLL(walt_amd.LIB_PATH)
+    L = ctypes.CDLL(walt_amd.lib_path(pattern))
     names = declared_functions()
     assert len(names) >= 18
     for nm in names:
-        assert hasattr(L, nm), "libwalt_amd.so does not export %s" % nm
+        assert hasattr(L, nm), "%s does not export %s" % (os.path.basename(walt_amd.lib_path(pattern)), nm)
+    assert L.walt_seed_pattern() == pattern
+    L.walt_min_read_len.restype = ctypes.c_uint32
+    L.walt_max_read_len.restype = ctypes.c_uint32
+    assert (L.walt_min_read_len(), L.walt_max_read_len()) == {3: (38, 1024), 5: (32, 148), 7: (23, 152)}[pattern]
 
 
 def test_struct_layouts_match_reference_types():

@@ -19,8 +19,29 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# WALT_AMD_LIB: another build of the same library (A/B timing of two builds on one GPU box; diagnostic)
-LIB_PATH = os.environ.get("WALT_AMD_LIB") or os.path.join(_HERE, "lib", "libwalt_amd.so")
+# Seed pattern: a compile-time choice of the library, like the reference's -D SEEDPATTERN3 / 5 / 7
+# (src/walt/Makefile:34, FAQ.md:5-13): libwalt_amd.so is pattern 3 (the default), libwalt_amd_sp5.so /
+# libwalt_amd_sp7.so the other two.  set_pattern() (or WALT_AMD_PATTERN) selects the library that lib(),
+# makedb() and the Index constructors use; an Index keeps the library it was made with.
+PATTERN = int(os.environ.get("WALT_AMD_PATTERN", "3"))
+
+
+def set_pattern(p):
+    global PATTERN
+    if p not in (3, 5, 7):
+        raise ValueError("seed pattern must be 3, 5 or 7")
+    PATTERN = p
+
+
+def lib_path(pattern=None):
+    pattern = PATTERN if pattern is None else pattern
+    # WALT_AMD_LIB: another build of the default library (A/B timing of two builds on one GPU box; diagnostic)
+    if pattern == 3 and os.environ.get("WALT_AMD_LIB"):
+        return os.environ["WALT_AMD_LIB"]
+    return os.path.join(_HERE, "lib", "libwalt_amd%s.so" % ("" if pattern == 3 else "_sp%d" % pattern))
+
+
+LIB_PATH = lib_path(3)
 
 WALT_OK = 0
 STRAND_CT00, STRAND_CT01, STRAND_GA10, STRAND_GA11 = 1, 2, 4, 8
@@ -70,7 +91,7 @@ class WaltError(RuntimeError):
         self.code = code
 
 
-_lib = None
+_libs = {}
 
 
 def _preload_hip_runtime():
@@ -95,21 +116,26 @@ def _preload_hip_runtime():
         ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
 
 
-def lib():
-    """Load libwalt_amd.so (fails loudly when it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(pattern=None):
+    """Load libwalt_amd.so / its _sp5 / _sp7 variant (fails loudly when it has not been built)."""
+    pattern = PATTERN if pattern is None else pattern
+    if pattern in _libs:
+        return _libs[pattern]
+    path = lib_path(pattern)
+    if not os.path.exists(path):
         raise ImportError(
             "walt_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(there is no CPU fallback for the hot path)" % LIB_PATH)
+            "(there is no CPU fallback for the hot path)" % path)
     _preload_hip_runtime()
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     c = ctypes
     vp, u32, u64, ci = c.c_void_p, c.c_uint32, c.c_uint64, c.c_int
     L.walt_last_error.restype = c.c_char_p
     L.walt_device_count.restype = ci
+    L.walt_min_read_len.restype = u32
+    L.walt_max_read_len.restype = u32
+    if L.walt_seed_pattern() != pattern:
+        raise ImportError("walt_amd: %s was built for seed pattern %d, not %d" % (path, L.walt_seed_pattern(), pattern))
     L.walt_index_open.argtypes = [c.c_char_p, ci, c.c_uint, ci, c.POINTER(vp)]
     L.walt_index_from_host.argtypes = [u32, vp, vp, vp, vp, vp, vp, ci, ci, c.POINTER(vp)]
     L.walt_index_close.argtypes = [vp]
@@ -147,7 +173,7 @@ def lib():
     L.walt_index_write.argtypes = [vp, c.c_char_p]
     L.walt_profile_enable.argtypes = [vp, ci]
     L.walt_profile_last.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_float)]
-    _lib = L
+    _libs[pattern] = L
     return L
 
 
@@ -182,15 +208,20 @@ def pack_reads(seqs):
 class Index:
     """Device-resident index (all selected strands stay in HBM)."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, L=None):
         self._h = handle
+        self._L = L if L is not None else lib()
+
+    def _ck(self, rc):
+        if rc != WALT_OK:
+            raise WaltError(rc, self._L.walt_last_error().decode("utf-8", "replace"))
 
     @classmethod
     def open(cls, dbindex_path, device=0, strands=STRANDS_ALL, dir_bits=-1):
         h = ctypes.c_void_p()
         _check(lib().walt_index_open(os.fsencode(dbindex_path), int(device), int(strands), int(dir_bits),
                                      ctypes.byref(h)))
-        return cls(h)
+        return cls(h, lib())
 
     @classmethod
     def from_host(cls, chrom_len, genome, counter, index, chrom_names=None, device=0, dir_bits=-1):
@@ -220,7 +251,7 @@ class Index:
                                           ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(ix, ctypes.c_void_p),
                                           ctypes.cast(sz, ctypes.c_void_p), int(device), int(dir_bits),
                                           ctypes.byref(h)))
-        return cls(h)
+        return cls(h, lib())
 
     @classmethod
     def build_device(cls, d_genome_ascii, chrom_len, chrom_names=None, device=0, strands=STRANDS_ALL,
@@ -235,33 +266,33 @@ class Index:
         h = ctypes.c_void_p()
         _check(lib().walt_index_build_device(d_genome_ascii, n, cl.ctypes.data, names, int(device), int(strands),
                                              int(dir_bits), ctypes.byref(h)))
-        return cls(h)
+        return cls(h, lib())
 
     def index_size(self, strand):
-        return lib().walt_index_size(self._h, strand)
+        return self._L.walt_index_size(self._h, strand)
 
     def export_strand(self, strand, want_genome=True):
         """(genome bytes, counter, index) numpy arrays of a resident strand (reference.cpp:302-322 layout)."""
         g = np.empty(self.genome_len, dtype=np.uint8) if want_genome else None
         cnt = np.empty((1 << 24) + 1, dtype=np.uint32)
         ix = np.empty(self.index_size(strand), dtype=np.uint32)
-        _check(lib().walt_index_export_strand(self._h, strand, _ptr(g), _ptr(cnt), _ptr(ix)))
+        self._ck(self._L.walt_index_export_strand(self._h, strand, _ptr(g), _ptr(cnt), _ptr(ix)))
         return g, cnt, ix
 
     def write(self, dbindex_path):
-        _check(lib().walt_index_write(self._h, os.fsencode(dbindex_path)))
+        self._ck(self._L.walt_index_write(self._h, os.fsencode(dbindex_path)))
 
     def profile_enable(self, on=True):
-        _check(lib().walt_profile_enable(self._h, int(on)))
+        self._ck(self._L.walt_profile_enable(self._h, int(on)))
 
     def profile_last(self):
         a, b = ctypes.c_float(0), ctypes.c_float(0)
-        _check(lib().walt_profile_last(self._h, ctypes.byref(a), ctypes.byref(b)))
+        self._ck(self._L.walt_profile_last(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
     def close(self):
         if self._h:
-            lib().walt_index_close(self._h)
+            self._L.walt_index_close(self._h)
             self._h = None
 
     def __del__(self):
@@ -276,33 +307,33 @@ class Index:
 
     @property
     def n_chrom(self):
-        return lib().walt_index_n_chrom(self._h)
+        return self._L.walt_index_n_chrom(self._h)
 
     @property
     def chrom_lengths(self):
-        return [lib().walt_index_chrom_len(self._h, i) for i in range(self.n_chrom)]
+        return [self._L.walt_index_chrom_len(self._h, i) for i in range(self.n_chrom)]
 
     @property
     def chrom_names(self):
-        return [lib().walt_index_chrom_name(self._h, i).decode() for i in range(self.n_chrom)]
+        return [self._L.walt_index_chrom_name(self._h, i).decode() for i in range(self.n_chrom)]
 
     @property
     def genome_len(self):
-        return lib().walt_index_genome_len(self._h)
+        return self._L.walt_index_genome_len(self._h)
 
     @property
     def device_bytes(self):
-        return lib().walt_index_device_bytes(self._h)
+        return self._L.walt_index_device_bytes(self._h)
 
     @property
     def dir_bits(self):
-        return lib().walt_index_dir_bits(self._h)
+        return self._L.walt_index_dir_bits(self._h)
 
     def bad_buckets(self, strand):
-        return lib().walt_index_bad_buckets(self._h, strand)
+        return self._L.walt_index_bad_buckets(self._h, strand)
 
     def outliers(self, strand):
-        return lib().walt_index_outliers(self._h, strand)
+        return self._L.walt_index_outliers(self._h, strand)
 
     # -- single-end -----------------------------------------------------------
     def map_se_batch(self, bases, offsets, ag_wildcard=False, max_mismatches=6, b=5000):
@@ -312,14 +343,14 @@ class Index:
         n = offsets.size - 1
         out = np.zeros(n, dtype=best_match_dtype)
         stats = np.zeros(1, dtype=batch_stats_dtype)
-        _check(lib().walt_map_se_batch(self._h, _ptr(bases), _ptr(offsets), n, int(bool(ag_wildcard)),
+        self._ck(self._L.walt_map_se_batch(self._h, _ptr(bases), _ptr(offsets), n, int(bool(ag_wildcard)),
                                        int(max_mismatches), int(b), _ptr(out), _ptr(stats)))
         return out, stats[0]
 
     def map_se_batch_device(self, d_bases, d_offsets, n, max_read_len, d_out, d_stats, d_workspace, stream=0,
                             ag_wildcard=False, max_mismatches=6, b=5000):
         """Device-pointer form (ints are HBM addresses, stream a hipStream_t value)."""
-        _check(lib().walt_map_se_batch_device(self._h, d_bases, d_offsets, int(n), int(max_read_len),
+        self._ck(self._L.walt_map_se_batch_device(self._h, d_bases, d_offsets, int(n), int(max_read_len),
                                               int(bool(ag_wildcard)), int(max_mismatches), int(b), d_out, d_stats,
                                               d_workspace, stream))
 
@@ -330,7 +361,7 @@ class Index:
 
     def map_pe_batch_device(self, d_bases1, d_offsets1, d_bases2, d_offsets2, n, max_read_len, d_out, d_stats,
                             d_workspace, stream=0, max_mismatches=6, b=5000, top_k=50, frag_range=1000):
-        _check(lib().walt_map_pe_batch_device(self._h, d_bases1, d_offsets1, d_bases2, d_offsets2, int(n),
+        self._ck(self._L.walt_map_pe_batch_device(self._h, d_bases1, d_offsets1, d_bases2, d_offsets2, int(n),
                                               int(max_read_len), int(max_mismatches), int(b), int(top_k),
                                               int(frag_range), d_out, d_stats, d_workspace, stream))
 
@@ -352,7 +383,7 @@ class Index:
             r2 = np.zeros((n, top_k), dtype=candidate_dtype)
             n1 = np.zeros(n, dtype=np.uint32)
             n2 = np.zeros(n, dtype=np.uint32)
-        _check(lib().walt_map_pe_batch(self._h, _ptr(bases1), _ptr(offsets1), _ptr(bases2), _ptr(offsets2), n,
+        self._ck(self._L.walt_map_pe_batch(self._h, _ptr(bases1), _ptr(offsets1), _ptr(bases2), _ptr(offsets2), n,
                                        int(max_mismatches), int(b), int(top_k), int(frag_range), _ptr(out),
                                        _ptr(r1), _ptr(n1), _ptr(r2), _ptr(n2), _ptr(stats)))
         if want_ranked:

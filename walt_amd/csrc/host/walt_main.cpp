@@ -36,7 +36,7 @@ using hostio::Sink;
 using hostio::View;
 
 static const uint32_t MAX_LINE_LENGTH = 1000;  // util.hpp:43
-static const int MINIMALREADLEN = 38;          // seedpattern.hpp:359
+#define MINIMALREADLEN walt_min_read_len()       // seedpattern.hpp:359 / 230 / 33 (38 / 32 / 23 by seed pattern)
 
 static void die(const string& msg) { throw std::runtime_error(msg); }
 static void check(int rc) { if (rc != WALT_OK) die(walt_last_error()); }

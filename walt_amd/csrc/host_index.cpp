@@ -393,6 +393,10 @@ extern "C" {
 
 const char* walt_last_error(void) { return last_error_cstr(); }
 
+int walt_seed_pattern(void) { return (int)kPat; }
+uint32_t walt_min_read_len(void) { return kMinReadLen; }
+uint32_t walt_max_read_len(void) { return kMaxReadLen; }
+
 // makedb main flow, makedb.cpp:128-159.  The reference seeds rand() from the
 // clock (makedb.cpp:88) and re-reads the genome for each of the four indexes
 // and once more for the head file; WALT_MAKEDB_SEED pins the seed instead.
