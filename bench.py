@@ -320,9 +320,16 @@ def main():
     ap.add_argument("--mode", choices=["se", "pe"], default="se", help="se = configs[1] (headline), pe = configs[2]")
     ap.add_argument("--top-k", type=int, default=50)
     ap.add_argument("--frag-range", type=int, default=1000)
+    ap.add_argument("--pattern", type=int, choices=[3, 5, 7], default=3,
+                    help="seed pattern (the reference's -D SEEDPATTERN3/5/7); 5 and 7 use libwalt_amd_sp5/_sp7.so, "
+                         "whose kernels search literally -- not the headline configuration")
     args = ap.parse_args()
 
     import walt_amd  # loads the HIP library (and the HIP runtime torch will share)
+    import refio
+    walt_amd.set_pattern(args.pattern)
+    refio.set_pattern(args.pattern)  # the oracle build of the cpu_baseline leg
+    walt_amd.lib()
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -432,8 +439,9 @@ def main():
     value = world * n * args.steps / elapsed
     if rank == 0:
         out = {
-            "metric": "mapped reads/sec (%d bp single-end, hg19-scale index, -m %d -b %d)" % (
-                args.read_len, args.max_mismatches, args.bucket),
+            "metric": "mapped reads/sec (%d bp single-end, hg19-scale index, -m %d -b %d)%s" % (
+                args.read_len, args.max_mismatches, args.bucket,
+                "" if args.pattern == 3 else ", seed pattern %d" % args.pattern),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
@@ -496,7 +504,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK, "traffic": traffic,
                                "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
-                               "kernel": "k_map_se<7> (+ literal pass)",
+                               "kernel": "k_map_se<7> (+ literal pass)" if args.pattern == 3 else "k_map_se_literal<7> (every read; literal search)",
                                "algorithmic_bytes_per_read": bytes_per_read,
                                "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate) + streamed read/result bytes",
                                "useful_bytes_per_read": useful, "per_read": per_read,
