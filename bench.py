@@ -462,7 +462,10 @@ def main():
         if os.path.exists(tj):
             try:
                 t = json.load(open(tj))
-                if t.get("reads_per_launch") == n and t.get("genome_bp") == int(sum(lens)):
+                # the stored PMC figure belongs to the headline workload only
+                if (t.get("reads_per_launch") == n and t.get("genome_bp") == int(sum(lens)) and args.read_len == 100
+                        and args.max_mismatches == 6 and args.bucket == 5000 and args.pattern == 3
+                        and not args.contigs):
                     traffic = t["hbm_bytes_per_launch"]
                     stored = t.get("algorithmic_per_read")
             except (ValueError, KeyError):
