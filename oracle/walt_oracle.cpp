@@ -259,7 +259,7 @@ void orc_se_map_read(const orc_strand* x, const char* org_read, uint32_t read_le
   if (read_len < ORC_MINREAD) { ++work->too_short; return; }
   uint32_t repeats, seed_len;
   orc_seed_geom(read_len, &repeats, &seed_len);
-  std::vector<char> buf(read_len + 1);
+  std::vector<char> buf(read_len + 8);  // zero slack: pattern 7 hashes up to offset 24 of a 23-base read (the reference exits in getBits there)
   char* read = buf.data();
   orc_convert(org_read, read_len, ag_wildcard, read);
 
@@ -377,7 +377,7 @@ static void orc_pe_map_read(const orc_strand* x, const char* org_read, uint32_t 
   if (read_len < ORC_MINREAD) { ++work->too_short; return; }
   uint32_t repeats, seed_len;
   orc_seed_geom(read_len, &repeats, &seed_len);
-  std::vector<char> buf(read_len + 1);
+  std::vector<char> buf(read_len + 8);  // zero slack: pattern 7 hashes up to offset 24 of a 23-base read (the reference exits in getBits there)
   char* read = buf.data();
   orc_convert(org_read, read_len, ag_wildcard, read);
 

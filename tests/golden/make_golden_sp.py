@@ -72,7 +72,43 @@ def dump_tables(pat, hdr="/root/reference/src/walt/seedpattern.hpp"):
         json.dump({"F2CAREDPOSITION": care, "F2NOCAREDPOSITION": nocare}, f)
 
 
+def make_short_reads(path):
+    """Reads at the lower end of the length range: MINIMALREADLEN is 32 / 23 for patterns 5 / 7, and reads of
+    32-33 (pattern 5) or 25-26 (pattern 7) bases have seeds of 10 / 8 care characters, fewer than the 12 that
+    getHashValue reads (util.hpp:175-182).  23- and 24-base reads are left out: with pattern 7 the reference
+    hashes beyond their end and exits in getBits (util.hpp:117-119) as soon as it reaches seed shift 5."""
+    import random
+    rng = random.Random(5577)
+    seqs, name, cur = [], None, []
+    for line in open(os.path.join(HERE, "g1.fa")):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            if name is not None:
+                seqs.append("".join(cur).upper())
+            name, cur = line, []
+        else:
+            cur.append(line)
+    seqs.append("".join(cur).upper())
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    with open(path, "w") as f:
+        k = 0
+        for L in list(range(25, 41)) * 12:
+            g = seqs[rng.randrange(3)]
+            p = rng.randrange(0, len(g) - L + 1)
+            s = g[p:p + L]
+            if rng.random() < 0.5:
+                s = "".join(comp[c] for c in reversed(s))
+            s = "".join("T" if (c == "C" and rng.random() < 0.95) else c for c in s)
+            if rng.random() < 0.4:
+                i = rng.randrange(L)
+                s = s[:i] + rng.choice([c for c in "ACGT" if c != s[i]]) + s[i + 1:]
+            f.write("@short_%d_len%d\n%s\n+\n%s\n" % (k, L, s, "I" * L))
+            k += 1
+
+
 CASES = {
+    "se_short_sam_au": ("sp_short", ["-sam", "-a", "-u"]),
+    "se_short_mr_au_m2": ("sp_short", ["-a", "-u", "-m", "2"]),
     "se_mr": ("sp_se_ct", []),
     "se_sam_au": ("sp_se_ct", ["-sam", "-a", "-u"]),
     "se_sam_au_m10": ("sp_se_ct", ["-sam", "-a", "-u", "-m", "10"]),
@@ -89,6 +125,7 @@ def main():
     n1 = filter_se("se_ct.fastq", "sp_se_ct.fastq")
     n2 = filter_se("se_ga.fastq", "sp_se_ga.fastq")
     n3 = filter_pe("pe_1.fastq", "pe_2.fastq", "sp_pe_1.fastq", "sp_pe_2.fastq")
+    make_short_reads(os.path.join(HERE, "sp_short.fastq"))
     print("read sets: %d + %d single-end, %d pairs" % (n1, n2, n3))
     for pat in (5, 7):
         sfx = "_sp%d" % pat

@@ -36,7 +36,8 @@ def pat(request, scratch):
         walt_amd.set_pattern(3)
 
 
-@pytest.mark.parametrize("case", ["se_mr", "se_sam_au", "se_sam_au_m10", "se_sam_au_b2", "se_ag_sam_au"])
+@pytest.mark.parametrize("case", ["se_mr", "se_sam_au", "se_sam_au_m10", "se_sam_au_b2", "se_ag_sam_au",
+                                  "se_short_sam_au", "se_short_mr_au_m2"])
 def test_gpu_se_reproduces_reference_files(pat, case):
     import walt_amd
     _, meta, db, idx, _ = pat

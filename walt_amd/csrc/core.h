@@ -163,6 +163,9 @@ WALT_HD uint32_t seed_repeats(uint32_t read_len) {
   return r < kMaxRepeats ? r : kMaxRepeats;
 }
 WALT_HD uint32_t seed_len_of(uint32_t repeats) { return repeats * kCareW; }  // mapping.cpp:239
+// characters a care string holds: the seed's, but never fewer than the 12 that getHashValue reads
+// (util.hpp:175-182 hashes F2CAREDPOSITION[0..11] whatever the seed length; patterns 5 / 7 have seeds of 10 / 8)
+WALT_HD uint32_t care_len_of(uint32_t seed_len) { return seed_len ? (seed_len > kKeyWeight ? seed_len : kKeyWeight) : 0u; }
 
 // 2-bit code of a sanitised base; 4 = not ACGT (getBits would exit, util.hpp:117-119)
 WALT_HD uint32_t base_code(uint8_t c) {
@@ -353,9 +356,6 @@ WALT_HD uint32_t outl_dir_hash(uint32_t h) {
   return x ^ (x >> 15);
 }
 WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
-  // patterns 5 and 7 always take the literal LowerBound/UpperBound search (the directory/key search and
-  // its exactness argument, DESIGN.md section 4, are built for pattern 3, the reference's default)
-  if (kPat != 3) return true;
   const uint32_t h = care[0] >> 8;
   if (bucket_is_bad(sv, h)) return true;
   uint32_t lo = 0, hi = sv.n_outl;  // first outlier of bucket h
@@ -545,7 +545,9 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
   out.npos = 0;
   out.reg = empty_region();
   uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
-  uint32_t n = seed_len - kKeyWeight;
+  // care characters behind the 12 hashed ones; none for the shortest reads of patterns 5 / 7 (seed_len 10 / 8:
+  // IndexRegion's loop over [F2SEEDKEYWEIGHT, seed_len) is empty there and the region is the whole bucket)
+  uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0u;
   if (!known_good && probe_is_dangerous(sv, care, seed_len)) {
     uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
     if (first == second) return;                         // mapping.cpp:271-272
@@ -600,7 +602,19 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
   }
   if (n > kKeyChars) {
     const uint32_t size = u - a + 1;
-    if (size <= kLookupPos && out.npos == size) {
+    if (kPat != 3 && size == 1) {
+      // IndexRegion on one slot (mapping.cpp:206-211): it survives iff every remaining care character
+      // matches.  No early exit, so the genome words are fetched together (pattern 7: up to 36 characters
+      // over 63 bases) instead of one dependent load per character as lit_region would.
+      const uint32_t pos = out.npos == 1 ? out.pos[0] : sv.ent[a].pos;
+      bool ok = true;
+      for (uint32_t p = kKeyWeight + kKeyChars; p < seed_len; ++p) {
+        const uint64_t q = (uint64_t)pos + care_pos(p);
+        const uint32_t c = g2_code(sv.g2, q < sv.genome_len ? q : 0);
+        ok = ok && q < sv.genome_len && c == care_char(care, p);
+      }
+      if (ok) { out.reg.l = a; out.reg.u = a; out.npos = 1; out.pos[0] = pos; } else { out.npos = 0; }
+    } else if (kPat == 3 && size <= kLookupPos && out.npos == size) {  // the two-word tail window is pattern 3's (15 bases)
       out.reg = lit_region_small(sv, care, seed_len, a, size, out.pos, out.npos);
     } else {
       out.npos = 0;

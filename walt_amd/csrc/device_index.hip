@@ -162,7 +162,6 @@ static int dev_alloc(walt_index* idx, T** p, uint64_t count) {
 }
 
 int choose_dir_bits(uint64_t max_index_size, int requested) {
-  if (kPat != 3) return (int)kMinDirBits;  // patterns 5 / 7 search literally (core.h probe_is_dangerous): smallest directory
   if (requested >= 0) return requested > (int)kMaxDirBits ? (int)kMaxDirBits : requested < (int)kMinDirBits ? (int)kMinDirBits : requested;
   // smallest Bd with index_size / 2^Bd <= 2 entries per directory slot (slots of
   // up to kScan entries are searched with independent loads, core.h)

@@ -91,15 +91,15 @@ WALT_HD bool pack_read(const uint8_t* bases, uint32_t len, uint32_t ga, uint32_t
   uint32_t seed_len = len >= kMinReadLen ? seed_len_of(seed_repeats(len)) : 0;
   for (uint32_t s = 0; s < kPat; ++s) {
     uint32_t care[kCareWords] = {};
-    for (uint32_t p = 0; p < seed_len; ++p) {
-      uint32_t i = s + care_pos(p);  // < len, see DESIGN.md
-      uint32_t c = base_code(bases[i]);
+    for (uint32_t p = 0; p < care_len_of(seed_len); ++p) {
+      uint32_t i = s + care_pos(p);  // < len, see DESIGN.md (pattern 7, 23/24-base reads: beyond -> 0)
+      uint32_t c = i < len ? base_code(bases[i]) : 0u;
       if (c > 3) c = 0;
       c = convert_code(c, ga);
       care[p >> 4] |= c << (30 - 2 * (p & 15));
     }
     uint32_t v_lo = 0, span = 0;
-    if (seed_len) dir_range(care, seed_len, ga, Bd, v_lo, span);
+    if (seed_len) dir_range(care, care_len_of(seed_len), ga, Bd, v_lo, span);
     uint32_t base = 1 + nw + s * kPerSeedWords;
     for (uint32_t w = 0; w < kCareWords; ++w) out[(base + w) * stride] = care[w];
     out[(base + kCareWords) * stride] = seed_len ? (1u << Bd) - v_lo : 0u;  // index into the reversed directory

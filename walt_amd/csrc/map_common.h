@@ -182,9 +182,10 @@ __device__ __forceinline__ void seed_query(const uint32_t* rd, uint32_t seed_len
     const int q = (int)(care_pos(i) - care_pos(0));  // compile-time offset in the shifted read
     care[i >> 4] |= ((shd[q >> 4] >> (2 * (q & 15))) & 3u) << (30 - 2 * (i & 15));
   }
+  const uint32_t care_len = care_len_of(seed_len);
 #pragma unroll
-  for (int w = 0; w < (int)kCareWords; ++w) {  // zero the characters at and beyond seed_len
-    const uint32_t keep = seed_len > 16u * w ? seed_len - 16u * w : 0u;
+  for (int w = 0; w < (int)kCareWords; ++w) {  // zero the characters at and beyond the seed (core.h care_len_of)
+    const uint32_t keep = care_len > 16u * w ? care_len - 16u * w : 0u;
     care[w] = keep >= 16 ? care[w] : (keep ? care[w] & ~(0xFFFFFFFFu >> (2 * keep)) : 0u);
   }
   // prefix code of the first 32 characters (>= 32 bits), 4 characters per table lookup
@@ -198,7 +199,7 @@ __device__ __forceinline__ void seed_query(const uint32_t* rd, uint32_t seed_len
   }
   const uint32_t v_lo = (uint32_t)(acc >> (nb - Bd));
   // code bits the seed itself carries: 2 per character minus the one-bit letters (T after C->T, A after G->A)
-  const uint32_t k = seed_len < 32 ? seed_len : 32;
+  const uint32_t k = care_len < 32 ? care_len : 32;
   uint32_t shorts = 0;
 #pragma unroll
   for (int w = 0; w < 2; ++w) {
@@ -317,7 +318,7 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
   out.npos = 0;
   out.reg = empty_region();
   if (p.ne == 0) return;
-  const uint32_t n = seed_len - kKeyWeight;
+  const uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0u;
   const uint32_t nk = n < kKeyChars ? n : kKeyChars;
   const uint64_t M = key_mask(nk);
   const uint64_t T = target_key(care) & M;

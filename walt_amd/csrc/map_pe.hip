@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uin
   for (uint64_t base = (uint64_t)wave * rpw; base < count; base += (uint64_t)total_waves * rpw) {
     const uint64_t i = base + lane;
     const bool valid = lane < rpw && i < count;
-    const uint32_t r = valid ? (all_reads ? (uint32_t)i : list[i]) : 0;
+    const uint32_t r = valid ? (all_reads ? (uint32_t)i : (list[i] & kDeferMask)) : 0;
     uint32_t len;
     pe_process<NW, LITERAL>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, heap, ranked,
                             heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
@@ -655,8 +655,12 @@ static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const u
   uint32_t* cplx_list = defer_list + 2 * stride;
 #if WALT_SEEDPATTERN != 3
   (void)lit_sorted; (void)cplx_list; (void)cplx_count;
+  // patterns 5 / 7: the strand-major list kernel over every read with the directory/key search, Bloom hits
+  // deferred to the literal list
+  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(1536), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, nullptr, nullptr, lit_count, lit_list, n);
   hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(1536), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
-                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, nullptr, nullptr, n);
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, nullptr, nullptr, 0u);
   return WALT_OK;
 #else
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
 #endif  // WALT_SEEDPATTERN == 3
 
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
-template <int NW>
+template <int NW, bool LITERAL = true>
 __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
                                                             const uint64_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ err, uint32_t strand_base,
@@ -607,23 +607,25 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
                                                             uint32_t b, const uint32_t* __restrict__ mask_table,
                                                             BestMatch* __restrict__ out,
                                                             unsigned long long* __restrict__ stats,
-                                                            const uint32_t* __restrict__ defer_count,
-                                                            const uint32_t* __restrict__ defer_list,
+                                                            uint32_t* __restrict__ defer_count,
+                                                            uint32_t* __restrict__ defer_list,
                                                             uint32_t all_reads) {
   __shared__ BlockShared sh;
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
-  // all_reads != 0 (seed patterns 5 and 7, which have no pass 1): every read 0 .. all_reads-1
+  // all_reads != 0 (seed patterns 5 and 7, which have no seed-major pass 1): every read 0 .. all_reads-1 with
+  // LITERAL = false (directory/key search; a Bloom hit appends the read to defer_list), then the list with
+  // LITERAL = true
   const uint32_t count = all_reads ? all_reads : *defer_count;
   MapCounters ctr = {0, 0, 0};
   uint32_t shortv = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < count;
-    const uint32_t r = valid ? (all_reads ? i : defer_list[i]) : 0;
+    const uint32_t r = valid ? (all_reads ? i : (defer_list[i] & kDeferMask)) : 0;
     uint32_t len;
     StampsT<false> st;
-    se_process<NW, true, false>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, out, nullptr,
-                                nullptr, ctr, len, 0u, st);
+    se_process<NW, LITERAL, false>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, out,
+                                   LITERAL ? nullptr : defer_count, LITERAL ? nullptr : defer_list, ctr, len, 0u, st);
     // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 counts it when there is one
     if (all_reads) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
@@ -650,10 +652,15 @@ static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const ui
                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
                          hipStream_t stream) {
 #if WALT_SEEDPATTERN != 3
-  (void)defer_list; (void)stride;
-  const unsigned g2 = grid_for(n) < 4 * kLiteralGrid ? grid_for(n) : 4 * kLiteralGrid;
-  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
+  (void)stride;
+  // patterns 5 / 7: strand-major kernel over every read with the directory/key search, Bloom hits deferred
+  // (untagged order) to the literal pass
+  const unsigned g1 = grid_for(n) < 4 * kLiteralGrid ? grid_for(n) : 4 * kLiteralGrid;
+  hipLaunchKernelGGL((k_map_se_literal<NW, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, n);
+  const unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+  hipLaunchKernelGGL((k_map_se_literal<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
+                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u);
   return WALT_OK;
 #else
   unsigned pg = kPersistentGrid;
@@ -685,6 +692,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   if ((idx->strand_mask & need) != need)
     return fail(WALT_EINVAL, ag ? "index opened without the _GA10/_GA11 strands" : "index opened without the _CT00/_CT01 strands");
   if (n == 0) return WALT_OK;
+  if (n > kDeferMask + 1) return fail(WALT_EINVAL, "more than 2^28 reads in one batch (the reference's -N limit is 10^8, walt.cpp:236-239)");
   {
     const char* ab = getenv("WALT_AMD_ABLATE");
     g_ablate = ab ? (uint32_t)atoi(ab) : 0u;
