@@ -105,7 +105,7 @@ void walt_host_free(void* p);
  * 324-351; call sites mapping.cpp:437,492 and paired.cpp:583,661): reads
  * <path> and the selected <path>_CT00/_CT01/_GA10/_GA11 files once, uploads
  * them to `device` and builds the derived HBM structures (2-bit genome, entry
- * keys, directory).  dir_bits = directory prefix length in bits (24..31); < 0
+ * keys, directory).  dir_bits = directory prefix length in bits (24..32); < 0
  * picks it from the index size. */
 int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, int dir_bits,
                     walt_index** out);

@@ -263,7 +263,7 @@ int walt_index_build_device(const void* d_genome_ascii, uint32_t n_chrom, const 
   head.genome_len = (uint32_t)total;
   head.max_index_size = head.genome_len;  // upper bound, used to pick the directory depth
   walt_index* idx = nullptr;
-  int rc = new_index(device, head, dir_bits, &idx);
+  int rc = new_index(device, head, dir_bits, __builtin_popcount(strand_mask & 15u), &idx);
   if (rc) return rc;
   std::vector<uint32_t> start(n_chrom + 1, 0);
   for (uint32_t i = 0; i < n_chrom; ++i) start[i + 1] = start[i] + chrom_len[i];

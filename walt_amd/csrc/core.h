@@ -75,7 +75,7 @@ constexpr uint32_t kKeyChars = 32;      // care chars 12..43 held in Ent::key
 constexpr uint32_t kMaskWords = 10;     // 160 bases of table-driven compare mask
 constexpr uint32_t kNumBuckets = 1u << 24;
 constexpr uint32_t kMinDirBits = 24;    // directory prefixes always cover the 12 hash characters
-constexpr uint32_t kMaxDirBits = 31;
+constexpr uint32_t kMaxDirBits = 32;    // 2^32 slots: slot numbers 1..2^32 are handled modulo 2^32 (core.h dir_top)
 constexpr uint32_t kEraseBucket = 500000;  // reference.cpp:211
 
 // F2CAREDPOSITION[i] (the tables of all three patterns follow their formula exactly; tests/golden/seedpattern*.json)
@@ -124,7 +124,7 @@ struct IndexView {
   const uint32_t* start_index;   // n_chrom + 1 (Genome::start_index, reference.hpp:55)
   uint32_t n_chrom;
   uint32_t dir_bits;             // Bd: directory prefix length in code bits
-  uint32_t dir_slots;            // S = 2^Bd
+  uint32_t dir_slots;            // S = 2^Bd modulo 2^32 (0 when Bd == 32; see dir_top)
   uint32_t pad_;
 };
 
@@ -212,6 +212,11 @@ WALT_HD uint32_t care_char(const uint32_t* care, uint32_t p) {
   v = w == 0 ? c0 : v;
   return (v >> (30 - 2 * (p & 15))) & 3u;
 }
+
+// S = 2^Bd as a 32-bit value: the reversed directory is addressed by slot = S - v for code prefix v, i.e.
+// slot in [1, S]; with Bd == 32 slot S is represented by 0 and all slot arithmetic is modulo 2^32.  The
+// directory pair of a slot is read at dir + (uint32_t)(slot - 1), which is exact for every slot in [1, 2^32].
+WALT_HD uint32_t dir_top(uint32_t Bd) { return Bd < 32 ? (1u << Bd) : 0u; }
 
 // Directory range of a care string of nchars characters: code prefixes
 // [v_lo, v_lo + span) (span is a power of two; 1 when the string has >= Bd bits).
@@ -555,8 +560,9 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     return;
   }
   (void)iv;
-  uint32_t lo = sv.dir[slot];
-  uint32_t hi = sv.dir[slot - span];
+  const uint32_t* dp = sv.dir + (uint32_t)(slot - 1u);  // slot S = 2^32 is held as 0 (dir_top)
+  uint32_t lo = dp[1];
+  uint32_t hi = span == 1 ? dp[0] : sv.dir[(uint32_t)(slot - span)];
   if (lo >= hi) return;
   uint32_t nk = n < kKeyChars ? n : kKeyChars;
   uint64_t M = key_mask(nk);

@@ -67,9 +67,9 @@ int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, con
 int alloc_strand_g2(walt_index* idx, uint32_t** g2_out, hipStream_t stream);
 int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32_t* d_counter,
                          const uint32_t* d_index, uint32_t index_size, hipStream_t stream);
-int new_index(int device, const IndexHead& head, int dir_bits, walt_index** out);
+int new_index(int device, const IndexHead& head, int dir_bits, int n_strands, walt_index** out);
 int finish_index_device(walt_index* idx);  // start_index, mask table
-int choose_dir_bits(uint64_t max_index_size, int requested);
+int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands);
 
 }  // namespace walt
 #endif

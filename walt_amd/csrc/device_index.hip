@@ -126,16 +126,19 @@ __global__ void k_check_buckets(const uint32_t* __restrict__ g2, const Ent* __re
 // Reversed directory, step 1: dir[S - v] = smallest index slot whose code prefix
 // is v (only run starts need to write; atomicMin because BAD buckets are not
 // monotone).  Step 2 (host driver): inclusive running minimum over dir[0..S].
-__global__ void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
+__global__ void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {  // grid-stride: n may exceed 2^32
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+__global__ void k_carry_min(uint32_t* __restrict__ p) {  // p[0] = min(p[-1], p[0]): joins two pieces of the running minimum
+  if (p[-1] < p[0]) p[0] = p[-1];
 }
 __global__ void k_dir_scatter(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t n, uint32_t ga,
                               uint32_t Bd, uint32_t* __restrict__ dir) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const uint32_t v = ent_prefix(g2, ent[j], ga, Bd);
-  if (j == 0 || ent_prefix(g2, ent[j - 1], ga, Bd) != v) atomicMin(&dir[(1u << Bd) - v], j);
+  if (j == 0 || ent_prefix(g2, ent[j - 1], ga, Bd) != v) atomicMin(&dir[(1ull << Bd) - v], j);
 }
 
 __global__ void k_popcount(const uint32_t* __restrict__ words, uint32_t n, unsigned long long* __restrict__ out) {
@@ -161,12 +164,17 @@ static int dev_alloc(walt_index* idx, T** p, uint64_t count) {
   return WALT_OK;
 }
 
-int choose_dir_bits(uint64_t max_index_size, int requested) {
+int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands) {
   if (requested >= 0) return requested > (int)kMaxDirBits ? (int)kMaxDirBits : requested < (int)kMinDirBits ? (int)kMinDirBits : requested;
   // smallest Bd with index_size / 2^Bd <= 2 entries per directory slot (slots of
-  // up to kScan entries are searched with independent loads, core.h)
+  // up to kScan entries are searched with independent loads, core.h) ...
   int B = (int)kMinDirBits;
-  while (B < (int)kMaxDirBits && max_index_size > (2ull << B)) ++B;
+  while (B < 31 && max_index_size > (2ull << B)) ++B;
+  // ... and one bit more (2^32 slots, 17 GB per strand) at hg19 scale when only two strands are resident
+  // (single-end mapping): half of the slots a non-matching probe lands in are then empty and cost no entry
+  // line (-7 % HBM lines per read).  Four resident strands (paired-end) stay at 31: 4 x 17 GB more would
+  // not leave room for the builder's temporaries and the batch workspace in 288 GB.
+  if (B == 31 && n_strands <= 2 && max_index_size > (1ull << 31)) B = 32;
   return B;
 }
 
@@ -185,7 +193,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   const uint32_t genome_len = idx->head.genome_len;
   const uint32_t ga = strand >= 2 ? 1u : 0u;
   const uint32_t Bd = idx->view.dir_bits;
-  const uint32_t slots = idx->view.dir_slots;
+  const uint64_t slots = 1ull << Bd;
   StrandView& sv = idx->view.s[strand];
   uint32_t *cnt = nullptr, *bad = nullptr, *dir = nullptr, *err = nullptr;
   uint64_t* bloom = nullptr;
@@ -225,19 +233,26 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
                          index_size, idx->view.start_index, n_chrom, bad);
   }
   // reversed directory: fill with "past the end", scatter run starts, running minimum
-  hipLaunchKernelGGL(k_fill_u32, dim3(grid_for((uint64_t)slots + 1)), dim3(kBlock), 0, stream, dir,
-                     (uint64_t)slots + 1, index_size);
+  hipLaunchKernelGGL(k_fill_u32, dim3(1u << 16), dim3(kBlock), 0, stream, dir, (uint64_t)slots + 1, index_size);
   if (index_size)
     hipLaunchKernelGGL(k_dir_scatter, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, ent, index_size, ga,
                        Bd, dir);
   {
+    // running minimum in pieces of 2^30 elements (a 2^32-slot directory has more elements than a 32-bit
+    // count holds); a piece starts from the minimum the previous one ended with
+    const uint64_t total = slots + 1, piece = 1ull << 30;
     size_t tmp_bytes = 0;
-    WALT_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, dir, dir, (size_t)slots + 1, rocprim::minimum<uint32_t>(),
-                                     stream));
+    WALT_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, dir, dir, (size_t)(total < piece ? total : piece),
+                                     rocprim::minimum<uint32_t>(), stream));
     void* tmp = nullptr;
     WALT_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    hipError_t se = rocprim::inclusive_scan(tmp, tmp_bytes, dir, dir, (size_t)slots + 1,
-                                            rocprim::minimum<uint32_t>(), stream);
+    hipError_t se = hipSuccess;
+    for (uint64_t at = 0; at < total && se == hipSuccess; at += piece) {
+      const uint64_t cnt = total - at < piece ? total - at : piece;
+      if (at) hipLaunchKernelGGL(k_carry_min, dim3(1), dim3(1), 0, stream, dir + at);
+      size_t tb = tmp_bytes;
+      se = rocprim::inclusive_scan(tmp, tb, dir + at, dir + at, (size_t)cnt, rocprim::minimum<uint32_t>(), stream);
+    }
     hipError_t sy = hipStreamSynchronize(stream);
     hipFree(tmp);
     WALT_HIP(se);
@@ -347,7 +362,7 @@ int finish_index_device(walt_index* idx) {
   return WALT_OK;
 }
 
-int new_index(int device, const IndexHead& head, int dir_bits, walt_index** out) {
+int new_index(int device, const IndexHead& head, int dir_bits, int n_strands, walt_index** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(WALT_EHIP, "no HIP device available (the walt_amd hot path has no CPU fallback)");
@@ -357,8 +372,8 @@ int new_index(int device, const IndexHead& head, int dir_bits, walt_index** out)
   idx->device = device;
   idx->head = head;
   memset(&idx->view, 0, sizeof(idx->view));
-  idx->view.dir_bits = (uint32_t)choose_dir_bits(head.max_index_size, dir_bits);
-  idx->view.dir_slots = 1u << idx->view.dir_bits;
+  idx->view.dir_bits = (uint32_t)choose_dir_bits(head.max_index_size, dir_bits, n_strands);
+  idx->view.dir_slots = dir_top(idx->view.dir_bits);
   // chromosome starts are needed by the strand builders (outlier detection)
   const uint32_t n = (uint32_t)idx->head.lengths.size();
   idx->start_index.assign(n + 1, 0);
@@ -576,7 +591,7 @@ int walt_index_open(const char* dbindex_path, int device, unsigned strand_mask, 
   int rc = read_index_head(dbindex_path, head);
   if (rc) return rc;
   walt_index* idx = nullptr;
-  if ((rc = new_index(device, head, dir_bits, &idx))) return rc;
+  if ((rc = new_index(device, head, dir_bits, __builtin_popcount(strand_mask & 15u), &idx))) return rc;
   static const char* sfx[4] = {"_CT00", "_CT01", "_GA10", "_GA11"};
   {
     StreamRing ring;
@@ -615,7 +630,9 @@ int walt_index_from_host(uint32_t n_chrom, const uint32_t* chrom_len, const char
   for (int s = 0; s < 4; ++s)
     if (genome[s] && index_size[s] > head.max_index_size) head.max_index_size = index_size[s];
   walt_index* idx = nullptr;
-  int rc = new_index(device, head, dir_bits, &idx);
+  int n_strands = 0;
+  for (int s = 0; s < 4; ++s) n_strands += genome[s] ? 1 : 0;
+  int rc = new_index(device, head, dir_bits, n_strands, &idx);
   if (rc) return rc;
   for (int s = 0; s < 4 && !rc; ++s) {
     if (!genome[s]) continue;

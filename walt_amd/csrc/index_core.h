@@ -102,7 +102,7 @@ WALT_HD bool pack_read(const uint8_t* bases, uint32_t len, uint32_t ga, uint32_t
     if (seed_len) dir_range(care, care_len_of(seed_len), ga, Bd, v_lo, span);
     uint32_t base = 1 + nw + s * kPerSeedWords;
     for (uint32_t w = 0; w < kCareWords; ++w) out[(base + w) * stride] = care[w];
-    out[(base + kCareWords) * stride] = seed_len ? (1u << Bd) - v_lo : 0u;  // index into the reversed directory
+    out[(base + kCareWords) * stride] = seed_len ? dir_top(Bd) - v_lo : 0u;  // index into the reversed directory
     out[(base + kCareWords + 1) * stride] = span;
   }
   return ok;

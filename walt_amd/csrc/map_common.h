@@ -212,7 +212,7 @@ __device__ __forceinline__ void seed_query(const uint32_t* rd, uint32_t seed_len
   }
   const uint32_t nb_seed = 2 * k - shorts;
   span = seed_len ? (nb_seed < Bd ? 1u << (Bd - nb_seed) : 1u) : 0u;
-  slot = seed_len ? (1u << Bd) - (nb_seed < Bd ? (v_lo >> (Bd - nb_seed)) << (Bd - nb_seed) : v_lo) : 0u;
+  slot = seed_len ? dir_top(Bd) - (nb_seed < Bd ? (v_lo >> (Bd - nb_seed)) << (Bd - nb_seed) : v_lo) : 0u;
 }
 
 // getChromID (reference.cpp:43-60) with a fixed number of steps: largest l with
@@ -291,12 +291,12 @@ __device__ __forceinline__ void probe_issue(const StrandView& sv, bool need, uin
                                             uint32_t& lo, uint32_t& hi) {
   hi = lo = 0;
   if (need) {  // idle lanes issue no load (see verify_nobranch)
-    const uint32_t* p = sv.dir + (slot - 1);  // slot >= 1 whenever a seed exists
+    const uint32_t* p = sv.dir + (uint32_t)(slot - 1u);  // slot in [1, 2^Bd]; 2^32 is held as 0 (core.h dir_top)
     uint32_t pair[2];
     __builtin_memcpy(pair, p, 8);
     hi = pair[0];
     lo = pair[1];
-    if (span != 1) hi = sv.dir[slot - span];
+    if (span != 1) hi = sv.dir[(uint32_t)(slot - span)];
   }
 }
 __device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p) {

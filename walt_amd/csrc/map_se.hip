@@ -204,7 +204,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
             defer_iter = fi * kPat + seed_i;
           } else if (ablate & 4u) {                       // diagnostic: no lookup at all
           } else if (ablate & 2u) {                       // diagnostic: directory only
-            uint32_t lo = sv.dir[slot], hi = sv.dir[slot - span];
+            uint32_t lo = (sv.dir + (uint32_t)(slot - 1u))[1], hi = sv.dir[(uint32_t)(slot - span)];
             if (lo > hi) lk.reg.l = 0;
           } else {
             seed_lookup_ex(iv, sv, care, slot, span, seed_len_of(lr.repeats), lk, !LITERAL);
