@@ -296,3 +296,29 @@ def test_gpu_crowded_chromosome_ends(wa, scratch):
             for j in range(len(reads)):
                 assert np.array_equal(g1[j][:no[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), (k, j)
         idx.close()
+
+
+def test_gpu_directory_of_2_pow_32_slots(wa, g1_db, scratch):
+    """dir_bits = 32: slot numbers run to 2^32 and are handled modulo 2^32 (core.h dir_top); the all-zero code
+    prefix (poly-A seeds on the G->A strands, where A is the one-bit letter) is the slot that wraps.  Same
+    records as the oracle, single-end on both strand pairs and paired-end."""
+    path = os.path.join(scratch, "g1_prod.dbindex")
+    if not os.path.exists(path):
+        wa.makedb(os.path.join(refio.GOLDEN, "g1.fa"), path, threads=4)
+    idx = wa.Index.open(path, device=0, strands=wa.STRANDS_ALL, dir_bits=32)
+    assert idx.dir_bits == 32
+    extra = ["A" * 100, "A" * 60 + "ACGTTGCA" * 5, "T" * 100, "G" * 38, "C" * 64, "AG" * 50, "A" * 38]
+    for fq, ag in (("se_ct.fastq", False), ("se_ga.fastq", True)):
+        _, seqs, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, fq), 10 ** 7))
+        seqs = list(seqs) + extra
+        want, work = refio.oracle_se(g1_db, seqs, ag=ag, max_mm=6, b=5000)
+        got, stats = idx.map_se_batch(*wa.pack_reads(seqs), ag_wildcard=ag, max_mismatches=6, b=5000)
+        assert_best_equal(got, want, "%s dir_bits=32" % fq)
+    _, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 300))
+    _, s2, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_2.fastq"), 300))
+    s1, s2 = list(s1) + extra, list(s2) + extra[::-1]
+    res, _ = idx.map_pe_batch(*wa.pack_reads(s1), *wa.pack_reads(s2))
+    wantp, _, _ = refio.oracle_pe(g1_db, s1, s2)
+    for f in ("best_times", "frag_len", "pair_mm"):
+        assert np.array_equal(res[f], wantp[f]), f
+    idx.close()
