@@ -102,6 +102,12 @@ struct StrandView {
   const uint64_t* bloom;  // blocked Bloom filter (64-bit blocks) over the probes that can be dangerous
   uint32_t bloom_mask;    // number of blocks - 1 (a power of two, sized by the number of keys)
   const uint32_t* pre;    // kPreBits-bit prefilter of the same keys, copied into LDS by the pass-1 kernels
+  // Optional direct-mapped slot table (nullptr when not built): one 12-byte record per directory slot,
+  // tab[3 (slot - 1) ..] = the slot's only entry {key_hi, key_lo, pos} when it holds exactly one, else
+  // {first index slot, number of entries, kTabMulti}.  With 0.72 entries per slot (2^32 slots at hg19
+  // scale) a probe then needs ONE line where directory pair + entry needed two: half of the probes that hit
+  // and two thirds of the non-empty misses end in a single-entry slot.  51.5 GB per strand at 2^32 slots.
+  const uint32_t* tab;
   const struct Outlier* outl;  // chromosome-end entries, sorted by bucket (see probe_is_dangerous)
   const uint32_t* outl_dir;    // open-addressing table bucket -> first outlier: pairs {bucket + 1 (0 = free), index}
   uint32_t outl_dir_mask;      // pairs - 1 (power of two); outl_dir == nullptr: binary search
@@ -314,6 +320,7 @@ WALT_HD bool bucket_is_bad(const StrandView& sv, uint32_t h) { return (sv.bad[h 
 // among the inserted values); a BAD bucket inserts all 256.  Two characters were not enough: in the
 // 3-letter, T-heavy converted alphabet 1 % of the reads shared (bucket, 2 chars) with some
 // chromosome end.
+constexpr uint32_t kTabMulti = 0xFFFFFFFFu;  // never a genome position (genomes stop below 2^32 - 256)
 constexpr uint32_t kBloomMinBlocks = 1u << 10, kBloomMaxBlocks = 1u << 20;  // 8 KB .. 8 MB
 WALT_HD uint32_t bloom_blocks_for(uint64_t n_keys) {  // >= 2 blocks (128 bits) per key, power of two
   uint64_t want = 2 * n_keys;

@@ -130,6 +130,20 @@ __global__ void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {  
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     p[i] = v;
 }
+// slot table (core.h StrandView::tab) from the finished directory: record t belongs to slot t + 1
+__global__ void k_make_table(const uint32_t* __restrict__ dir, const Ent* __restrict__ ent, uint64_t slots,
+                             uint32_t* __restrict__ tab) {
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < slots; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t hi = dir[t], lo = dir[t + 1];
+    const uint32_t ne = hi > lo ? hi - lo : 0u;
+    uint32_t w0 = lo, w1 = ne, w2 = kTabMulti;
+    if (ne == 1) {
+      const Ent e = ent[lo];
+      w0 = e.key_hi; w1 = e.key_lo; w2 = e.pos;
+    }
+    tab[3 * t] = w0; tab[3 * t + 1] = w1; tab[3 * t + 2] = w2;
+  }
+}
 __global__ void k_carry_min(uint32_t* __restrict__ p) {  // p[0] = min(p[-1], p[0]): joins two pieces of the running minimum
   if (p[-1] < p[0]) p[0] = p[-1];
 }
@@ -258,6 +272,28 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     WALT_HIP(se);
     WALT_HIP(sy);
   }
+  // Slot table: built when the directory has 2^32 slots (where 0.72 entries per slot make single-entry
+  // slots the common case) and the device keeps >= 48 GB free afterwards for the other strand's builder
+  // temporaries and the batches; WALT_AMD_TABLE=1 / 0 forces it on (any directory depth; tests) / off.
+  uint32_t* tab = nullptr;
+  {
+    const char* e = getenv("WALT_AMD_TABLE");
+    const uint64_t tab_bytes = 12ull * slots;
+    bool want = false;
+    if (e) {
+      want = atoi(e) != 0;
+    } else if (Bd == 32) {
+      size_t free_b = 0, total_b = 0;
+      WALT_HIP(hipMemGetInfo(&free_b, &total_b));
+      want = free_b >= tab_bytes + (48ull << 30);
+    }
+    if (want && index_size) {
+      if ((rc = dev_alloc(idx, &tab, 3ull * slots))) return rc;
+      hipLaunchKernelGGL(k_make_table, dim3(1u << 16), dim3(kBlock), 0, stream, dir, ent, slots, tab);
+      WALT_HIP(hipStreamSynchronize(stream));
+      WALT_HIP(hipGetLastError());
+    }
+  }
   unsigned long long* d_cnt64 = nullptr;
   WALT_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt64), sizeof(unsigned long long)));
   WALT_HIP(hipMemsetAsync(d_cnt64, 0, sizeof(unsigned long long), stream));
@@ -326,7 +362,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   idx->outliers[strand] = n_outl;
   sv.outl = outl; sv.n_outl = n_outl;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
-  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1; sv.pre = pre;
+  sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1; sv.pre = pre; sv.tab = tab;
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }

@@ -281,27 +281,46 @@ __device__ __forceinline__ void block_flush_stats(uint32_t a0, uint32_t a1, uint
 // ---- slot probes of the seed-major kernels (map_se.hip se_process_dual, map_pe.hip pe_process_dual) ----
 struct SlotProbe {
   uint32_t lo, ne;      // slot range [lo, lo+ne) of the directory lookup (ne == 0: nothing)
-  Ent e[kScan];         // its first entries (clamped indices, independent loads)
+  Ent e[kScan];         // its first entries (independent loads)
+  bool inl;             // e[0] came inline with the slot table record (single-entry slot; lo is not known)
 };
 
 // directory pair of a probe: dir[slot] (start) and dir[slot - span] (end).  span is 1
 // for every seed of >= dir_bits code bits, so the pair is ONE 8-byte load of
 // dir[slot-1 .. slot]; short seeds (span > 1) fetch the far end separately.
+// With a slot table (core.h StrandView::tab) the pair comes from the slot's 12-byte record, which holds the
+// entry itself when the slot has exactly one: then lo = 0, hi = 1 and p.e[0] is already there.
 __device__ __forceinline__ void probe_issue(const StrandView& sv, bool need, uint32_t slot, uint32_t span,
-                                            uint32_t& lo, uint32_t& hi) {
-  hi = lo = 0;
+                                            SlotProbe& p, uint32_t& hi) {
+  hi = p.lo = 0;
+  p.inl = false;
+  p.e[0].key_hi = p.e[0].key_lo = p.e[0].pos = 0;
   if (need) {  // idle lanes issue no load (see verify_nobranch)
-    const uint32_t* p = sv.dir + (uint32_t)(slot - 1u);  // slot in [1, 2^Bd]; 2^32 is held as 0 (core.h dir_top)
-    uint32_t pair[2];
-    __builtin_memcpy(pair, p, 8);
-    hi = pair[0];
-    lo = pair[1];
-    if (span != 1) hi = sv.dir[(uint32_t)(slot - span)];
+    if (sv.tab != nullptr && span == 1) {
+      uint32_t w[3];
+      __builtin_memcpy(w, sv.tab + 3ull * (uint32_t)(slot - 1u), 12);
+      if (w[2] == kTabMulti) {
+        p.lo = w[0];
+        hi = w[0] + w[1];
+      } else {
+        p.e[0].key_hi = w[0]; p.e[0].key_lo = w[1]; p.e[0].pos = w[2];
+        p.inl = true;
+        hi = 1;
+      }
+    } else {
+      const uint32_t* q = sv.dir + (uint32_t)(slot - 1u);  // slot in [1, 2^Bd]; 2^32 is held as 0 (core.h dir_top)
+      uint32_t pair[2];
+      __builtin_memcpy(pair, q, 8);
+      hi = pair[0];
+      p.lo = pair[1];
+      if (span != 1) hi = sv.dir[(uint32_t)(slot - span)];
+    }
   }
 }
 __device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p) {
+  if (p.ne && !p.inl) p.e[0] = sv.ent[p.lo];
 #pragma unroll
-  for (uint32_t j = 0; j < kScan; ++j) {
+  for (uint32_t j = 1; j < kScan; ++j) {
     Ent z; z.key_hi = z.key_lo = z.pos = 0;
     p.e[j] = z;
     if (j < p.ne) p.e[j] = sv.ent[p.lo + j];

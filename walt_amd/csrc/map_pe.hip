@@ -261,8 +261,8 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     if (need && prefilter_hit(pf, 1, bkey)) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
     SlotProbe pp, pm;
     uint32_t hi_p, hi_m;
-    probe_issue(svp, need, slot, span, pp.lo, hi_p);
-    probe_issue(svm, need, slot, span, pm.lo, hi_m);
+    probe_issue(svp, need, slot, span, pp, hi_p);
+    probe_issue(svm, need, slot, span, pm, hi_m);
     const bool bad_p = need && bloom_hit(bw_p, bkey);
     const bool bad_m = need && bloom_hit(bw_m, bkey);
     if (bad_p || bad_m) {

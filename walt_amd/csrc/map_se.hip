@@ -337,8 +337,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     if (need_m && prefilter_hit(pf, 1, bkey)) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
     SlotProbe pp, pm;
     uint32_t hi_p, hi_m;
-    probe_issue(svp, need_p, slot, span, pp.lo, hi_p);
-    probe_issue(svm, need_m, slot, span, pm.lo, hi_m);
+    probe_issue(svp, need_p, slot, span, pp, hi_p);
+    probe_issue(svm, need_m, slot, span, pm, hi_m);
     const bool bad_p = need_p && bloom_hit(bw_p, bkey);
     const bool bad_m = need_m && bloom_hit(bw_m, bkey);
     if (bad_p || bad_m) {
