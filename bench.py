@@ -320,11 +320,15 @@ def main():
     ap.add_argument("--mode", choices=["se", "pe"], default="se", help="se = configs[1] (headline), pe = configs[2]")
     ap.add_argument("--top-k", type=int, default=50)
     ap.add_argument("--frag-range", type=int, default=1000)
+    ap.add_argument("--slot-table", action="store_true",
+                    help="build the opt-in direct-mapped slot table (WALT_AMD_TABLE=1: +51.5 GB per strand at hg19 scale)")
     ap.add_argument("--pattern", type=int, choices=[3, 5, 7], default=3,
                     help="seed pattern (the reference's -D SEEDPATTERN3/5/7); 5 and 7 use libwalt_amd_sp5/_sp7.so, "
                          "whose kernels search literally -- not the headline configuration")
     args = ap.parse_args()
 
+    if args.slot_table:
+        os.environ["WALT_AMD_TABLE"] = "1"
     import walt_amd  # loads the HIP library (and the HIP runtime torch will share)
     import refio
     walt_amd.set_pattern(args.pattern)
@@ -465,7 +469,7 @@ def main():
                 # the stored PMC figure belongs to the headline workload only
                 if (t.get("reads_per_launch") == n and t.get("genome_bp") == int(sum(lens)) and args.read_len == 100
                         and args.max_mismatches == 6 and args.bucket == 5000 and args.pattern == 3
-                        and not args.contigs):
+                        and not args.contigs and not os.environ.get("WALT_AMD_TABLE")):
                     traffic = t["hbm_bytes_per_launch"]
                     stored = t.get("algorithmic_per_read")
             except (ValueError, KeyError):
@@ -498,7 +502,8 @@ def main():
             # ~540 binary-search steps per read and is kept below as `survey_8d` (it exceeds the peak because
             # the directory replaces those steps).
             P, S, C = per_read["probes"], per_read["search_steps"], per_read["candidates"]
-            lines = 2.0 * P + C
+            table = bool(os.environ.get("WALT_AMD_TABLE", "0") not in ("", "0"))
+            lines = (1.0 if table else 2.0) * P + C  # with the slot table a probe can be served by one line
             bytes_per_read = 128.0 * lines + args.read_len / 4.0 + 16
             useful = args.read_len / 4.0 + 16 + P * (8 + 12) + C * 32.0  # the same accesses counted in useful bytes
             kern_s = float(np.mean(map_ms)) / 1e3
@@ -509,7 +514,7 @@ def main():
                                "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
                                "kernel": "k_map_se<7> (+ literal pass)" if args.pattern == 3 else "k_map_se_literal<7> (every read; literal search)",
                                "algorithmic_bytes_per_read": bytes_per_read,
-                               "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate) + streamed read/result bytes",
+                               "granularity": "128-byte line per dependent gather (%d per probe, 1 per candidate) + streamed read/result bytes" % (1 if table else 2),
                                "useful_bytes_per_read": useful, "per_read": per_read,
                                "per_read_source": per_read_src,
                                "survey_8d": {"bytes_per_read": survey, "achieved": survey * n / kern_s / 1e9,

@@ -322,3 +322,34 @@ def test_gpu_directory_of_2_pow_32_slots(wa, g1_db, scratch):
     for f in ("best_times", "frag_len", "pair_mm"):
         assert np.array_equal(res[f], wantp[f]), f
     idx.close()
+
+
+def test_gpu_slot_table(wa, g1_db, scratch, monkeypatch):
+    """WALT_AMD_TABLE=1: the opt-in direct-mapped slot table (single-entry slots inline, core.h
+    StrandView::tab) gives the same records as the oracle, single-end and paired-end, at two directory depths."""
+    monkeypatch.setenv("WALT_AMD_TABLE", "1")
+    path = os.path.join(scratch, "g1_prod.dbindex")
+    if not os.path.exists(path):
+        wa.makedb(os.path.join(refio.GOLDEN, "g1.fa"), path, threads=4)
+    _, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 400))
+    _, s2, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_2.fastq"), 400))
+    wantp, _, _ = refio.oracle_pe(g1_db, s1, s2)
+    for D in (24, 28):
+        idx = wa.Index.open(path, device=0, strands=wa.STRANDS_ALL, dir_bits=D)
+        plain_bytes = None
+        for fq, ag in (("se_ct.fastq", False), ("se_ga.fastq", True)):
+            _, seqs, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, fq), 10 ** 7))
+            want, _ = refio.oracle_se(g1_db, seqs, ag=ag, max_mm=6, b=5000)
+            got, _ = idx.map_se_batch(*wa.pack_reads(seqs), ag_wildcard=ag, max_mismatches=6, b=5000)
+            assert_best_equal(got, want, "%s slot table D=%d" % (fq, D))
+        res, _ = idx.map_pe_batch(*wa.pack_reads(s1), *wa.pack_reads(s2))
+        for f in ("best_times", "frag_len", "pair_mm"):
+            assert np.array_equal(res[f], wantp[f]), f
+        # the table is really there: 12 bytes per slot and strand on top of the plain index
+        monkeypatch.setenv("WALT_AMD_TABLE", "0")
+        plain = wa.Index.open(path, device=0, strands=wa.STRANDS_ALL, dir_bits=D)
+        plain_bytes = plain.device_bytes
+        plain.close()
+        monkeypatch.setenv("WALT_AMD_TABLE", "1")
+        assert idx.device_bytes - plain_bytes >= 4 * 12 * (1 << D)
+        idx.close()

@@ -102,7 +102,7 @@ struct StrandView {
   const uint64_t* bloom;  // blocked Bloom filter (64-bit blocks) over the probes that can be dangerous
   uint32_t bloom_mask;    // number of blocks - 1 (a power of two, sized by the number of keys)
   const uint32_t* pre;    // kPreBits-bit prefilter of the same keys, copied into LDS by the pass-1 kernels
-  // Optional direct-mapped slot table (nullptr when not built): one 12-byte record per directory slot,
+  // Optional direct-mapped slot table (nullptr unless WALT_AMD_TABLE=1): one 12-byte record per directory slot,
   // tab[3 (slot - 1) ..] = the slot's only entry {key_hi, key_lo, pos} when it holds exactly one, else
   // {first index slot, number of entries, kTabMulti}.  With 0.72 entries per slot (2^32 slots at hg19
   // scale) a probe then needs ONE line where directory pair + entry needed two: half of the probes that hit
