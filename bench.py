@@ -259,6 +259,84 @@ def cpu_baseline(idx, reads_host, read_len, n_sample, lens, max_mm, b):
     return out, work[0], elapsed, cores
 
 
+def reference_binary_leg(idx, d_bases, d_out, read_len, n_ref, max_mm, b, cores):
+    """The REAL reference binary (oracle/_ref/walt, built from the reference sources by oracle/Makefile.ref;
+    test infrastructure) on the same box in the same run: the resident index is written in the reference's
+    .dbindex format to a RAM-backed scratch directory, the first n_ref reads of the batch go to a FASTQ file,
+    `walt -t <cores>` maps them, and its .mapstats is compared with the GPU's records for the same reads.
+    Returns a dict (or a dict with "skipped")."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "walt")
+    if not os.path.exists(ref_bin):
+        return {"skipped": "oracle/_ref/walt is not built"}
+    need = 2 * (idx.genome_len + 4 * (idx.index_size(0) + (1 << 24) + 8)) + n_ref * (2 * read_len + 20) * 2
+    base = None
+    for cand in (os.environ.get("WALT_AMD_SCRATCH"), "/dev/shm", "/tmp"):
+        if cand and os.path.isdir(cand) and shutil.disk_usage(cand).free > 1.3 * need:
+            base = cand
+            break
+    try:
+        avail_kb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+    except (OSError, IndexError, ValueError):
+        avail_kb = 0
+    if base is None or avail_kb * 1024 < 2.2 * need:
+        return {"skipped": "no scratch space / host memory for a %.0f GB index copy" % (need / 1e9)}
+    scratch = tempfile.mkdtemp(prefix="walt_amd_bench_ref_", dir=base)
+    try:
+        dbi = os.path.join(scratch, "hg.dbindex")
+        t0 = time.perf_counter()
+        idx.write(dbi)
+        for sfx in ("_GA10", "_GA11"):  # the binary only checks that all four strand files exist
+            if not os.path.exists(dbi + sfx):
+                open(dbi + sfx, "wb").close()
+        t_write = time.perf_counter() - t0
+        host = d_bases[:n_ref * read_len].cpu().numpy()
+        fq = os.path.join(scratch, "sample.fastq")
+        rec = np.dtype([("at", "S2"), ("num", "S9"), ("nl0", "S1"), ("seq", "S%d" % read_len), ("mid", "S3"),
+                        ("qual", "S%d" % read_len), ("nl1", "S1")])
+        with open(fq, "wb") as f:
+            for s0 in range(0, n_ref, 1 << 20):
+                m = min(1 << 20, n_ref - s0)
+                a = np.zeros(m, dtype=rec)
+                a["at"], a["nl0"], a["mid"], a["nl1"] = b"@r", b"\n", b"\n+\n", b"\n"
+                a["num"] = np.char.zfill(np.arange(s0, s0 + m).astype("S9"), 9)
+                a["seq"] = host[s0 * read_len:(s0 + m) * read_len].view("S%d" % read_len)
+                a["qual"] = b"I" * read_len
+                f.write(a.tobytes())
+        out = os.path.join(scratch, "ref.mr")
+        cmd = [ref_bin, "-i", dbi, "-r", fq, "-o", out, "-m", str(max_mm), "-b", str(b), "-t", str(cores)]
+        t0 = time.perf_counter()
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        wall = time.perf_counter() - t0
+        if pr.returncode != 0:
+            return {"skipped": "reference binary failed: " + pr.stdout[-300:]}
+        stats = {}
+        for ln in open(out + ".mapstats"):
+            k, _, v = ln.strip().partition(":")
+            if v.strip().lstrip("-").replace(".", "", 1).isdigit():
+                stats[k.strip()] = v.strip()
+        times = d_out[:n_ref * 16].view(torch_int32()).view(n_ref, 4)[:, 1]
+        mine = {"unique": int((times == 1).sum().item()), "ambiguous": int((times >= 2).sum().item()),
+                "unmapped": int((times == 0).sum().item())}
+        same = all(int(stats.get(k, -1)) == v for k, v in mine.items())
+        return {"value": n_ref / wall, "unit": "reads/s", "cores": cores, "kind": "reference",
+                "sample": "oracle/_ref/walt -t %d on the first %d reads of the batch, wall clock of the whole run "
+                          "including its read of both strand index files (%.0f GB, RAM-backed) -- the reference "
+                          "reloads them for every batch (mapping.cpp:491-492)" % (
+                              cores, n_ref, 2 * (idx.genome_len + 4 * (idx.index_size(0) + (1 << 24) + 8)) / 1e9),
+                "wall_s": wall, "index_write_s": t_write, "mapstats_equal_gpu": bool(same)}
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
+def torch_int32():
+    import torch
+    return torch.int32
+
+
 def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, frag_range):
     """Oracle restatement of PairEndMapping + MergePairedEndResults on the host cores; the two strand
     indexes of one mate are in host memory at a time."""
@@ -320,6 +398,9 @@ def main():
     ap.add_argument("--mode", choices=["se", "pe"], default="se", help="se = configs[1] (headline), pe = configs[2]")
     ap.add_argument("--top-k", type=int, default=50)
     ap.add_argument("--frag-range", type=int, default=1000)
+    ap.add_argument("--ref-sample", type=int, default=3_000_000,
+                    help="reads the real reference binary (oracle/_ref/walt) maps beside the oracle port at N=1 "
+                         "(0 = skip; needs ~35 GB of RAM-backed scratch for the index copy)")
     ap.add_argument("--slot-table", action="store_true",
                     help="build the opt-in direct-mapped slot table (WALT_AMD_TABLE=1: +51.5 GB per strand at hg19 scale)")
     ap.add_argument("--pattern", type=int, choices=[3, 5, 7], default=3,
@@ -488,6 +569,14 @@ def main():
                                    "sample": "first %d reads of rank 0's batch, both strand passes, oracle "
                                              "restatement with OpenMP; index in host memory" % ns,
                                    "bit_exact_vs_gpu": bool(same)}
+            if args.ref_sample > 0 and args.pattern == 3:
+                # the real reference binary beside it (slower than the port: it also reads its index files)
+                try:
+                    out["cpu_baseline"]["reference_binary"] = reference_binary_leg(
+                        idx, d_bases, d_out, args.read_len, min(args.ref_sample, n), args.max_mismatches,
+                        args.bucket, cores)
+                except Exception as e:  # never let the extra leg break the bench line
+                    out["cpu_baseline"]["reference_binary"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
         elif stored and args.read_len == 100 and args.max_mismatches == 6 and args.bucket == 5000:
             per_read = {k: float(stored[k]) for k in ("probes", "search_steps", "candidates")}
             per_read_src = "profiles/traffic.json (oracle counters of the N=1 run of this workload)"
