@@ -69,7 +69,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
                          const uint32_t* d_index, uint32_t index_size, hipStream_t stream);
 int new_index(int device, const IndexHead& head, int dir_bits, int n_strands, walt_index** out);
 int finish_index_device(walt_index* idx);  // start_index, mask table
-int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands);
+int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands, uint64_t device_bytes);
 
 }  // namespace walt
 #endif

@@ -178,17 +178,23 @@ static int dev_alloc(walt_index* idx, T** p, uint64_t count) {
   return WALT_OK;
 }
 
-int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands) {
+int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands, uint64_t device_bytes) {
   if (requested >= 0) return requested > (int)kMaxDirBits ? (int)kMaxDirBits : requested < (int)kMinDirBits ? (int)kMinDirBits : requested;
   // smallest Bd with index_size / 2^Bd <= 2 entries per directory slot (slots of
   // up to kScan entries are searched with independent loads, core.h) ...
   int B = (int)kMinDirBits;
   while (B < 31 && max_index_size > (2ull << B)) ++B;
-  // ... and one bit more (2^32 slots, 17 GB per strand) at hg19 scale when only two strands are resident
-  // (single-end mapping): half of the slots a non-matching probe lands in are then empty and cost no entry
-  // line (-7 % HBM lines per read).  Four resident strands (paired-end) stay at 31: 4 x 17 GB more would
-  // not leave room for the builder's temporaries and the batch workspace in 288 GB.
-  if (B == 31 && n_strands <= 2 && max_index_size > (1ull << 31)) B = 32;
+  // ... and one bit more (2^32 slots, 17 GB per strand, 0.72 entries per slot at hg19 scale) when the device
+  // has the room: half of the slots a non-matching probe lands in are then empty and cost no entry line
+  // (single-end pass 1: 12.9 -> 11.5 ms; paired-end: 875 -> 958 M pairs/s).  Room = all strands resident plus
+  // 30 GB for batches, and the GPU builder's peak while it sorts the last strand (24 bytes of keys and
+  // positions per entry, 4 of slack) beside the strands already finished.
+  if (B == 31 && max_index_size > (1ull << 31)) {
+    const uint64_t strand = 12ull * max_index_size + (4ull << 32) + max_index_size / 3 + (80ull << 20);
+    const uint64_t resident = (uint64_t)n_strands * strand + (30ull << 30);
+    const uint64_t build_peak = (uint64_t)(n_strands - 1) * strand + 28ull * max_index_size;
+    if (resident <= device_bytes && build_peak <= device_bytes) B = 32;
+  }
   return B;
 }
 
@@ -406,7 +412,9 @@ int new_index(int device, const IndexHead& head, int dir_bits, int n_strands, wa
   idx->device = device;
   idx->head = head;
   memset(&idx->view, 0, sizeof(idx->view));
-  idx->view.dir_bits = (uint32_t)choose_dir_bits(head.max_index_size, dir_bits, n_strands);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
+  idx->view.dir_bits = (uint32_t)choose_dir_bits(head.max_index_size, dir_bits, n_strands < 1 ? 1 : n_strands, total_b);
   idx->view.dir_slots = dir_top(idx->view.dir_bits);
   // chromosome starts are needed by the strand builders (outlier detection)
   const uint32_t n = (uint32_t)idx->head.lengths.size();
