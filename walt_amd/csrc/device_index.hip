@@ -347,6 +347,12 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     bloom_blocks = bloom_blocks_for(keys.size());
     std::vector<uint64_t> hb(bloom_blocks, 0);
     for (uint32_t k : keys) bloom_insert(hb.data(), bloom_blocks - 1, k);
+    if (getenv("WALT_AMD_VERBOSE")) {
+      uint64_t bits = 0;
+      for (uint64_t w : hb) bits += (uint64_t)__builtin_popcountll(w);
+      fprintf(stderr, "[walt_amd index: strand %d: %u outliers, %zu filter keys, %u Bloom blocks, %.2f %% of its bits set]\n",
+              strand, n_outl, keys.size(), bloom_blocks, 100.0 * (double)bits / (64.0 * bloom_blocks));
+    }
     if ((rc = dev_alloc(idx, &bloom, (uint64_t)bloom_blocks))) return rc;
     std::vector<uint32_t> hp(kPreBits / 32, 0);
     for (uint32_t k : keys) hp[pre_hash(k) >> 5] |= 1u << (pre_hash(k) & 31);
