@@ -359,6 +359,22 @@ constexpr uint32_t kPreBits = 1u << 16;
 WALT_HD uint32_t pre_hash(uint32_t key) { return (key * 0x9E3779B1u) >> 16; }
 // key of a probe: bucket and care characters 12..15 of its (zero padded) care string
 WALT_HD uint32_t bloom_key_of_care(const uint32_t* care) { return care[0]; }
+// Second level: an outlier whose beyond-the-end characters start at q >= kBloomChars2 (most of them: q runs
+// to 43) endangers only probes that agree with it on ALL of the characters 12..q-1, in particular on
+// 12..19.  Such an outlier is inserted into the block its 16-character key selects, but with the bit pattern
+// of its 20-character key, and a probe tests both patterns on the one block it loads: no extra memory access,
+// and the four extra characters cut these outliers' chance matches by 0.375^4 = 1/50 (a converted strand has
+// three letters, one of them half of all bases) -- a third fewer deferred reads on an assembly of many contigs.
+constexpr uint32_t kBloomChars2 = 8;   // care characters 12..19
+WALT_HD uint32_t bloom_key2(uint32_t key16, uint32_t chars16_19) {
+  return (key16 * 0x85EBCA6Bu) ^ ((chars16_19 + 1u) * 0xC2B2AE35u);
+}
+WALT_HD uint32_t bloom_key2_of_care(const uint32_t* care) { return bloom_key2(care[0], care[1] >> 24); }
+// the pass-1 test on the loaded block (0 = not loaded: no hit)
+WALT_HD bool danger_filter_hit(uint64_t block, const uint32_t* care) {
+  const uint64_t b1 = bloom_bits(bloom_key_of_care(care)), b2 = bloom_bits(bloom_key2_of_care(care));
+  return (block & b1) == b1 || (block & b2) == b2;
+}
 WALT_HD uint64_t key_mask(uint32_t nk);
 WALT_HD uint64_t target_key(const uint32_t* care);
 

@@ -328,8 +328,14 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     });
     // filter keys: see core.h; the filter is sized by their number
     std::vector<uint32_t> keys;
+    std::vector<std::pair<uint32_t, uint32_t>> keys2;  // (16-character key: block and prefilter, 20-character key: bits)
     for (const Outlier& o : ho) {
       const uint32_t own = o.key_hi >> (32 - 2 * kBloomChars);  // care characters 12..15, MSB first
+      if (o.q >= kKeyWeight + kBloomChars2) {  // second level (core.h bloom_key2): its characters 12..19 are real
+        const uint32_t k16 = bloom_key(o.h, own);
+        keys2.push_back(std::make_pair(k16, bloom_key2(k16, (o.key_hi >> (32 - 2 * kBloomChars2)) & 0xFFu)));
+        continue;
+      }
       // characters from q on take every value (q == 12 + j: the low 2 * (kBloomChars - j) bits are free)
       const uint32_t real = o.q <= kKeyWeight ? 0u : (o.q - kKeyWeight < kBloomChars ? o.q - kKeyWeight : kBloomChars);
       const uint32_t free_bits = 2 * (kBloomChars - real);
@@ -344,18 +350,20 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
           if ((bm[w] >> bit) & 1u)
             for (uint32_t v = 0; v < (1u << (2 * kBloomChars)); ++v) keys.push_back(bloom_key(w * 32 + bit, v));
     }
-    bloom_blocks = bloom_blocks_for(keys.size());
+    bloom_blocks = bloom_blocks_for(keys.size() + keys2.size());
     std::vector<uint64_t> hb(bloom_blocks, 0);
     for (uint32_t k : keys) bloom_insert(hb.data(), bloom_blocks - 1, k);
+    for (const auto& k : keys2) hb[bloom_block(k.first, bloom_blocks - 1)] |= bloom_bits(k.second);
     if (getenv("WALT_AMD_VERBOSE")) {
       uint64_t bits = 0;
       for (uint64_t w : hb) bits += (uint64_t)__builtin_popcountll(w);
       fprintf(stderr, "[walt_amd index: strand %d: %u outliers, %zu filter keys, %u Bloom blocks, %.2f %% of its bits set]\n",
-              strand, n_outl, keys.size(), bloom_blocks, 100.0 * (double)bits / (64.0 * bloom_blocks));
+              strand, n_outl, keys.size() + keys2.size(), bloom_blocks, 100.0 * (double)bits / (64.0 * bloom_blocks));
     }
     if ((rc = dev_alloc(idx, &bloom, (uint64_t)bloom_blocks))) return rc;
     std::vector<uint32_t> hp(kPreBits / 32, 0);
     for (uint32_t k : keys) hp[pre_hash(k) >> 5] |= 1u << (pre_hash(k) & 31);
+    for (const auto& k : keys2) hp[pre_hash(k.first) >> 5] |= 1u << (pre_hash(k.first) & 31);
     if ((rc = dev_alloc(idx, &pre, (uint64_t)kPreBits / 32))) return rc;
     WALT_HIP(hipMemcpy(pre, hp.data(), kPreBits / 8, hipMemcpyHostToDevice));
     if (n_outl) WALT_HIP(hipMemcpy(outl, ho.data(), n_outl * sizeof(Outlier), hipMemcpyHostToDevice));

@@ -97,7 +97,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         uint32_t slot, span;
         seed_query<NW>(lr.rd, seed_len_of(lr.repeats), seed_i, ga, Bd, sh.pcode4, care, slot, span);
         const uint32_t bk = bloom_key_of_care(care);
-        if (!LITERAL && bloom_hit(sv.bloom[bloom_block(bk, sv.bloom_mask)], bk)) {
+        if (!LITERAL && danger_filter_hit(sv.bloom[bloom_block(bk, sv.bloom_mask)], care)) {
           deferred = true;
           mappable = false;
           defer_iter = fi * kPat + seed_i;
@@ -263,8 +263,8 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     uint32_t hi_p, hi_m;
     probe_issue(svp, need, slot, span, pp, hi_p);
     probe_issue(svm, need, slot, span, pm, hi_m);
-    const bool bad_p = need && bloom_hit(bw_p, bkey);
-    const bool bad_m = need && bloom_hit(bw_m, bkey);
+    const bool bad_p = need && bw_p && danger_filter_hit(bw_p, care);
+    const bool bad_m = need && bw_m && danger_filter_hit(bw_m, care);
     if (bad_p || bad_m) {
       deferred = true;
       mappable = false;

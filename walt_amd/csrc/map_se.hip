@@ -194,7 +194,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         bool is_bad = false;
         if (act && !LITERAL) {
           const uint32_t bk = bloom_key_of_care(care);
-          is_bad = bloom_hit(sv.bloom[bloom_block(bk, sv.bloom_mask)], bk);
+          is_bad = danger_filter_hit(sv.bloom[bloom_block(bk, sv.bloom_mask)], care);
         }
         stamp(st, 2);
         if (act) {
@@ -339,8 +339,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     uint32_t hi_p, hi_m;
     probe_issue(svp, need_p, slot, span, pp, hi_p);
     probe_issue(svm, need_m, slot, span, pm, hi_m);
-    const bool bad_p = need_p && bloom_hit(bw_p, bkey);
-    const bool bad_m = need_m && bloom_hit(bw_m, bkey);
+    const bool bad_p = need_p && bw_p && danger_filter_hit(bw_p, care);
+    const bool bad_m = need_m && bw_m && danger_filter_hit(bw_m, care);
     if (bad_p || bad_m) {
       deferred = true;
       mappable = false;
