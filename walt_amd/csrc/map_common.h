@@ -424,6 +424,21 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const Bloc
   if (ok) mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
 }
 
+// Append `value` to a device list for the lanes with `take` set: ONE atomic per wavefront (an assembly of
+// thousands of contigs defers a fifth of the reads, and ten million same-address atomics cost milliseconds).
+// All 64 lanes must call this.
+__device__ __forceinline__ void wave_append(bool take, uint32_t value, uint32_t* __restrict__ count,
+                                            uint32_t* __restrict__ list) {
+  const unsigned long long m = __ballot(take);
+  if (!m) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const int leader = (int)__ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = bcast(base, leader);
+  if (take) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
 // Deferred reads are tagged with the (strand, seed) iteration of their first BAD
 // probe and grouped by it before the literal pass, so that the lanes of a
 // literal-pass wave run their long searches in the same iteration instead of

@@ -333,11 +333,10 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     }
   }
   const uint32_t total = hsize + n_minus;
-  if (deferred) {
-    bloom_list[atomicAdd(bloom_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
-  } else if (valid && (cplx || total > kFastCands || total >= top_k)) {
-    cplx_list[atomicAdd(cplx_count, 1u)] = r;
-  } else if (valid) {
+  const bool to_cplx = !deferred && valid && (cplx || total > kFastCands || total >= top_k);
+  wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, bloom_count, bloom_list);
+  wave_append(to_cplx, r, cplx_count, cplx_list);
+  if (!deferred && !to_cplx && valid) {
     // the heap never fills: plain pushes in the reference's order, then the drain of paired.cpp:685-692
     if (n_minus > 0) { HeapEnt e; e.pos = mp0; e.mms = mm0 | 0x80000000u; heap_push(fast, hsize, e); }
     if (n_minus > 1) { HeapEnt e; e.pos = mp1; e.mms = mm1 | 0x80000000u; heap_push(fast, hsize, e); }

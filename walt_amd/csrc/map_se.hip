@@ -433,11 +433,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     fold_region(best, m1, '-');
     if (best.mismatch > 1) fold_region(best, m2, '-');
   }
-  if (deferred) {
-    defer_list[atomicAdd(defer_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
-  } else if (valid) {
-    out[r] = best;
-  }
+  wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, defer_count, defer_list);
+  if (!deferred && valid) out[r] = best;
   stamp(st, 7);
 }
 
