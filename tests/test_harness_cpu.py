@@ -194,3 +194,57 @@ def test_harness_crowded_chromosome_ends(scratch):
             for j in range(500):
                 assert np.array_equal(r[j][:n[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), (k, j)
         h.close()
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_harness_outlier_stress_low_entropy(scratch, seed):
+    """Thousands of chromosome ends in a low-entropy genome (T-rich after conversion, few distinct 12-mers):
+    most probes share long prefixes with chromosome-end entries, which is where the refined danger rule
+    (core.h probe_is_dangerous: a probe whose character at the outlier's first missing position exceeds the real
+    byte there is safe) must agree with the literal search.  Directory search, forced literal search and the
+    oracle must give identical records."""
+    rng = random.Random(1000 + seed)
+    alphabet = "TTTTTTCCAG" if seed % 2 else "TTCCCCAAGG"  # C -> T makes the first one ~80 % T
+    motif = "".join(rng.choice(alphabet) for _ in range(400))
+    seqs = []
+    for i in range(1500):
+        L = rng.choice([37, 38, 39, 40, 45, 52, 60, 75, 90, 120, 135])
+        a = rng.randrange(0, 400 - 136)
+        s = list(motif[a:a + L])
+        for _ in range(rng.randrange(0, 3)):
+            s[rng.randrange(len(s))] = rng.choice("ACGT")
+        seqs.append(("t%d" % i, "".join(s)))
+    seqs.append(("long", motif * 4))
+    fa = os.path.join(scratch, "stress_%d.fa" % seed)
+    with open(fa, "w") as f:
+        for nm, s in seqs:
+            f.write(">%s\n%s\n" % (nm, s))
+    idxp = os.path.join(scratch, "stress_%d.dbindex" % seed)
+    assert refio.harness().walt_makedb(fa.encode(), idxp.encode(), 4) == 0
+    db = refio.DbIndex(idxp)
+    long_seq = motif * 4
+    reads = []
+    for _ in range(6000):
+        L = rng.choice([38, 41, 44, 50, 62, 80, 100, 100, 130])
+        a = rng.randrange(0, len(long_seq) - L)
+        s = long_seq[a:a + L]
+        if rng.random() < 0.5:
+            s = refio.revcomp(s)
+        s = "".join("T" if (c == "C" and rng.random() < 0.9) else c for c in s)
+        s = "".join(rng.choice("ACGT") if rng.random() < 0.02 else c for c in s)
+        reads.append(s)
+    want, _ = refio.oracle_se(db, reads, max_mm=6, b=5000)
+    want_b, _ = refio.oracle_se(db, reads, max_mm=4, b=30)
+    for D in (24, 27):
+        h = refio.HarnessIndex(db, D)
+        got, _ = h.map_se(reads, False, 6, 5000)
+        assert_best_equal(got, want, "stress D=%d" % D)
+        got, _ = h.map_se(reads, False, 4, 30)
+        assert_best_equal(got, want_b, "stress b=30 D=%d" % D)
+        if D == 24:
+            r, n, _ = h.pe_topk(reads[:800], False, 6, 5000, 50)
+            ro, no, _ = refio.oracle_pe_topk(db, reads[:800], False, 6, 5000, 50)
+            assert np.array_equal(n, no)
+            for j in range(800):
+                assert np.array_equal(r[j][:n[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), j
+        h.close()

@@ -408,7 +408,19 @@ WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint
     const Outlier o = sv.outl[lo];
     if (o.q >= lim) continue;  // the search never compares a character this entry lacks
     const uint64_t k = ((uint64_t)o.key_hi << 32) | o.key_lo;
-    if (((T ^ k) & key_mask(o.q - kKeyWeight)) == 0) return true;
+    if (((T ^ k) & key_mask(o.q - kKeyWeight)) == 0) {
+      // The probe shares the outlier's characters 12..q-1.  The outlier sits at the START of that group
+      // (makedb ranks its missing character q below every base) while the search reads a real byte x there.
+      // If the probe's character q is GREATER than x, the outlier cannot matter: LowerBound's bisection
+      // (mapping.cpp:166-180) reaches the group's first entries only when every entry it examined before
+      // had a character >= the probe's, and then sees x < c and steps over the outlier -- the same range as
+      // without it; UpperBound never examines its lower end; and in the directory the outlier's own prefix
+      // is below the probe's, so the slots the probe reads are the undisturbed ones (or, when the prefixes
+      // coincide in their first dir_bits, the outlier heads the slot as an entry smaller than the target,
+      // which the key scan counts as such).  Anything else (c <= x) stays literal.  DESIGN.md section 4.
+      const uint32_t sh = 2 * (kKeyWeight + kKeyChars - 1 - o.q);
+      if (!(((T >> sh) & 3u) > ((k >> sh) & 3u))) return true;
+    }
   }
   return false;
 }
