@@ -340,7 +340,13 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       const uint32_t real = o.q <= kKeyWeight ? 0u : (o.q - kKeyWeight < kBloomChars ? o.q - kKeyWeight : kBloomChars);
       const uint32_t free_bits = 2 * (kBloomChars - real);
       const uint32_t fixed = free_bits >= 8 ? 0u : (own >> free_bits) << free_bits;
-      for (uint32_t v = 0; v < (1u << free_bits); ++v) keys.push_back(bloom_key(o.h, fixed | v));
+      // of the values the free characters can take, only those whose FIRST free character (index q) does not
+      // exceed the outlier's real byte there can belong to a dangerous probe (core.h probe_is_dangerous)
+      const uint32_t xq = real < kBloomChars ? (o.key_hi >> (30 - 2 * real)) & 3u : 0u;
+      for (uint32_t v = 0; v < (1u << free_bits); ++v) {
+        if (free_bits && (v >> (free_bits - 2)) > xq) continue;
+        keys.push_back(bloom_key(o.h, fixed | v));
+      }
     }
     if (nbad) {  // buckets with unexplained disorder: every probe into them is dangerous
       std::vector<uint32_t> bm(kNumBuckets / 32);
