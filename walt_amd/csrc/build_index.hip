@@ -64,7 +64,7 @@ __global__ void k_count_buckets(const uint32_t* __restrict__ g2, const uint32_t*
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= genome_len) return;
   if (!indexed_position(start, n_chrom, j)) return;
-  atomicAdd(&hist[hash_at(g2, j)], 1u);
+  atomicAdd(&hist[hash_at_dev(g2, j)], 1u);
 }
 
 // erase buckets >= 500000 (reference.cpp:211-218): hist -> 0, erased bit set
@@ -86,7 +86,7 @@ struct KeepPosition {
   uint32_t n_chrom;
   __device__ bool operator()(const uint32_t& j) const {
     if (!indexed_position(start, n_chrom, j)) return false;
-    uint32_t h = hash_at(g2, j);
+    uint32_t h = hash_at_dev(g2, j);
     return !((erased[h >> 5] >> (h & 31)) & 1u);
   }
 };
@@ -100,18 +100,15 @@ __device__ __forceinline__ uint32_t marked_char(const uint32_t* g2, uint32_t p, 
   uint32_t c = g2_code(g2, (uint64_t)p + cp);
   return c == 0 ? 1u : c == 3 ? 3u : 2u;
 }
-// pass A: care chars [q_lo, q_hi), at most 32 of them (28..59 for pattern 3; pattern 7's 28..79 take two passes)
+// pass A: care chars [Q_LO, Q_HI), at most 32 of them (28..59 for pattern 3; pattern 7's 28..79 take two passes)
+template <uint32_t Q_LO, uint32_t Q_HI>
 __global__ void k_keys_low(const uint32_t* __restrict__ g2, const uint32_t* __restrict__ start, uint32_t n_chrom,
-                           const uint32_t* __restrict__ pos, uint32_t n, uint32_t q_lo, uint32_t q_hi,
-                           unsigned long long* __restrict__ keys) {
+                           const uint32_t* __restrict__ pos, uint32_t n, unsigned long long* __restrict__ keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t p = pos[i];
   uint32_t chr = chrom_id(start, n_chrom, p);
-  uint32_t room = start[chr + 1] - p;
-  unsigned long long k = 0;
-  for (uint32_t q = q_lo; q < q_hi; ++q) k = (k << 2) | marked_char(g2, p, room, q);
-  keys[i] = k;
+  keys[i] = marked_chars_dev<Q_LO, Q_HI>(g2, p, start[chr + 1] - p);
 }
 // pass B: (bucket << 32) | care chars 12..27
 __global__ void k_keys_high(const uint32_t* __restrict__ g2, const uint32_t* __restrict__ start, uint32_t n_chrom,
@@ -120,10 +117,7 @@ __global__ void k_keys_high(const uint32_t* __restrict__ g2, const uint32_t* __r
   if (i >= n) return;
   uint32_t p = pos[i];
   uint32_t chr = chrom_id(start, n_chrom, p);
-  uint32_t room = start[chr + 1] - p;
-  unsigned long long k = hash_at(g2, p);
-  for (uint32_t q = 12; q < 28; ++q) k = (k << 2) | marked_char(g2, p, room, q);
-  keys[i] = k;
+  keys[i] = ((unsigned long long)hash_at_dev(g2, p) << 32) | marked_chars_dev<12, 28>(g2, p, start[chr + 1] - p);
 }
 
 __global__ void k_unpack_genome(const uint32_t* __restrict__ g2, uint32_t genome_len, uint8_t* __restrict__ out) {
@@ -217,14 +211,17 @@ static int build_one_strand(walt_index* idx, int strand, const uint8_t* d_ascii,
     DevBuf sort_tmp;
     WALT_HIPB(sort_tmp.alloc(sort_bytes));
     // pass A (stable LSD passes): care chars 28 .. kNumCare-1, the least significant 32 first
-    for (uint32_t q_hi = kNumCare; q_hi > 28;) {
-      const uint32_t q_lo = q_hi > 28 + 32 ? q_hi - 32 : 28;
-      hipLaunchKernelGGL(k_keys_low, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, d_start, n_chrom,
-                         vals.current(), index_size, q_lo, q_hi, keys.current());
-      WALT_HIPB(rocprim::radix_sort_pairs(sort_tmp.p, sort_bytes, keys, vals, (size_t)index_size, 0u,
-                                          2u * (q_hi - q_lo), stream));
-      q_hi = q_lo;
-    }
+    auto pass_a = [&](auto kernel, uint32_t nchars) -> hipError_t {
+      hipLaunchKernelGGL(kernel, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, d_start, n_chrom,
+                         vals.current(), index_size, keys.current());
+      return rocprim::radix_sort_pairs(sort_tmp.p, sort_bytes, keys, vals, (size_t)index_size, 0u, 2u * nchars, stream);
+    };
+#if WALT_SEEDPATTERN == 7  // 80 care characters: 48..79, then 28..47
+    WALT_HIPB(pass_a(k_keys_low<kNumCare - 32, kNumCare>, 32));
+    WALT_HIPB(pass_a(k_keys_low<28, kNumCare - 32>, kNumCare - 32 - 28));
+#else
+    WALT_HIPB(pass_a(k_keys_low<28, kNumCare>, kNumCare - 28));
+#endif
     // pass B (stable): bucket + first 16 care chars
     hipLaunchKernelGGL(k_keys_high, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, d_start, n_chrom,
                        vals.current(), index_size, keys.current());

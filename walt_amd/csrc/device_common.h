@@ -59,6 +59,53 @@ inline int nw_for_len(uint32_t max_len) {
   return 0;
 }
 
+constexpr uint32_t kHashSpan = care_pos(kKeyWeight - 1) - care_pos(0);
+constexpr int kHashWin = (int)(kHashSpan / 16) + 2;
+// the 12 hashed characters (indexed positions keep them inside the genome, reference.cpp:202-203), MSB first
+__device__ __forceinline__ uint32_t hash_at_dev(const uint32_t* __restrict__ g2, uint32_t pos) {
+  const uint64_t first = (uint64_t)pos + care_pos(0);
+  const uint32_t* w = g2 + (first >> 4);
+  const uint32_t sh = 2 * (uint32_t)(first & 15);
+  uint32_t raw[kHashWin + 1];
+#pragma unroll
+  for (int i = 0; i <= kHashWin; ++i) raw[i] = w[i];
+  uint32_t h = 0;
+#pragma unroll
+  for (uint32_t p = 0; p < kKeyWeight; ++p) {
+    const uint32_t off = care_pos(p) - care_pos(0);
+    const uint32_t word = funnel_r(raw[off >> 4], raw[(off >> 4) + 1], sh);
+    h = (h << 2) | ((word >> (2 * (off & 15))) & 3u);
+  }
+  return h;
+}
+
+// Care characters [P0, P1) (at most 32) behind genome position pos as makedb's comparator ranks them
+// (reference.cpp:271-288): 0 when the character lies at or beyond `room` = chromosome end - pos, else 1 / 2 / 3
+// for the strand's three letters in order; one window of genome words, characters at compile-time offsets.
+template <uint32_t P0, uint32_t P1>
+__device__ __forceinline__ unsigned long long marked_chars_dev(const uint32_t* __restrict__ g2, uint32_t pos,
+                                                               uint32_t room) {
+  static_assert(P1 > P0 && P1 - P0 <= 32, "at most 32 characters");
+  constexpr uint32_t span = care_pos(P1 - 1) - care_pos(P0);
+  constexpr int kWin = (int)(span / 16) + 2;
+  const uint64_t first = (uint64_t)pos + care_pos(P0);
+  const uint32_t* w = g2 + (first >> 4);  // g2 carries kG2PadWords of slack behind the genome
+  const uint32_t sh = 2 * (uint32_t)(first & 15);
+  uint32_t raw[kWin + 1];
+#pragma unroll
+  for (int i = 0; i <= kWin; ++i) raw[i] = w[i];
+  unsigned long long k = 0;
+#pragma unroll
+  for (uint32_t p = P0; p < P1; ++p) {
+    const uint32_t off = care_pos(p) - care_pos(P0);
+    const uint32_t word = funnel_r(raw[off >> 4], raw[(off >> 4) + 1], sh);
+    const uint32_t c = (word >> (2 * (off & 15))) & 3u;
+    const uint32_t v = care_pos(p) >= room ? 0u : (c == 0 ? 1u : (c == 3 ? 3u : 2u));
+    k = (k << 2) | v;
+  }
+  return k;
+}
+
 // Upload + derived-structure build for one strand from DEVICE-resident raw
 // arrays (genome bytes, counter, index).  Takes ownership of nothing; the raw
 // index/bytes may be freed by the caller afterwards; counter is copied.

@@ -60,6 +60,51 @@ __global__ void k_pack_genome(const uint8_t* __restrict__ bytes, uint32_t len, u
   if (bad) atomicAdd(err, bad);
 }
 
+// Device forms of index_core.h make_ent / ent_prefix: the genome words that hold the characters are loaded
+// once (these builders are bound by the number of per-lane loads, like the mapping kernels) and aligned to
+// the first character by funnel shifts, so every character sits at a compile-time offset.
+constexpr uint32_t kKeySpan = care_pos(kKeyWeight + kKeyChars - 1) - care_pos(kKeyWeight);  // bases between care chars 12 and 43
+constexpr int kKeyWin = (int)(kKeySpan / 16) + 2;
+__device__ __forceinline__ Ent make_ent_dev(const uint32_t* __restrict__ g2, uint32_t genome_len, uint32_t pos,
+                                            bool& touches_end) {
+  const uint64_t first = (uint64_t)pos + care_pos(kKeyWeight);
+  const uint32_t* w = g2 + (first >> 4);  // g2 carries kG2PadWords of slack behind the genome
+  const uint32_t sh = 2 * (uint32_t)(first & 15);
+  uint32_t raw[kKeyWin + 1];
+#pragma unroll
+  for (int i = 0; i <= kKeyWin; ++i) raw[i] = w[i];
+  uint64_t key = 0;
+  touches_end = false;
+#pragma unroll
+  for (uint32_t p = kKeyWeight; p < kKeyWeight + kKeyChars; ++p) {
+    const uint32_t off = care_pos(p) - care_pos(kKeyWeight);  // compile-time
+    const uint32_t word = funnel_r(raw[off >> 4], raw[(off >> 4) + 1], sh);
+    uint32_t c = (word >> (2 * (off & 15))) & 3u;
+    if (first + off >= genome_len) { c = 0; touches_end = true; }
+    key = (key << 2) | c;
+  }
+  Ent e;
+  e.key_hi = (uint32_t)(key >> 32);
+  e.key_lo = (uint32_t)key;
+  e.pos = pos;
+  return e;
+}
+__device__ __forceinline__ uint32_t ent_prefix_dev(const uint32_t* __restrict__ g2, const Ent& e, uint32_t ga,
+                                                   uint32_t Bd) {
+  const uint32_t h = hash_at_dev(g2, e.pos);
+  const uint64_t key = ent_key(e);
+  uint64_t acc = 0;
+  uint32_t nb = 0;
+  for (uint32_t i = 0; i < kKeyWeight + kKeyChars && nb < Bd; ++i) {
+    const uint32_t c = i < kKeyWeight ? (h >> (2 * (kKeyWeight - 1 - i))) & 3u
+                                      : (uint32_t)((key >> (2 * (kKeyWeight + kKeyChars - 1 - i))) & 3u);
+    const uint32_t l = pcode_len(c, ga);
+    acc = (acc << l) | pcode_bits(c, ga);
+    nb += l;
+  }
+  return (uint32_t)(acc >> (nb - Bd));
+}
+
 // index[] -> Ent {key, pos}; entries whose care characters < 44 run over their
 // chromosome's end are appended to the outlier list (core.h struct Outlier).
 __global__ void k_make_ent(const uint32_t* __restrict__ g2, uint32_t genome_len,
@@ -76,7 +121,7 @@ __global__ void k_make_ent(const uint32_t* __restrict__ g2, uint32_t genome_len,
     return;
   }
   bool touches;
-  Ent e = make_ent(g2, genome_len, pos, touches);
+  Ent e = make_ent_dev(g2, genome_len, pos, touches);
   ent[j] = e;
   const uint32_t chr = chrom_id(start, n_chrom, pos);
   const uint32_t room = start[chr + 1] - pos;
@@ -119,7 +164,7 @@ __global__ void k_check_buckets(const uint32_t* __restrict__ g2, const Ent* __re
                                 const uint32_t* __restrict__ cnt, uint32_t* __restrict__ err) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  uint32_t h = hash_at(g2, ent[j].pos);
+  uint32_t h = hash_at_dev(g2, ent[j].pos);
   if (!(cnt[h] <= j && j < cnt[h + 1])) atomicAdd(err + 2, 1u);
 }
 
@@ -151,8 +196,11 @@ __global__ void k_dir_scatter(const uint32_t* __restrict__ g2, const Ent* __rest
                               uint32_t Bd, uint32_t* __restrict__ dir) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const uint32_t v = ent_prefix(g2, ent[j], ga, Bd);
-  if (j == 0 || ent_prefix(g2, ent[j - 1], ga, Bd) != v) atomicMin(&dir[(1ull << Bd) - v], j);
+  const uint32_t v = ent_prefix_dev(g2, ent[j], ga, Bd);
+  // the predecessor's prefix comes from the neighbouring lane (the first lane of a wave computes it)
+  uint32_t pv = __shfl_up(v, 1);
+  if ((threadIdx.x & 63) == 0 && j) pv = ent_prefix_dev(g2, ent[j - 1], ga, Bd);
+  if (j == 0 || pv != v) atomicMin(&dir[(1ull << Bd) - v], j);
 }
 
 __global__ void k_popcount(const uint32_t* __restrict__ words, uint32_t n, unsigned long long* __restrict__ out) {
