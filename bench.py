@@ -518,6 +518,9 @@ def main():
                      "store", "total"]
             log("phase shares (s_memtime, drained at boundaries): " +
                 ", ".join("%s %.1f%%" % (nm, 100.0 * buf[i] / tot) for i, nm in enumerate(names[:8])))
+            if int(os.environ.get("WALT_AMD_ABLATE", "0")) & 8:
+                log("danger-filter self-check: %d probe pairs checked, %d dangerous probes NOT flagged by the filter "
+                    "(must be 0)" % (buf[14], buf[15]))
     ctl = d_ws[:64 * 4].view(torch.int32).cpu().numpy()
     log("deferred to the literal pass: %d reads (bins %s)" % (int(ctl[32]), ctl[40:46].tolist()))
     ms_per_step = 1e3 * elapsed / args.steps

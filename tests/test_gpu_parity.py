@@ -353,3 +353,28 @@ def test_gpu_slot_table(wa, g1_db, scratch, monkeypatch):
         monkeypatch.setenv("WALT_AMD_TABLE", "1")
         assert idx.device_bytes - plain_bytes >= 4 * 12 * (1 << D)
         idx.close()
+
+
+def test_gpu_filter_covers_every_dangerous_probe(wa, scratch, monkeypatch):
+    """In-kernel self-check (WALT_AMD_STAMPS=1 WALT_AMD_ABLATE=8): for every probe pass 1 issues, the exact test
+    (core.h probe_is_dangerous) is evaluated beside the prefilter/Bloom decision; a probe that is dangerous but
+    not flagged would silently take the key search.  Genomes with hundreds of chromosome ends; the count of
+    such probes must be zero while thousands of probes are checked."""
+    import ctypes
+    monkeypatch.setenv("WALT_AMD_STAMPS", "1")
+    monkeypatch.setenv("WALT_AMD_ABLATE", "8")
+    checked = 0
+    for seed, n_chrom in ((21, 300), (22, 1100)):
+        seqs, db = make_random_case(seed, n_chrom, scratch)
+        rng = random.Random(seed)
+        reads = [r for r in sample_reads(rng, seqs, 4000, "CT") if len(r) <= 112]  # the 7-word pass-1 instance
+        idx = wa.Index.from_host(db.lengths, db.genome, db.counter, db.index, chrom_names=db.names, device=0)
+        want, _ = refio.oracle_se(db, reads)
+        got, _ = idx.map_se_batch(*wa.pack_reads(reads))
+        assert_best_equal(got, want, "self-check run")  # results stay valid in this mode
+        buf = (ctypes.c_ulonglong * 16)()
+        assert wa.lib().walt_profile_stamps(buf) == 0
+        assert buf[15] == 0, "%d dangerous probes were not flagged by the filter" % buf[15]
+        checked += buf[14]
+        idx.close()
+    assert checked > 5000

@@ -341,6 +341,13 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     probe_issue(svm, need_m, slot, span, pm, hi_m);
     const bool bad_p = need_p && bw_p && danger_filter_hit(bw_p, care);
     const bool bad_m = need_m && bw_m && danger_filter_hit(bw_m, care);
+    if constexpr (DIAG) if (ablate & 8u) {
+      // self-check (WALT_AMD_STAMPS=1 WALT_AMD_ABLATE=8; results stay valid): the filter must flag every probe
+      // the exact test calls dangerous; violations are counted in stamp word 15
+      if (need_p && !bad_p && probe_is_dangerous(svp, care, seed_len_of(lr.repeats))) atomicAdd(&st.buf[15], 1ull);
+      if (need_m && !bad_m && probe_is_dangerous(svm, care, seed_len_of(lr.repeats))) atomicAdd(&st.buf[15], 1ull);
+      if (need_p) atomicAdd(&st.buf[14], 1ull);  // probes checked
+    }
     if (bad_p || bad_m) {
       deferred = true;
       mappable = false;
@@ -693,7 +700,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   {
     const char* ab = getenv("WALT_AMD_ABLATE");
     g_ablate = ab ? (uint32_t)atoi(ab) : 0u;
-    if (g_ablate) fprintf(stderr, "[walt_amd] WALT_AMD_ABLATE=%u: DIAGNOSTIC RUN, mapping results are not valid\n", g_ablate);
+    if (g_ablate & 7u) fprintf(stderr, "[walt_amd] WALT_AMD_ABLATE=%u: DIAGNOSTIC RUN, mapping results are not valid\n", g_ablate);
     if (getenv("WALT_AMD_STAMPS") && !g_stamps) {
       WALT_HIP(hipMalloc(reinterpret_cast<void**>(&g_stamps), 16 * sizeof(unsigned long long)));
       WALT_HIP(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
