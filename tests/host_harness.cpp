@@ -265,6 +265,54 @@ int hh_pack(const char* bases, const uint64_t* offsets, uint32_t n, int ga, uint
   return bad;
 }
 
+// Region-level check of the exactness argument: for EVERY (read, strand, seed) probe
+// compare the region of the directory/key search with the region of the literal LowerBound/UpperBound search
+// over the whole bucket.  They must be equal whenever probe_is_dangerous() says the probe is safe.
+// out[0] probes, out[1] safe probes whose regions differ (must be 0), out[2] probes called dangerous,
+// out[3] safe probes that share an outlier's characters 12..q-1 (the class the refined rule releases).
+int hh_region_check(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, int ag, uint64_t* out4) {
+  HIndex* h = reinterpret_cast<HIndex*>(hp);
+  const IndexView& iv = h->view;
+  constexpr int NW = 64;
+  std::vector<uint32_t> rec(packed_fields(NW));
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  for (uint32_t r = 0; r < n; ++r) {
+    uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
+    if (len > kMaxReadLen) return -1;
+    if (len < kMinReadLen) continue;
+    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_bits, NW,
+                   rec.data(), 1))
+      return -2;
+    const uint32_t seed_len = seed_len_of(seed_repeats(len));
+    for (uint32_t fi = 0; fi < 2; ++fi) {
+      const StrandView& sv = iv.s[(ag ? 2 : 0) + fi];
+      for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
+        const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
+        ++out4[0];
+        if (probe_is_dangerous(sv, care, seed_len)) { ++out4[2]; continue; }
+        Lookup fast;
+        seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, fast, true);
+        Region lit = empty_region();
+        const uint32_t hh = care[0] >> 8;
+        const uint32_t first = sv.cnt[hh], second = sv.cnt[hh + 1];
+        if (first != second) lit = lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);
+        const bool e1 = fast.reg.l > fast.reg.u, e2 = lit.l > lit.u;
+        if (e1 != e2 || (!e1 && (fast.reg.l != lit.l || fast.reg.u != lit.u))) ++out4[1];
+        // does it share some outlier's characters 12..q-1 (and is safe only by the refined rule)?
+        const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
+        const uint64_t T = target_key(care);
+        for (uint32_t k = 0; k < sv.n_outl; ++k) {
+          const Outlier& o = sv.outl[k];
+          if (o.h != hh || o.q >= lim) continue;
+          const uint64_t key = ((uint64_t)o.key_hi << 32) | o.key_lo;
+          if (((T ^ key) & key_mask(o.q - kKeyWeight)) == 0) { ++out4[3]; break; }
+        }
+      }
+    }
+  }
+  return 0;
+}
+
 // expose the literal tables for tests/test_seedtab.py
 int hh_pattern() { return (int)kPat; }
 void hh_get_nocare(uint32_t* out /* kPat x 150 */) {

@@ -153,6 +153,7 @@ def harness():
         L.hh_pe_topk.argtypes = [vp, vp, vp, u32, ci, u32, u32, u32, vp, vp, vp]
         L.hh_pe_merge.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, ci, u32, vp]
         L.hh_get_nocare.argtypes = [vp]
+        L.hh_region_check.argtypes = [vp, vp, vp, u32, ci, vp]
         L.hh_pack.argtypes = [vp, vp, u32, ci, u32, u32, vp, ctypes.c_uint64]
         L.walt_makedb.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci]
         L.walt_last_error.restype = ctypes.c_char_p
@@ -312,6 +313,16 @@ class HarnessIndex:
                                  out.ctypes.data, ctypes.addressof(ts))
         assert rc == 0, rc
         return out, ts.value
+
+    def region_check(self, seqs, ag=False):
+        """(probes, safe probes whose key-search region differs from the literal one, dangerous probes,
+        safe probes sharing an outlier's prefix) -- host_harness.cpp hh_region_check"""
+        bases, offsets = pack_reads(seqs)
+        out = np.zeros(4, dtype=np.uint64)
+        rc = harness().hh_region_check(self.h, bases.ctypes.data, offsets.ctypes.data, len(seqs), int(ag),
+                                       out.ctypes.data)
+        assert rc == 0, rc
+        return [int(v) for v in out]
 
     def pe_topk(self, seqs, ag, max_mm=6, b=5000, top_k=50):
         bases, offsets = pack_reads(seqs)

@@ -237,6 +237,11 @@ def test_harness_outlier_stress_low_entropy(scratch, seed):
     want_b, _ = refio.oracle_se(db, reads, max_mm=4, b=30)
     for D in (24, 27):
         h = refio.HarnessIndex(db, D)
+        # region level: every probe the danger test calls safe gets the literal search's region from the
+        # directory/key search -- including the probes that share an outlier's prefix (refined rule)
+        probes, differ, dangerous, released = h.region_check(reads)
+        assert differ == 0, "%d of %d safe probes differ from the literal search" % (differ, probes)
+        assert dangerous > 100 and released > 100, (probes, dangerous, released)
         got, _ = h.map_se(reads, False, 6, 5000)
         assert_best_equal(got, want, "stress D=%d" % D)
         got, _ = h.map_se(reads, False, 4, 30)
