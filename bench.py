@@ -217,8 +217,8 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
                n, args.read_len), "index_hbm_gb": round(idx.device_bytes / 1e9, 2)},
            "mapping": {"pairs": pairs_t, "unique_pairs": uniq_t, "ambiguous_pairs": amb_t, "unpaired": unp_t}}
     if run_cpu:
-        want, cpu_s, cores = cpu_baseline_pe(idx, m1_host, m2_host, args.read_len, ns, lens, args.max_mismatches,
-                                             args.bucket, args.top_k, args.frag_range)
+        want, cpu_s, cores, works = cpu_baseline_pe(idx, m1_host, m2_host, args.read_len, ns, lens, args.max_mismatches,
+                                                    args.bucket, args.top_k, args.frag_range)
         got = d_out[:ns * 64].cpu().numpy().view(walt_amd.pair_result_dtype)
         same = all(np.array_equal(got[f], want[f]) for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"))
         for m in ("m1", "m2"):
@@ -227,6 +227,22 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
                                "sample": "first %d pairs, oracle restatement of PairEndMapping on both mates and "
                                          "strands + pair merge, OpenMP; two strand indexes in host memory at a time" % ns,
                                "bit_exact_vs_gpu": bool(same)}
+        # Same accounting as the single-end line: per pair, P probes and C candidates over
+        # both mates (oracle counters) -> 2 P + C dependent gathers of one 128-byte line each, plus per mate the
+        # ranked list written by the top-k kernel and read back by the merge (one line each way), the packed
+        # reads and the 64-byte pair record.  Time = the whole step (the mates' kernels overlap on several
+        # streams, so no single kernel's duration is meaningful); no PMC traffic figure for this path yet.
+        P = sum(w[0] for w in works) / ns
+        C = sum(w[1] for w in works) / ns
+        bytes_per_pair = 128.0 * (2.0 * P + C + 4.0) + 2 * args.read_len / 4.0 + 64
+        step_s = elapsed / args.steps
+        out["roofline"] = {"bound": "hbm", "achieved": bytes_per_pair * n / step_s / 1e9, "peak": HBM_PEAK / 1e9,
+                           "unit": "GB/s", "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": None,
+                           "kernel": "whole paired-end step (k_pe_topk_dual + list kernels of both mates, k_pe_merge)",
+                           "algorithmic_bytes_per_pair": bytes_per_pair,
+                           "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate, 2 per "
+                                          "mate for the ranked list) + streamed reads / pair record",
+                           "per_pair": {"probes": P, "candidates": C}}
     if rank == 0:
         print(json.dumps(out), flush=True)
     idx.close()
@@ -348,6 +364,7 @@ def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, 
     start = np.zeros(len(lens) + 1, dtype=np.uint32)
     start[1:] = np.cumsum(lens, dtype=np.uint64).astype(np.uint32)
     ranked, counts = [], []
+    works = []
     elapsed = 0.0
     for mate, bases in ((0, m1_host), (1, m2_host)):
         keep = []
@@ -368,6 +385,7 @@ def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, 
         elapsed += time.perf_counter() - t0
         ranked.append(r)
         counts.append(c)
+        works.append((float(work[0]["probes"]), float(work[0]["cands"])))
         del keep, arr
     out = np.zeros(n, dtype=refio.pair_dtype)
     t0 = time.perf_counter()
@@ -375,7 +393,7 @@ def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, 
                            top_k, offsets.ctypes.data, offsets.ctypes.data, n, start.ctypes.data, len(lens), frag_range,
                            max_mm, out.ctypes.data)
     elapsed += time.perf_counter() - t0
-    return out, elapsed, cores
+    return out, elapsed, cores, works
 
 
 def main():
