@@ -231,13 +231,22 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
         # both mates (oracle counters) -> 2 P + C dependent gathers of one 128-byte line each, plus per mate the
         # ranked list written by the top-k kernel and read back by the merge (one line each way), the packed
         # reads and the 64-byte pair record.  Time = the whole step (the mates' kernels overlap on several
-        # streams, so no single kernel's duration is meaningful); no PMC traffic figure for this path yet.
+        # streams, so no single kernel's duration is meaningful); traffic from profiles/traffic_pe.json when it matches.
         P = sum(w[0] for w in works) / ns
         C = sum(w[1] for w in works) / ns
         bytes_per_pair = 128.0 * (2.0 * P + C + 4.0) + 2 * args.read_len / 4.0 + 64
         step_s = elapsed / args.steps
+        traffic = None  # PMC figure of tools/prof_pmc.sh ... --mode pe + tools/pe_traffic.py, for this exact workload
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic_pe.json")))
+            if (t.get("pairs_per_step") == n and args.read_len == 100 and args.max_mismatches == 6 and
+                    args.bucket == 5000 and args.top_k == 50 and args.pattern == 3 and not args.contigs):
+                traffic = t["hbm_bytes_per_step"]
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "hbm", "achieved": bytes_per_pair * n / step_s / 1e9, "peak": HBM_PEAK / 1e9,
-                           "unit": "GB/s", "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": None,
+                           "unit": "GB/s", "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": traffic,
+                           "traffic_frac": (traffic / step_s / HBM_PEAK) if traffic else None,
                            "kernel": "whole paired-end step (k_pe_topk_dual + list kernels of both mates, k_pe_merge)",
                            "algorithmic_bytes_per_pair": bytes_per_pair,
                            "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate, 2 per "
