@@ -35,6 +35,9 @@ def make_genome(rng, pattern):
             s[p:p + ln] = unit[:ln]
         seqs.append(("c%d" % i, "".join(s)))
     seqs.append(("big", "".join(rng.choice(alphabet) for _ in range(20000)) + unit * 3))
+    if rng.random() < 0.12:  # now and then a few Mbp, so that buckets and directory slots fill up
+        big = np.random.default_rng(rng.randrange(1 << 30)).integers(0, len(alphabet), rng.choice([1500000, 4000000]))
+        seqs.append(("huge", "".join(np.array(list(alphabet))[big])))
     return seqs
 
 
