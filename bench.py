@@ -200,8 +200,8 @@ def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
     from walt_amd import dist as wdist
     elapsed = wdist.allreduce_max(elapsed, device=dev)  # MAX over ranks
     ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last chunk (map_pe.hip carve_pe)
-    log("last chunk: literal-list %d / %d, complex-list %d / %d (mate 1 / mate 2), heavy pairs %d" % (
-        int(ctl[64]), int(ctl[96]), int(ctl[88]), int(ctl[120]), int(ctl[128])))
+    log("last chunk: literal-list %d / %d, of which overflowed the 8-slot heaps %d / %d (mate 1 / mate 2), heavy pairs %d" % (
+        int(ctl[64]), int(ctl[96]), int(ctl[89]), int(ctl[121]), int(ctl[128])))
     res = d_out.view(torch.int32).view(n, 16)
     bt = res[:, 8]
     # StatPairedReads pair counters (paired.hpp:96-105), summed over ranks: the only collective

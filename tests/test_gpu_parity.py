@@ -378,3 +378,54 @@ def test_gpu_filter_covers_every_dangerous_probe(wa, scratch, monkeypatch):
         checked += buf[14]
         idx.close()
     assert checked > 5000
+
+
+def test_gpu_pe_small_heaps_with_overflow_list(wa, scratch, monkeypatch):
+    """The literal list kernel of the paired-end path switches to 8-slot heaps (64 reads per wavefront) when its
+    list is long, and hands reads that collect more candidates to an overflow list mapped with full heaps.
+    WALT_AMD_SMALL_HEAPS forces that mode.  Genome: 300 short chromosomes cut from one repeated sequence, so
+    that most reads are deferred to the literal list (chromosome ends everywhere) AND collect dozens of
+    candidates (every read occurs in many chromosomes): the overflow path carries most of the load.  Pair
+    records and ranked lists must equal the oracle's."""
+    monkeypatch.setenv("WALT_AMD_SMALL_HEAPS", "1")
+    rng = random.Random(4242)
+    unit = "".join(rng.choice("ACGT") for _ in range(600))
+    seqs = []
+    for i in range(300):
+        a = rng.randrange(0, 300)
+        L = rng.choice([60, 90, 131, 150, 200, 260])
+        s_ = list(unit[a:a + L])
+        for _ in range(rng.randrange(0, 3)):
+            s_[rng.randrange(len(s_))] = rng.choice("ACGT")
+        seqs.append(("u%d" % i, "".join(s_)))
+    seqs.append(("long", unit * 3))
+    fa = os.path.join(scratch, "crowded_pe.fa")
+    with open(fa, "w") as f:
+        for nm, s_ in seqs:
+            f.write(">%s\n%s\n" % (nm, s_))
+    path = os.path.join(scratch, "crowded_pe.dbindex")
+    wa.makedb(fa, path, threads=4)
+    db = refio.DbIndex(path)
+    s1, s2 = [], []
+    big = unit * 3
+    for _ in range(1500):
+        flen = rng.randrange(120, 400)
+        a = rng.randrange(0, len(big) - flen)
+        frag = big[a:a + flen]
+        if rng.random() < 0.5:
+            frag = refio.revcomp(frag)
+        frag = "".join("T" if (c == "C" and rng.random() < 0.9) else c for c in frag)
+        L = rng.choice([50, 75, 100])
+        s1.append(frag[:L])
+        s2.append(refio.revcomp(frag)[:L])
+    idx = wa.Index.open(path, device=0)
+    deferred_any = False
+    for k in (50, 5, 300):
+        res, stats, ranked = idx.map_pe_batch(*wa.pack_reads(s1), *wa.pack_reads(s2), top_k=k, want_ranked=True)
+        wantp, wranked, _ = refio.oracle_pe(db, s1, s2, top_k=k)
+        for f in ("best_times", "frag_len", "pair_mm", "best_i", "best_j"):
+            assert np.array_equal(res[f], wantp[f]), (k, f)
+        assert np.array_equal(ranked[1], wranked[1]) and np.array_equal(ranked[3], wranked[3])
+        deferred_any = deferred_any or int(np.max(ranked[1])) > 8
+    assert deferred_any, "the read set should produce lists longer than the small heaps"
+    idx.close()

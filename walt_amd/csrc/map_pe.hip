@@ -63,7 +63,13 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
                                            Candidate* __restrict__ ranked,
                                            uint32_t* __restrict__ heap_n, uint32_t* __restrict__ defer_count,
                                            uint32_t* __restrict__ defer_list, uint32_t& n_probe,
-                                           uint32_t& n_verified, uint32_t& n_big, uint32_t& len_out) {
+                                           uint32_t& n_verified, uint32_t& n_big, uint32_t& len_out,
+                                           uint32_t heap_cap = 0xFFFFFFFFu, uint32_t* __restrict__ over_count = nullptr,
+                                           uint32_t* __restrict__ over_list = nullptr) {
+  // heap_cap < top_k: this lane's heap has room for heap_cap candidates only (more reads per wavefront share
+  // the LDS); a read that collects more is handed to over_list and mapped again with a full heap.  Below
+  // top_k entries TopCandidates::Push only appends, so nothing else changes.
+  bool overflow = false;
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
@@ -121,7 +127,8 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
               ++n_verified;
               if (mm <= max_mm) {  // paired.cpp:192-195
                 HeapEnt e; e.pos = gp; e.mms = mm | (fi << 31);
-                topk_push(heap, hsize, top_k, e);
+                if (heap_cap < top_k && hsize >= heap_cap) { overflow = true; mappable = false; }
+                if (!overflow) topk_push(heap, hsize, top_k, e);
               }
             }
           }
@@ -179,7 +186,8 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
               const uint32_t c_gp = bcast(gp, src), c_mm = bcast(mm, src);
               if ((int)lane == owner) {
                 HeapEnt e; e.pos = c_gp; e.mms = c_mm | (fi << 31);
-                topk_push(heap, hsize, top_k, e);
+                if (heap_cap < top_k && hsize >= heap_cap) { overflow = true; mappable = false; }
+                if (!overflow) topk_push(heap, hsize, top_k, e);
               }
             }
           }
@@ -188,9 +196,11 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
       }
     }
   }
+  const bool over = valid && overflow && !(!LITERAL && deferred);
+  if (over_list) wave_append(over, r, over_count, over_list);  // every lane of the wave gets here
   if (!LITERAL && deferred) {
     defer_list[atomicAdd(defer_count, 1u)] = r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r;
-  } else if (valid) {
+  } else if (valid && !over) {
     // paired.cpp:685-692: pop everything; ranked[r][i] = i-th popped (descending mismatch)
     heap_n[r] = hsize;
     Candidate* out = ranked + (uint64_t)r * top_k;
@@ -403,9 +413,12 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uin
                                                           const uint32_t* __restrict__ list_count,
                                                           const uint32_t* __restrict__ list,
                                                           uint32_t* __restrict__ defer_count,
-                                                          uint32_t* __restrict__ defer_list, uint32_t all_reads) {
+                                                          uint32_t* __restrict__ defer_list, uint32_t all_reads,
+                                                          uint32_t heap_cap = 0, uint32_t* __restrict__ over_count = nullptr,
+                                                          uint32_t* __restrict__ over_list = nullptr) {
   __shared__ BlockShared sh;
   __shared__ HeapEnt s_heap[kBlock / 64][kListHeapSlots];  // the heaps of the reads a wave is working on
+  if (!all_reads && *list_count == 0) return;  // empty list (the usual state of the overflow list): no prologue
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   // all_reads != 0 (seed patterns 5 and 7, which have no pass 1): every read 0 .. all_reads-1
   const uint32_t count = all_reads ? all_reads : *list_count;
@@ -418,16 +431,24 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uin
   const uint32_t total_waves = gridDim.x * waves_per_block;
   const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
   uint32_t rpw = (count + total_waves - 1) / total_waves;
-  const uint32_t rpw_max = kListHeapSlots / top_k < 64 ? kListHeapSlots / top_k : 64;  // top_k <= 300: at least 2
+  // heap slots per read: top_k, or heap_cap when the launch offers small heaps with an overflow list AND the
+  // list is too long for full heaps to keep every wave busy anyway (a short list gains nothing from them)
+  const uint32_t rpw_full = kListHeapSlots / top_k < 64 ? kListHeapSlots / top_k : 64;
+  const uint32_t want_cap = heap_cap & 0x7FFFFFFFu;  // bit 31: use the small heaps whatever the list length (tests)
+  const bool small = want_cap && want_cap < top_k && over_list &&
+                     ((heap_cap >> 31) || (uint64_t)count > (uint64_t)rpw_full * total_waves);
+  const uint32_t cap = small ? want_cap : top_k;
+  const uint32_t rpw_max = kListHeapSlots / cap < 64 ? kListHeapSlots / cap : 64;  // top_k <= 300: at least 2
   rpw = rpw < 1 ? 1 : (rpw > rpw_max ? rpw_max : rpw);
-  HeapEnt* heap = &s_heap[threadIdx.x >> 6][(lane < rpw ? lane : 0) * top_k];
+  HeapEnt* heap = &s_heap[threadIdx.x >> 6][(lane < rpw ? lane : 0) * cap];
   for (uint64_t base = (uint64_t)wave * rpw; base < count; base += (uint64_t)total_waves * rpw) {
     const uint64_t i = base + lane;
     const bool valid = lane < rpw && i < count;
     const uint32_t r = valid ? (all_reads ? (uint32_t)i : (list[i] & kDeferMask)) : 0;
     uint32_t len;
     pe_process<NW, LITERAL>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, heap, ranked,
-                            heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len);
+                            heap_n, defer_count, defer_list, n_probe, n_verified, n_big, len,
+                            cap < top_k ? cap : 0xFFFFFFFFu, over_count, over_list);
     if (all_reads) shortv += (valid && len < kMinReadLen) ? 2u : 0u;  // paired.cpp:112-115, once per strand pass
   }
   pe_flush(shortv, n_probe, n_verified, n_big, stats);
@@ -671,8 +692,16 @@ static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const u
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, cplx_count, cplx_list, lit_count,
                      lit_list, 0u);
   launch_bin_deferred(lit_count, lit_list, lit_sorted, stream);
+  // literal list: 8-slot heaps, so that 64 reads share a wavefront instead of 15 at -k 50 (with thousands of
+  // contigs a tenth of the reads is here); the few reads with more candidates overflow into the complex list's
+  // area, which is free again, and are mapped with full heaps
+  const uint32_t kSmallHeap = 8u | (getenv("WALT_AMD_SMALL_HEAPS") ? 0x80000000u : 0u);  // env: force (tests)
+  uint32_t* over_count = ctl + 25;  // zeroed with the control block at the start of the pass
   hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
-                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr, 0u);
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr, 0u,
+                     kSmallHeap, over_count, cplx_list);
+  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+                     max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, over_count, cplx_list, nullptr, nullptr, 0u);
   return WALT_OK;
 #endif
 }
