@@ -2,22 +2,29 @@
 """bench.py -- mapped reads/s of the single-end seed-and-extend hot path on
 N x MI355X (BASELINE.json: metric "mapped reads/sec (100 bp, hg19)").
 
-Workload at N=1 (BASELINE.json configs[1]): hg19-scale synthetic genome (24
-chromosomes with hg19's lengths, 3.096 Gbp, iid bases + implanted repeat
-families), its _CT00/_CT01 strand indexes built on the GPU by the product's
-makedb-compatible builder, 50 M synthetic 100 bp single-end reads (both
-strands, 95 % C->T, 1 % substitutions), -m 6 -b 5000.  A step = one pass of the
-hot path over the whole resident batch (read packing + mapping kernels, both
-strand passes).  For N > 1 every rank holds a full index replica and its own
-50 M-read shard (weak scaling, BASELINE.json configs[3]); the only collective is
-the final all-reduce of the mapping statistics over RCCL.
+Workload at N=1 (BASELINE.json configs[1]): an hg19-LIKE synthetic genome (tools/synth.py: hg19's 93
+sequences, 3,137,161,264 bp, Alu-/L1-like families, segmental duplications, satellites, simple repeats --
+calibrated against the reference's own tables of region sizes and unique fractions on real hg19), its
+_CT00/_CT01 strand indexes built on the GPU by the product's makedb-compatible builder, 50 M synthetic
+100 bp single-end reads (both strands, 95 % C->T, 1 % substitutions), -m 6 -b 5000.  A step = one pass of
+the hot path over the whole resident batch (read packing + mapping kernels, both strand passes).
+`--genome easy` is the round-1 genome (iid + four small families).
+
+N > 1 (configs[3]): `python bench.py --gpus N` starts N ranks itself (torch.distributed.run as a child
+process, before anything touches the GPU); under an external launcher it checks WORLD_SIZE == N.  Every
+rank holds a full index replica and its own 50 M-read shard (weak scaling); the only collective is the
+final all-reduce of the statistics block over RCCL.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     : algorithmic bytes of the implemented search per launch (128-byte
-                 line per dependent gather) / HIP-event duration
-                 of the mapping kernels, vs 8 TB/s; measured HBM traffic beside it
-  cpu_baseline : the oracle restatement (bit-exact to the reference, OpenMP on
-                 all host cores) timed on a bounded sample of the same reads.
+  roofline     : algorithmic bytes of the implemented search per launch (128-byte line per dependent
+                 gather; DESIGN.md section 6) / HIP-event duration of the mapping kernels, vs 8 TB/s;
+                 measured HBM traffic (PMC, profiles/traffic.json) beside it
+  cpu_baseline : the oracle restatement (bit-exact to the reference, OpenMP on all host cores) timed on a
+                 uniform sample of the batch; the same pass checks GPU records bit for bit on that sample
+                 and on the hard classes (ambiguous, unmapped, deferred to the literal pass)
+  extra_lines  : (N = 1) the other BASELINE configs timed in the same process on the same box:
+                 configs[2] paired-end 2 x 100 bp, configs[4] 150 bp -A single-end and 2 x 150 bp PBAT
+                 paired-end at -m 10 -- each with its own roofline / cpu_baseline / bit_exact_vs_gpu.
 """
 import argparse
 import ctypes
@@ -26,17 +33,11 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HG19 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431,
-        135534747, 135006516, 133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983,
-        63025520, 48129895, 51304566, 155270560, 59373566]
-HG19_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 
 
@@ -45,255 +46,250 @@ def log(msg):
         print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def make_genome(torch, dev, scale, seed, contigs=0):
-    """ASCII genome on the GPU: iid bases + repeat families (deterministic per seed)."""
-    lens = [max(1000, int(l * scale)) for l in HG19]
-    if contigs:  # same bases cut into equal contigs: an assembly of many scaffolds (chromosome-end handling)
-        total = sum(lens)
-        lens = [total // contigs] * (contigs - 1) + [total - (total // contigs) * (contigs - 1)]
-    L = sum(lens)
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    codes = torch.empty(L, dtype=torch.uint8, device=dev)
-    step = 1 << 28
-    for s in range(0, L, step):
-        e = min(L, s + step)
-        codes[s:e] = torch.randint(0, 4, (e - s,), generator=g, device=dev, dtype=torch.uint8)
-
-    def implant(unit_len, copies, divergence):
-        if copies < 1:
-            return
-        unit = torch.randint(0, 4, (unit_len,), generator=g, device=dev, dtype=torch.uint8)
-        slot = max(unit_len + 64, L // (copies + 1))
-        nslots = (L - unit_len - 64) // slot
-        copies_eff = min(copies, nslots)
-        which = torch.randperm(nslots, generator=g, device=dev)[:copies_eff]
-        jitter = torch.randint(0, max(1, slot - unit_len - 32), (copies_eff,), generator=g, device=dev)
-        starts = which * slot + jitter
-        for c0 in range(0, copies_eff, 1 << 20):
-            st = starts[c0:c0 + (1 << 20)]
-            idx = (st[:, None] + torch.arange(unit_len, device=dev)[None, :]).reshape(-1)
-            vals = unit.repeat(st.numel())
-            if divergence > 0:
-                mut = torch.rand(vals.numel(), generator=g, device=dev) < divergence
-                rnd = torch.randint(1, 4, (vals.numel(),), generator=g, device=dev, dtype=torch.uint8)
-                vals = torch.where(mut, (vals + rnd) & 3, vals)
-            codes[idx] = vals
-
-    implant(300, int(20000 * scale), 0.10)    # SINE-like family
-    implant(6000, int(500 * scale), 0.02)     # LINE-like family
-    implant(48, int(600000 * scale), 0.0)     # exact micro-repeat: raw bucket >= 500000 is erased (reference.cpp:211)
-    implant(150, int(8000 * scale), 0.0)      # exact repeat: narrowed region > -b 5000 is skipped (mapping.cpp:275)
-    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
-    ascii_g = lut[codes.long()] if L < (1 << 28) else torch.cat([lut[codes[s:s + step].long()] for s in range(0, L, step)])
-    return ascii_g, lens
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome", choices=["hg19like", "easy"], default="hg19like",
+                    help="hg19like: 93 sequences, repeat-rich (tools/synth.py); easy: the round-1 genome")
+    ap.add_argument("--genome-mbp", type=float, default=None, help="synthetic genome size (default: full scale)")
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="uniform sample of the batch the oracle maps")
+    ap.add_argument("--hard-sample", type=int, default=100_000, help="reads per hard class added to the exactness check")
+    ap.add_argument("--max-mismatches", type=int, default=6)
+    ap.add_argument("--bucket", type=int, default=5000)
+    ap.add_argument("--dir-bits", type=int, default=-1)
+    ap.add_argument("--contigs", type=int, default=0, help="cut the genome into this many equal contigs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["se", "pe"], default="se", help="headline leg: se = configs[1], pe = configs[2]")
+    ap.add_argument("--ag", action="store_true", help="single-end -A: A-rich reads on the _GA10/_GA11 indexes")
+    ap.add_argument("--pbat", action="store_true", help="paired-end -P: mate 1 is the A-rich mate (mates exchanged for mapping)")
+    ap.add_argument("--top-k", type=int, default=50)
+    ap.add_argument("--frag-range", type=int, default=1000)
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_lines legs (configs[2], configs[4])")
+    ap.add_argument("--extra-pairs", type=int, default=0, help="pairs of the extra paired-end legs (default: --reads, 150 bp: half)")
+    ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--ref-sample", type=int, default=2_000_000,
+                    help="reads the real reference binary (oracle/_ref/walt) maps beside the oracle port at N=1 "
+                         "(0 = skip; needs ~35 GB of RAM-backed scratch for the index copy)")
+    ap.add_argument("--slot-table", action="store_true",
+                    help="build the opt-in direct-mapped slot table (WALT_AMD_TABLE=1: +51.5 GB per strand at hg19 scale)")
+    ap.add_argument("--seed-offset", type=int, default=0,
+                    help="added to the rank in the read seeds (tests: rank r of an N-rank run == a 1-rank run at offset r)")
+    ap.add_argument("--pattern", type=int, choices=[3, 5, 7], default=3,
+                    help="seed pattern (the reference's -D SEEDPATTERN3/5/7); 5 and 7 use libwalt_amd_sp5/_sp7.so")
+    return ap.parse_args(argv)
 
 
-def make_reads(torch, dev, genome_ascii, n, read_len, seed):
-    """n x read_len ASCII reads on the GPU: both strands, 95 % C->T, 1 % substitutions."""
-    L = genome_ascii.numel()
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    out = torch.empty((n, read_len), dtype=torch.uint8, device=dev)
-    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
-    for a, b in ((65, 84), (67, 71), (71, 67), (84, 65)):
-        comp[a] = b
-    ar = torch.arange(read_len, device=dev)
-    chunk = 1 << 22
-    for s in range(0, n, chunk):
-        m = min(chunk, n - s)
-        pos = torch.randint(0, L - read_len, (m,), generator=g, device=dev)
-        r = genome_ascii[pos[:, None] + ar[None, :]]
-        rev = torch.rand(m, generator=g, device=dev) < 0.5
-        rc = comp[r.flip(1).long()]
-        r = torch.where(rev[:, None], rc, r)
-        conv = (r == 67) & (torch.rand(r.shape, generator=g, device=dev) < 0.95)
-        r = torch.where(conv, torch.full_like(r, 84), r)
-        sub = torch.rand(r.shape, generator=g, device=dev) < 0.01
-        lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
-        rnd = lut[torch.randint(0, 4, r.shape, generator=g, device=dev)]
-        r = torch.where(sub, rnd, r)
-        out[s:s + m] = r
-    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * read_len
-    return out.reshape(-1), offsets
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start the N ranks as a CHILD process (this process never initialises the
+    GPU), forward their output and exit with their status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
-def make_pairs(torch, dev, genome_ascii, n, read_len, seed):
-    """n pairs on the GPU: fragment length U[120,500] from either strand, bisulfite (95 % C->T on the
-    fragment), mate 1 = fragment[:L], mate 2 = revcomp(fragment)[:L], 1 % substitutions."""
-    L = genome_ascii.numel()
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    m1 = torch.empty((n, read_len), dtype=torch.uint8, device=dev)
-    m2 = torch.empty((n, read_len), dtype=torch.uint8, device=dev)
-    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
-    for a, b in ((65, 84), (67, 71), (71, 67), (84, 65)):
-        comp[a] = b
-    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
-    ar = torch.arange(read_len, device=dev)
-    chunk = 1 << 21
-    for s in range(0, n, chunk):
-        m = min(chunk, n - s)
-        flen = torch.randint(max(120, read_len), 501, (m,), generator=g, device=dev)
-        pos = torch.randint(0, L - 600, (m,), generator=g, device=dev)
-        rev = torch.rand(m, generator=g, device=dev) < 0.5
-        # 5' end of the fragment on its own strand, and the 5' end of the opposite strand
-        left = genome_ascii[pos[:, None] + ar[None, :]]                                  # genome[pos : pos+L]
-        right = comp[genome_ascii[(pos + flen)[:, None] - 1 - ar[None, :]].long()]       # revcomp of the last L bases
-        f5 = torch.where(rev[:, None], right, left)     # fragment[:L]
-        f3rc = torch.where(rev[:, None], left, right)   # what revcomp(fragment)[:L] is BEFORE conversion ...
-        # bisulfite acts on the fragment strand: C->T in f5; the mate-2 read is the reverse complement of the
-        # converted fragment end, i.e. G->A relative to the opposite strand
-        r1 = torch.where((f5 == 67) & (torch.rand(f5.shape, generator=g, device=dev) < 0.95), torch.full_like(f5, 84), f5)
-        r2 = torch.where((f3rc == 71) & (torch.rand(f5.shape, generator=g, device=dev) < 0.95), torch.full_like(f5, 65), f3rc)
-        for r, dst in ((r1, m1), (r2, m2)):
-            sub = torch.rand(r.shape, generator=g, device=dev) < 0.01
-            rnd = lut[torch.randint(0, 4, r.shape, generator=g, device=dev)]
-            dst[s:s + m] = torch.where(sub, rnd, r)
-    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * read_len
-    return m1.reshape(-1), m2.reshape(-1), offsets
+class Ctx:
+    pass
 
 
-def run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens):
-    """configs[2]: paired-end mapping (top-k heaps + pair merge on the device); reports pairs/s."""
-    t0 = time.perf_counter()
-    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, HG19_NAMES, device=local,
-                                      strands=walt_amd.STRANDS_ALL, dir_bits=args.dir_bits)
-    t_index = time.perf_counter() - t0
-    log("index (4 strands): %.1f GB in HBM, dir_bits %d (%.1f s)" % (idx.device_bytes / 1e9, idx.dir_bits, t_index))
-    n = args.reads
-    d1, d2, d_off = make_pairs(torch, dev, genome_ascii, n, args.read_len, seed=2000 + rank)
-    torch.cuda.synchronize()
-    run_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    ns = min(args.cpu_sample // 4, n)  # paired-end costs ~3.4x single-end per read on the CPU (SURVEY a15)
-    if run_cpu:
-        m1_host, m2_host = d1[:ns * args.read_len].cpu().numpy(), d2[:ns * args.read_len].cpu().numpy()
-    del genome_ascii
-    torch.cuda.empty_cache()
-    d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
-    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
-    d_ws = torch.empty(walt_amd.lib().walt_pe_workspace_bytes(n, args.read_len, args.top_k), dtype=torch.uint8, device=dev)
+# ------------------------------------------------------------------------------------------------ single-end
+def se_leg(cx, idx, d_bases, d_off, n, read_len, max_mm, b, ag, steps, warmup, timed_barrier=True):
+    """K timed steps of the single-end hot path on a resident batch; returns timing + device result tensors."""
+    torch, walt_amd = cx.torch, cx.walt_amd
+    dev = cx.dev
+    d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+    d_ws = torch.empty(walt_amd.lib().walt_se_workspace_bytes(n, read_len), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    idx.profile_enable(True)
 
     def step():
-        rc = walt_amd.lib().walt_map_pe_batch_device(idx.handle, d1.data_ptr(), d_off.data_ptr(), d2.data_ptr(),
-                                                     d_off.data_ptr(), n, args.read_len, args.max_mismatches,
-                                                     args.bucket, args.top_k, args.frag_range, d_out.data_ptr(),
-                                                     d_stats.data_ptr(), d_ws.data_ptr(), stream)
-        assert rc == 0, walt_amd.lib().walt_last_error()
+        idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, read_len, d_out.data_ptr(),
+                                d_stats.data_ptr(), d_ws.data_ptr(), stream=stream, ag_wildcard=ag,
+                                max_mismatches=max_mm, b=b)
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    barrier()
+    cx.barrier() if timed_barrier else torch.cuda.synchronize()
+    pack_ms, map_ms = [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    barrier()
+        p_ms, m_ms = idx.profile_last()  # waits for this step's events (same stream)
+        pack_ms.append(p_ms)
+        map_ms.append(m_ms)
+    cx.barrier() if timed_barrier else torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     idx.check_batch(d_ws.data_ptr(), stream)  # no invalid read went unnoticed
-    from walt_amd import dist as wdist
-    elapsed = wdist.allreduce_max(elapsed, device=dev)  # MAX over ranks
-    ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last chunk (map_pe.hip carve_pe)
-    log("last chunk: literal-list %d / %d, of which overflowed the 8-slot heaps %d / %d (mate 1 / mate 2), heavy pairs %d" % (
-        int(ctl[64]), int(ctl[96]), int(ctl[89]), int(ctl[121]), int(ctl[128])))
-    res = d_out.view(torch.int32).view(n, 16)
-    bt = res[:, 8]
-    # StatPairedReads pair counters (paired.hpp:96-105), summed over ranks: the only collective
-    pst = wdist.allreduce_stats(torch.stack([torch.tensor(n, device=dev), (bt == 1).sum(), (bt >= 2).sum(),
-                                             (bt == 0).sum()]).to(torch.int64))
-    pairs_t, uniq_t, amb_t, unp_t = [int(v) for v in pst.tolist()]
-    out = {"metric": "mapped read pairs/sec (2 x %d bp paired-end, hg19-scale index, -m %d -k %d -L %d)" % (
-               args.read_len, args.max_mismatches, args.top_k, args.frag_range),
-           "value": world * n * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-           "config": {"workload": "configs[2]: hg19-scale synthetic genome, %d pairs 2 x %d bp, fragment U[120,500]" % (
-               n, args.read_len), "index_hbm_gb": round(idx.device_bytes / 1e9, 2)},
-           "mapping": {"pairs": pairs_t, "unique_pairs": uniq_t, "ambiguous_pairs": amb_t, "unpaired": unp_t}}
-    if run_cpu:
-        want, cpu_s, cores, works = cpu_baseline_pe(idx, m1_host, m2_host, args.read_len, ns, lens, args.max_mismatches,
-                                                    args.bucket, args.top_k, args.frag_range)
-        got = d_out[:ns * 64].cpu().numpy().view(walt_amd.pair_result_dtype)
-        same = all(np.array_equal(got[f], want[f]) for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"))
-        for m in ("m1", "m2"):
-            same = same and all(np.array_equal(got[m][f], want[m][f]) for f in ("genome_pos", "times", "strand", "mismatch"))
-        out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "pairs/s", "cores": cores, "kind": "port",
-                               "sample": "first %d pairs, oracle restatement of PairEndMapping on both mates and "
-                                         "strands + pair merge, OpenMP; two strand indexes in host memory at a time" % ns,
-                               "bit_exact_vs_gpu": bool(same)}
-        # Same accounting as the single-end line (DESIGN.md section 6): per pair, P probes and C candidates over
-        # both mates (oracle counters) -> 2 P + C dependent gathers of one 128-byte line each, plus per mate the
-        # ranked list written by the top-k kernel and read back by the merge (one line each way), the packed
-        # reads and the 64-byte pair record.  Time = the whole step (the mates' kernels overlap on several
-        # streams, so no single kernel's duration is meaningful); traffic from profiles/traffic_pe.json when it matches.
-        P = sum(w[0] for w in works) / ns
-        C = sum(w[1] for w in works) / ns
-        bytes_per_pair = 128.0 * (2.0 * P + C + 4.0) + 2 * args.read_len / 4.0 + 64
-        step_s = elapsed / args.steps
-        traffic = None  # PMC figure of tools/prof_pmc.sh ... --mode pe + tools/pe_traffic.py, for this exact workload
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "traffic_pe.json")))
-            if (t.get("pairs_per_step") == n and args.read_len == 100 and args.max_mismatches == 6 and
-                    args.bucket == 5000 and args.top_k == 50 and args.pattern == 3 and not args.contigs):
-                traffic = t["hbm_bytes_per_step"]
-        except (OSError, ValueError, KeyError):
-            pass
-        out["roofline"] = {"bound": "hbm", "achieved": bytes_per_pair * n / step_s / 1e9, "peak": HBM_PEAK / 1e9,
-                           "unit": "GB/s", "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": traffic,
-                           "traffic_frac": (traffic / step_s / HBM_PEAK) if traffic else None,
-                           "kernel": "whole paired-end step (k_pe_topk_dual + list kernels of both mates, k_pe_merge)",
-                           "algorithmic_bytes_per_pair": bytes_per_pair,
-                           "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate, 2 per "
-                                          "mate for the ranked list) + streamed reads / pair record",
-                           "per_pair": {"probes": P, "candidates": C}}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    idx.close()
+    st = d_stats.cpu().numpy() // (warmup + steps)  # walt_batch_stats of ONE step
+    ctl = d_ws[:64 * 4].view(torch.int32).cpu().numpy()
+    n_def = int(ctl[32])
+    # deferred list of the last step (workspace layout of map_se.hip: control words, statistic shards, list)
+    deferred = None
+    if n_def and cx.pattern == 3:
+        off = 64 * 4 + 256 * 16 * 8
+        deferred = (d_ws[off:off + 4 * n_def].view(torch.int32) & 0x0FFFFFFF).long()
+    return {"elapsed": elapsed, "pack_ms": pack_ms, "map_ms": map_ms, "d_out": d_out, "stats": st, "deferred": deferred,
+            "n_deferred": n_def, "d_ws": d_ws}
 
 
-def cpu_baseline(idx, reads_host, read_len, n_sample, lens, max_mm, b):
-    """Oracle restatement on the host cores, one strand index in memory at a time
-    (as the reference itself does, mapping.cpp:491-492)."""
+def se_sample(cx, leg, n, n_uniform, n_hard):
+    """Read indices the oracle checks: a uniform stride sample of the whole batch, plus up to n_hard reads of each
+    hard class as the GPU saw them (ambiguous, unmapped, deferred to the literal pass)."""
+    torch = cx.torch
+    times = leg["d_out"].view(torch.int32).view(n, 4)[:, 1]
+    nu = min(n_uniform, n)
+    uni = (torch.arange(nu, device=cx.dev, dtype=torch.int64) * n) // nu
+    hard = []
+    for cls in (times >= 2, times == 0):
+        ix = torch.nonzero(cls).flatten()
+        if ix.numel() > n_hard:
+            ix = ix[(torch.arange(n_hard, device=cx.dev, dtype=torch.int64) * ix.numel()) // n_hard]
+        hard.append(ix)
+    if leg["deferred"] is not None:
+        ix = leg["deferred"]
+        if ix.numel() > n_hard:
+            ix = ix[(torch.arange(n_hard, device=cx.dev, dtype=torch.int64) * ix.numel()) // n_hard]
+        hard.append(ix)
+    hard = torch.unique(torch.cat(hard)) if hard else torch.zeros(0, dtype=torch.int64, device=cx.dev)
+    return uni, hard
+
+
+def oracle_se_jobs(cx, idx, jobs, lens, strands):
+    """One export of each strand to the host serves every job (the reference also holds one strand index at a
+    time, mapping.cpp:491-492).  job: dict(bases [m*L] uint8 numpy, m, read_len, max_mm, b, ag, timed_first) ->
+    adds out (orc_best[m]), trace, work, cpu_s (time of the first `timed_first` reads only)."""
+    import numpy as np
     import refio
-    import walt_amd
-    cores = walt_amd.effective_cpus()  # affinity capped by the cgroup CPU quota (the GPU box grants 16 of 256)
+    cores = cx.walt_amd.effective_cpus()
     orc = refio.oracle()
-    n = n_sample
-    bases = np.ascontiguousarray(reads_host[:n * read_len])
-    offsets = (np.arange(n + 1, dtype=np.uint64) * read_len)
     start = np.zeros(len(lens) + 1, dtype=np.uint32)
     start[1:] = np.cumsum(lens, dtype=np.uint64).astype(np.uint32)
-    out = np.zeros(n, dtype=refio.best_dtype)
-    work = np.zeros(1, dtype=refio.work_dtype)
-    orc.orc_se_init(out.ctypes.data, n, max_mm)
-    elapsed = 0.0
-    for strand, ch in ((0, b"+"), (1, b"-")):
-        g, cnt, ix = idx.export_strand(strand)
+    for j in jobs:
+        m = j["m"]
+        j["out"] = np.zeros(m, dtype=refio.best_dtype)
+        orc.orc_se_init(j["out"].ctypes.data, m, j["max_mm"])
+        j["trace"] = np.zeros(m, dtype=refio.trace_dtype)
+        j["work"] = np.zeros(1, dtype=refio.work_dtype)
+        j["work_timed"] = np.zeros(1, dtype=refio.work_dtype)
+        j["cpu_s"] = 0.0
+        j["cores"] = cores
+    for k, ch in ((0, b"+"), (1, b"-")):
+        g, cnt, ix = idx.export_strand(strands[k])
         x = refio.make_orc_strand(g, cnt, ix, start)
-        t0 = time.perf_counter()
-        orc.orc_se_map_strand(ctypes.addressof(x), ch, bases.ctypes.data, offsets.ctypes.data, n, 0, b, cores,
-                              out.ctypes.data, work.ctypes.data)
-        elapsed += time.perf_counter() - t0
+        for j in jobs:
+            L, m, mt = j["read_len"], j["m"], min(j["timed_first"], j["m"])
+            offs = np.arange(m + 1, dtype=np.uint64) * L
+            for lo, hi, timed in ((0, mt, True), (mt, m, False)):
+                if hi <= lo:
+                    continue
+                w = j["work_timed"] if timed else j["work"]
+                t0 = time.perf_counter()
+                orc.orc_se_map_strand_trace(ctypes.addressof(x), ch, j["bases"].ctypes.data + lo * L,
+                                            (offs[:hi - lo + 1]).ctypes.data, hi - lo, int(j["ag"]), j["b"], cores,
+                                            j["out"].ctypes.data + lo * 16, w.ctypes.data,
+                                            j["trace"].ctypes.data + lo * 16)
+                if timed:
+                    j["cpu_s"] += time.perf_counter() - t0
         del g, cnt, ix, x
-    return out, work[0], elapsed, cores
 
 
-def reference_binary_leg(idx, d_bases, d_out, read_len, n_ref, max_mm, b, cores):
+def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, traffic_key, kernel_name):
+    """cpu_baseline + roofline objects of a single-end leg from its oracle job."""
+    import numpy as np
+    torch, walt_amd = cx.torch, cx.walt_amd
+    got = leg["d_out"].view(torch.int32).view(n, 4)[sel_all].cpu().numpy().view(walt_amd.best_match_dtype).reshape(-1)
+    want = job["out"]
+    same = all(np.array_equal(got[f], want[f]) for f in ("genome_pos", "times", "strand", "mismatch"))
+    nu = min(n_uniform, job["m"])
+    tr = job["trace"]
+    wt = job["work_timed"][0]
+    P, S, C = float(wt["probes"]) / nu, float(wt["steps"]) / nu, float(wt["cands"]) / nu
+    tu = tr[:nu]
+    big = tu["max_region"] > 4
+    classes = {"sampled_uniform": int(nu), "sampled_hard": int(job["m"] - nu),
+               "uniform_with_region_gt4": int(big.sum()), "uniform_with_region_gt64": int((tu["max_region"] > 64).sum()),
+               "uniform_with_region_gt1000": int((tu["max_region"] > 1000).sum()),
+               "uniform_over_b": int((tu["over_b"] > 0).sum()),
+               "hard_with_region_gt4": int((tr[nu:]["max_region"] > 4).sum()), "hard_over_b": int((tr[nu:]["over_b"] > 0).sum()),
+               "deferred_to_literal_pass_in_batch": int(leg["n_deferred"])}
+    uniq = want["times"][:nu] == 1
+    reg_of_unique = tu["max_region"][uniq]
+    cpu = {"value": nu / job["cpu_s"], "unit": "reads/s", "cores": job["cores"], "kind": "port",
+           "sample": "%d reads sampled uniformly (stride) over rank 0's batch, both strand passes, oracle restatement "
+                     "with OpenMP; one strand index in host memory at a time like the reference" % nu,
+           "bit_exact_vs_gpu": bool(same),
+           "exactness_sample": classes,
+           "unique_reads_by_largest_region": {">1": float((reg_of_unique > 1).mean()) if reg_of_unique.size else 0.0,
+                                              ">10": float((reg_of_unique > 10).mean()) if reg_of_unique.size else 0.0,
+                                              ">100": float((reg_of_unique > 100).mean()) if reg_of_unique.size else 0.0,
+                                              ">1000": float((reg_of_unique > 1000).mean()) if reg_of_unique.size else 0.0,
+                                              ">5000": float((reg_of_unique > 5000).mean()) if reg_of_unique.size else 0.0}}
+    # Algorithmic bytes per read of the IMPLEMENTED search (DESIGN.md section 6).  P probes and C verified
+    # candidates are the reference algorithm's own counts (oracle, SURVEY 8(d)); per probe the directory/key
+    # search must read one directory pair and one run of entries, per candidate one genome window --
+    # dependent random gathers, which HBM serves in whole 128-byte lines: 2 P + C lines, plus 12 bytes per
+    # candidate for its index entry (the entries of a region are contiguous, so they stream), the packed
+    # read (L/4 bytes) and the 16-byte result.  SURVEY 8(d)'s formula prices the REFERENCE algorithm's
+    # binary-search steps and is kept as `survey_8d`.
+    table = bool(os.environ.get("WALT_AMD_TABLE", "0") not in ("", "0"))
+    lines = (1.0 if table else 2.0) * P + C
+    bytes_per_read = 128.0 * lines + 12.0 * C + read_len / 4.0 + 16
+    useful = read_len / 4.0 + 16 + P * (8 + 12) + C * (12 + read_len / 4.0 + 8)
+    kern_s = float(np.median(leg["map_ms"])) / 1e3
+    achieved = bytes_per_read * n / kern_s
+    survey = read_len + 16 + 8 * P + S * 4.25 + C * (4 + read_len / 4.0)
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        try:
+            t = json.load(open(tj)).get(traffic_key)
+            if t and t.get("reads_per_launch") == n and t.get("genome") == args.genome and not args.contigs and not table \
+                    and args.pattern == 3 and t.get("genome_bp") == cx.genome_bp:
+                traffic = t["hbm_bytes_per_launch"]
+        except (ValueError, KeyError, AttributeError):
+            pass
+    roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
+            "kernel": kernel_name, "kernel_ms_median": kern_s * 1e3, "kernel_ms_min": float(np.min(leg["map_ms"])),
+            "algorithmic_bytes_per_read": bytes_per_read,
+            "granularity": "128-byte line per dependent gather (%d per probe, 1 per candidate) + 12-byte entry per "
+                           "candidate + streamed read/result bytes" % (1 if table else 2),
+            "useful_bytes_per_read": useful,
+            "per_read": {"probes": P, "search_steps": S, "candidates": C},
+            "per_read_source": "oracle counters on this run's uniform sample",
+            "survey_8d": {"bytes_per_read": survey, "achieved": survey * n / kern_s / 1e9,
+                          "frac": survey * n / kern_s / HBM_PEAK,
+                          "note": "bytes of the reference algorithm (binary-search steps S); not a bound on this "
+                                  "kernel, which replaces them by a directory lookup"}}
+    return cpu, roof
+
+
+def reference_binary_leg(cx, idx, d_bases, d_out, read_len, n_ref, max_mm, b, cores):
     """The REAL reference binary (oracle/_ref/walt, built from the reference sources by oracle/Makefile.ref;
     test infrastructure) on the same box in the same run: the resident index is written in the reference's
     .dbindex format to a RAM-backed scratch directory, the first n_ref reads of the batch go to a FASTQ file,
-    `walt -t <cores>` maps them, and its .mapstats is compared with the GPU's records for the same reads.
-    Returns a dict (or a dict with "skipped")."""
+    `walt -t <cores>` maps them, and its .mapstats is compared with the GPU's records for the same reads."""
     import shutil
     import subprocess
     import tempfile
 
+    import numpy as np
+    torch = cx.torch
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "walt")
     if not os.path.exists(ref_bin):
         return {"skipped": "oracle/_ref/walt is not built"}
@@ -343,7 +339,7 @@ def reference_binary_leg(idx, d_bases, d_out, read_len, n_ref, max_mm, b, cores)
             k, _, v = ln.strip().partition(":")
             if v.strip().lstrip("-").replace(".", "", 1).isdigit():
                 stats[k.strip()] = v.strip()
-        times = d_out[:n_ref * 16].view(torch_int32()).view(n_ref, 4)[:, 1]
+        times = d_out[:n_ref * 16].view(torch.int32).view(n_ref, 4)[:, 1]
         mine = {"unique": int((times == 1).sum().item()), "ambiguous": int((times >= 2).sum().item()),
                 "unmapped": int((times == 0).sum().item())}
         same = all(int(stats.get(k, -1)) == v for k, v in mine.items())
@@ -357,25 +353,52 @@ def reference_binary_leg(idx, d_bases, d_out, read_len, n_ref, max_mm, b, cores)
         shutil.rmtree(scratch, ignore_errors=True)
 
 
-def torch_int32():
-    import torch
-    return torch.int32
+# ------------------------------------------------------------------------------------------------ paired-end
+def pe_leg(cx, idx, d1, d2, d_off, n, read_len, max_mm, b, top_k, frag_range, steps, warmup, timed_barrier=True):
+    torch, walt_amd = cx.torch, cx.walt_amd
+    dev = cx.dev
+    d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+    d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
+    d_ws = torch.empty(walt_amd.lib().walt_pe_workspace_bytes(n, read_len, top_k), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        idx.map_pe_batch_device(d1.data_ptr(), d_off.data_ptr(), d2.data_ptr(), d_off.data_ptr(), n, read_len,
+                                d_out.data_ptr(), d_stats.data_ptr(), d_ws.data_ptr(), stream=stream,
+                                max_mismatches=max_mm, b=b, top_k=top_k, frag_range=frag_range)
+
+    for _ in range(warmup):
+        step()
+    cx.barrier() if timed_barrier else torch.cuda.synchronize()
+    per_step = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        per_step.append(time.perf_counter() - ts)
+    cx.barrier() if timed_barrier else torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    idx.check_batch(d_ws.data_ptr(), stream)
+    st = d_stats.cpu().numpy() // (warmup + steps)
+    ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last pass (map_pe.hip carve_pe)
+    return {"elapsed": elapsed, "per_step": per_step, "d_out": d_out, "stats": st,
+            "lists": {"literal": [int(ctl[64]), int(ctl[96])], "overflowed_small_heaps": [int(ctl[89]), int(ctl[121])],
+                      "heavy_pairs": int(ctl[128])}}
 
 
-def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, frag_range):
-    """Oracle restatement of PairEndMapping + MergePairedEndResults on the host cores; the two strand
-    indexes of one mate are in host memory at a time."""
+def oracle_pe_jobs(cx, idx, jobs, lens):
+    """job: dict(m1, m2 numpy bases, m, read_len, max_mm, b, top_k, frag_range, swap) -> out (pair records), cpu_s, works.
+    The two strand indexes of one mate are in host memory at a time; both exports serve every job."""
+    import numpy as np
     import refio
-    import walt_amd
-    cores = walt_amd.effective_cpus()
+    cores = cx.walt_amd.effective_cpus()
     orc = refio.oracle()
-    offsets = (np.arange(n + 1, dtype=np.uint64) * read_len)
     start = np.zeros(len(lens) + 1, dtype=np.uint32)
     start[1:] = np.cumsum(lens, dtype=np.uint64).astype(np.uint32)
-    ranked, counts = [], []
-    works = []
-    elapsed = 0.0
-    for mate, bases in ((0, m1_host), (1, m2_host)):
+    for j in jobs:
+        j["ranked"], j["counts"], j["works"], j["cpu_s"], j["cores"] = [], [], [], 0.0, cores
+    for mate in (0, 1):
         keep = []
         arr = (refio.OrcStrand * 2)()
         for k in range(2):
@@ -384,73 +407,134 @@ def cpu_baseline_pe(idx, m1_host, m2_host, read_len, n, lens, max_mm, b, top_k, 
             x = refio.make_orc_strand(g, cnt, ix, start)
             for f, _ in refio.OrcStrand._fields_:
                 setattr(arr[k], f, getattr(x, f))
-        r = np.zeros((n, top_k), dtype=refio.cand_dtype)
-        c = np.zeros(n, dtype=np.uint32)
-        work = np.zeros(1, dtype=refio.work_dtype)
-        bases = np.ascontiguousarray(bases[:n * read_len])
-        t0 = time.perf_counter()
-        orc.orc_pe_topk_batch(ctypes.addressof(arr), bases.ctypes.data, offsets.ctypes.data, n, mate, max_mm, b, top_k,
-                              cores, r.ctypes.data, c.ctypes.data, work.ctypes.data)
-        elapsed += time.perf_counter() - t0
-        ranked.append(r)
-        counts.append(c)
-        works.append((float(work[0]["probes"]), float(work[0]["cands"])))
+        for j in jobs:
+            m, L, top_k = j["m"], j["read_len"], j["top_k"]
+            offs = np.arange(m + 1, dtype=np.uint64) * L
+            r = np.zeros((m, top_k), dtype=refio.cand_dtype)
+            c = np.zeros(m, dtype=np.uint32)
+            work = np.zeros(1, dtype=refio.work_dtype)
+            bases = np.ascontiguousarray(j["m1"] if mate == 0 else j["m2"])
+            t0 = time.perf_counter()
+            orc.orc_pe_topk_batch(ctypes.addressof(arr), bases.ctypes.data, offs.ctypes.data, m, mate, j["max_mm"], j["b"],
+                                  top_k, cores, r.ctypes.data, c.ctypes.data, work.ctypes.data)
+            j["cpu_s"] += time.perf_counter() - t0
+            j["ranked"].append(r)
+            j["counts"].append(c)
+            j["works"].append((float(work[0]["probes"]), float(work[0]["cands"])))
         del keep, arr
-    out = np.zeros(n, dtype=refio.pair_dtype)
-    t0 = time.perf_counter()
-    orc.orc_pe_merge_batch(ranked[0].ctypes.data, counts[0].ctypes.data, ranked[1].ctypes.data, counts[1].ctypes.data,
-                           top_k, offsets.ctypes.data, offsets.ctypes.data, n, start.ctypes.data, len(lens), frag_range,
-                           max_mm, out.ctypes.data)
-    elapsed += time.perf_counter() - t0
-    return out, elapsed, cores, works
+    for j in jobs:
+        m, L = j["m"], j["read_len"]
+        offs = np.arange(m + 1, dtype=np.uint64) * L
+        out = np.zeros(m, dtype=refio.pair_dtype)
+        t0 = time.perf_counter()
+        orc.orc_pe_merge_batch(j["ranked"][0].ctypes.data, j["counts"][0].ctypes.data, j["ranked"][1].ctypes.data,
+                               j["counts"][1].ctypes.data, j["top_k"], offs.ctypes.data, offs.ctypes.data, m,
+                               start.ctypes.data, len(lens), j["frag_range"], j["max_mm"], out.ctypes.data)
+        j["cpu_s"] += time.perf_counter() - t0
+        j["out"] = out
 
 
-def main():
+def pe_sample(cx, leg, n, n_uniform, n_hard):
+    torch = cx.torch
+    bt = leg["d_out"].view(torch.int32).view(n, 16)[:, 8]
+    nu = min(n_uniform, n)
+    uni = (torch.arange(nu, device=cx.dev, dtype=torch.int64) * n) // nu
+    hard = []
+    for cls in (bt >= 2, bt == 0):
+        ix = torch.nonzero(cls).flatten()
+        if ix.numel() > n_hard:
+            ix = ix[(torch.arange(n_hard, device=cx.dev, dtype=torch.int64) * ix.numel()) // n_hard]
+        hard.append(ix)
+    return uni, torch.unique(torch.cat(hard))
+
+
+def pe_report(cx, args, leg, job, n, read_len, sel_all, nu, traffic_key):
+    import numpy as np
+    torch, walt_amd = cx.torch, cx.walt_amd
+    got = leg["d_out"].view(torch.int32).view(n, 16)[sel_all].cpu().numpy().view(walt_amd.pair_result_dtype).reshape(-1)
+    want = job["out"]
+    same = all(np.array_equal(got[f], want[f]) for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"))
+    for m in ("m1", "m2"):
+        same = same and all(np.array_equal(got[m][f], want[m][f]) for f in ("genome_pos", "times", "strand", "mismatch"))
+    m_all = job["m"]
+    cpu = {"value": m_all / job["cpu_s"], "unit": "pairs/s", "cores": job["cores"], "kind": "port",
+           "sample": "%d pairs sampled uniformly over the batch + %d from the hard classes (ambiguous / unpaired), oracle "
+                     "restatement of PairEndMapping on both mates and strands + pair merge, OpenMP; two strand indexes in "
+                     "host memory at a time" % (nu, m_all - nu),
+           "bit_exact_vs_gpu": bool(same)}
+    # Same accounting as the single-end line: per pair, P probes and C candidates over both mates (oracle
+    # counters) -> 2 P + C dependent gathers of one 128-byte line each + 12-byte entries, plus per mate the
+    # ranked list written by the top-k kernel and read back by the merge (one line each way), the packed reads and
+    # the 64-byte pair record.  Time = the whole step (the mates' kernels overlap on several streams).
+    P = sum(w[0] for w in job["works"]) / m_all
+    C = sum(w[1] for w in job["works"]) / m_all
+    bytes_per_pair = 128.0 * (2.0 * P + C + 4.0) + 12.0 * C + 2 * read_len / 4.0 + 64
+    step_s = float(np.median(leg["per_step"]))
+    traffic = None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(traffic_key)
+        if t and t.get("pairs_per_step") == n and t.get("genome") == args.genome and t.get("genome_bp") == cx.genome_bp \
+                and args.pattern == 3 and not args.contigs:
+            traffic = t["hbm_bytes_per_step"]
+    except (OSError, ValueError, KeyError, AttributeError):
+        pass
+    roof = {"bound": "hbm", "achieved": bytes_per_pair * n / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": traffic,
+            "traffic_frac": (traffic / step_s / HBM_PEAK) if traffic else None,
+            "kernel": "whole paired-end step (k_pe_topk_dual + list kernels of both mates, k_pe_merge)",
+            "step_ms_median": step_s * 1e3, "step_ms_min": float(np.min(leg["per_step"])) * 1e3,
+            "algorithmic_bytes_per_pair": bytes_per_pair,
+            "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate, 2 per mate for the ranked "
+                           "list) + 12-byte entry per candidate + streamed reads / pair record",
+            "per_pair": {"probes": P, "candidates": C}}
+    return cpu, roof
+
+
+# ------------------------------------------------------------------------------------------------ main
+def dryrun(args):
+    """WALT_AMD_BENCH_DRYRUN=1 (CPU test of the launch path): rendezvous over gloo, world-size check, one
+    all-reduce of a statistics vector; no GPU work, not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from walt_amd import dist as wdist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo")
+    vec = wdist.allreduce_stats(torch.tensor([1, rank, 10 * (rank + 1)], dtype=torch.int64))
+    if rank == 0:
+        print(json.dumps({"dryrun": True, "n_gpus": world, "stats": vec.tolist()}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def worker(args):
     # the paired-end path keeps several streams busy (two mates x two pipeline slots); the HIP runtime
     # multiplexes streams onto 4 hardware queues unless told otherwise, before it initialises
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=float, default=3095.677412, help="synthetic genome size (hg19 = 3095.68)")
-    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--cpu-sample", type=int, default=400_000)
-    ap.add_argument("--max-mismatches", type=int, default=6)
-    ap.add_argument("--bucket", type=int, default=5000)
-    ap.add_argument("--dir-bits", type=int, default=-1)
-    ap.add_argument("--contigs", type=int, default=0, help="cut the genome into this many equal contigs (default: hg19's 24)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["se", "pe"], default="se", help="se = configs[1] (headline), pe = configs[2]")
-    ap.add_argument("--top-k", type=int, default=50)
-    ap.add_argument("--frag-range", type=int, default=1000)
-    ap.add_argument("--ref-sample", type=int, default=3_000_000,
-                    help="reads the real reference binary (oracle/_ref/walt) maps beside the oracle port at N=1 "
-                         "(0 = skip; needs ~35 GB of RAM-backed scratch for the index copy)")
-    ap.add_argument("--slot-table", action="store_true",
-                    help="build the opt-in direct-mapped slot table (WALT_AMD_TABLE=1: +51.5 GB per strand at hg19 scale)")
-    ap.add_argument("--pattern", type=int, choices=[3, 5, 7], default=3,
-                    help="seed pattern (the reference's -D SEEDPATTERN3/5/7); 5 and 7 use libwalt_amd_sp5/_sp7.so, "
-                         "whose kernels search literally -- not the headline configuration")
-    args = ap.parse_args()
-
     if args.slot_table:
         os.environ["WALT_AMD_TABLE"] = "1"
+    import numpy as np
     import walt_amd  # loads the HIP library (and the HIP runtime torch will share)
-    import refio
+    import synth
     walt_amd.set_pattern(args.pattern)
-    refio.set_pattern(args.pattern)  # the oracle build of the cpu_baseline leg
     walt_amd.lib()
     import torch
+    from walt_amd import dist as wdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    dist = None
+    shared_gpu = bool(os.environ.get("WALT_AMD_BENCH_SHARE_GPU"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("WALT_AMD_BENCH_SHARE_GPU"):
+        if shared_gpu:
             # rehearsal of the multi-rank path on a one-GPU box: every rank on GPU 0, gloo instead of RCCL
             # (RCCL refuses two ranks on one device); not a measurement
             local = 0
@@ -464,188 +548,297 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    scale = args.genome_mbp * 1e6 / sum(HG19)
-    t0 = time.perf_counter()
-    genome_ascii, lens = make_genome(torch, dev, scale, seed=2, contigs=args.contigs)
-    names = HG19_NAMES if not args.contigs else ["ctg%d" % i for i in range(len(lens))]
-    torch.cuda.synchronize()
-    t_genome = time.perf_counter() - t0
-    log("genome: %d bp in %d chromosomes (%.1f s)" % (sum(lens), len(lens), t_genome))
-
-    torch.cuda.empty_cache()  # hand the generator's cached blocks back: the library allocates with hipMalloc
-    if args.mode == "pe":
-        run_pe(args, torch, walt_amd, dev, local, rank, world, genome_ascii, lens)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    t0 = time.perf_counter()
-    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local,
-                                      strands=walt_amd.STRANDS_CT, dir_bits=args.dir_bits)
-    t_index = time.perf_counter() - t0
-    log("index: CT00 %d + CT01 %d entries, dir_bits %d, %.1f GB in HBM, outliers %d/%d, bad buckets %d/%d (%.1f s)" % (
-        idx.index_size(0), idx.index_size(1), idx.dir_bits, idx.device_bytes / 1e9, idx.outliers(0),
-        idx.outliers(1), idx.bad_buckets(0), idx.bad_buckets(1), t_index))
-
-    n = args.reads
-    t0 = time.perf_counter()
-    d_bases, d_off = make_reads(torch, dev, genome_ascii, n, args.read_len, seed=1000 + rank)
-    torch.cuda.synchronize()
-    log("reads: %d x %d bp (%.1f s)" % (n, args.read_len, time.perf_counter() - t0))
-    reads_sample_host = None
-    run_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline  # the CPU leg runs at N=1 only
-    if run_cpu:
-        reads_sample_host = d_bases[:args.cpu_sample * args.read_len].cpu().numpy()
-    del genome_ascii
-    torch.cuda.empty_cache()
-
-    d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-    d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
-    d_ws = torch.empty(walt_amd.lib().walt_se_workspace_bytes(n, args.read_len), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    idx.profile_enable(True)
-
-    def step():
-        idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, args.read_len, d_out.data_ptr(),
-                                d_stats.data_ptr(), d_ws.data_ptr(), stream=stream,
-                                max_mismatches=args.max_mismatches, b=args.bucket)
+    cx = Ctx()
+    cx.torch, cx.walt_amd, cx.dev, cx.pattern = torch, walt_amd, dev, args.pattern
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    cx.barrier = barrier
+    run_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline  # the CPU legs run at N=1 only
+    if run_cpu:
+        import refio
+        refio.set_pattern(args.pattern)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    pack_ms, map_ms = [], []
+    full = synth.HG19_TOTAL if args.genome == "hg19like" else sum(synth.HG19_CHROMS)
+    scale = 1.0 if args.genome_mbp is None else args.genome_mbp * 1e6 / full
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        p_ms, m_ms = idx.profile_last()  # waits for this step's events (same stream)
-        pack_ms.append(p_ms)
-        map_ms.append(m_ms)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    idx.check_batch(d_ws.data_ptr(), stream)  # no invalid read went unnoticed
-    from walt_amd import dist as wdist
-    elapsed = wdist.allreduce_max(elapsed, device=dev)  # MAX over ranks
+    genome_ascii, lens, names = synth.make_genome(torch, dev, scale, seed=2, kind=args.genome, contigs=args.contigs)
+    torch.cuda.synchronize()
+    cx.genome_bp = int(sum(lens))
+    log("genome (%s): %d bp in %d sequences (%.1f s)" % (args.genome, sum(lens), len(lens), time.perf_counter() - t0))
+    torch.cuda.empty_cache()  # hand the generator's cached blocks back: the library allocates with hipMalloc
+    genome_desc = ("hg19-like synthetic genome (%d bp, %d sequences; Alu-/L1-like families, segmental duplications, "
+                   "satellites, simple repeats)" if args.genome == "hg19like" else
+                   "round-1 synthetic genome (%d bp, %d chromosomes, iid + four small repeat families)") % (sum(lens), len(lens))
+    n = args.reads
+    lowq = args.genome == "hg19like"  # the round-1 workload keeps its clean reads
+    out = None
+    extra = []
 
-    # mapping statistics of the last step; the ONLY data-path collective is this
-    # final sum over ranks (RCCL), mirroring StatSingleReads (mapping.hpp:94-100)
-    times = d_out.view(torch.int32).view(n, 4)[:, 1]
-    too_short = int(d_stats[0].item()) // (args.warmup + args.steps)
-    st = wdist.allreduce_stats(wdist.se_stats_vector(times, too_short))
-    total, uniq, amb, unm, short = [int(v) for v in st.tolist()]
-
-    if os.environ.get("WALT_AMD_STAMPS"):
-        buf = (ctypes.c_ulonglong * 16)()
-        if walt_amd.lib().walt_profile_stamps(buf) == 0:
-            tot = float(buf[8]) or 1.0
-            names = ["read record", "care loads", "bloom/bad", "lookup", "masks", "own-lane verify", "coop regions",
-                     "store", "total"]
-            log("phase shares (s_memtime, drained at boundaries): " +
-                ", ".join("%s %.1f%%" % (nm, 100.0 * buf[i] / tot) for i, nm in enumerate(names[:8])))
-            if int(os.environ.get("WALT_AMD_ABLATE", "0")) & 8:
-                log("danger-filter self-check: %d probe pairs checked, %d dangerous probes NOT flagged by the filter "
-                    "(must be 0)" % (buf[14], buf[15]))
-    ctl = d_ws[:64 * 4].view(torch.int32).cpu().numpy()
-    log("deferred to the literal pass: %d reads (bins %s)" % (int(ctl[32]), ctl[40:46].tolist()))
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * n * args.steps / elapsed
-    if rank == 0:
-        out = {
-            "metric": "mapped reads/sec (%d bp single-end, hg19-scale index, -m %d -b %d)%s" % (
-                args.read_len, args.max_mismatches, args.bucket,
-                "" if args.pattern == 3 else ", seed pattern %d" % args.pattern),
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "configs[1]: hg19-scale synthetic genome (%d bp, 24 chromosomes, repeat families), "
-                                   "%d x %d bp single-end C->T reads per GPU, -m %d -b %d" % (
-                                       sum(lens), n, args.read_len, args.max_mismatches, args.bucket),
-                       "genome_bp": int(sum(lens)), "reads_per_gpu": n, "read_len": args.read_len,
-                       "max_mismatches": args.max_mismatches, "bucket_cap": args.bucket,
-                       "index_dir_bits": idx.dir_bits, "index_hbm_gb": round(idx.device_bytes / 1e9, 2),
-                       "index_build_s": round(t_index, 1), "parallelism": "replica-per-gpu x%d" % world},
-            "mapping": {"total": total, "unique": uniq, "ambiguous": amb, "unmapped": unm, "too_short": short},
-            "kernel_ms": {"pack_reads": float(np.mean(pack_ms)), "map_se": float(np.mean(map_ms))},
-        }
-        # HBM bytes per launch from the PMC passes of tools/prof_pmc.sh on this same command
-        # (TCC_EA0_RDREQ x 128 B + WRITE_SIZE; profiles/traffic.json), null when not collected
-        traffic, stored = None, None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
+    # ---------------------------------------------------------------- headline leg
+    if args.mode == "se":
+        strands = walt_amd.STRANDS_GA if args.ag else walt_amd.STRANDS_CT
+        t0 = time.perf_counter()
+        idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local, strands=strands,
+                                          dir_bits=args.dir_bits)
+        t_index = time.perf_counter() - t0
+        s0 = 2 if args.ag else 0
+        log("index: %d + %d entries, dir_bits %d, %.1f GB in HBM, outliers %d/%d, bad buckets %d/%d (%.1f s)" % (
+            idx.index_size(s0), idx.index_size(s0 + 1), idx.dir_bits, idx.device_bytes / 1e9, idx.outliers(s0),
+            idx.outliers(s0 + 1), idx.bad_buckets(s0), idx.bad_buckets(s0 + 1), t_index))
+        t0 = time.perf_counter()
+        d_bases, d_off = synth.make_reads(torch, dev, genome_ascii, n, args.read_len, seed=1000 + rank + args.seed_offset, ag=args.ag, lowq=lowq)
+        torch.cuda.synchronize()
+        log("reads: %d x %d bp (%.1f s)" % (n, args.read_len, time.perf_counter() - t0))
+        leg = se_leg(cx, idx, d_bases, d_off, n, args.read_len, args.max_mismatches, args.bucket, args.ag, args.steps,
+                     args.warmup)
+        elapsed = wdist.allreduce_max(leg["elapsed"], device=dev if not shared_gpu else "cpu")  # MAX over ranks
+        # mapping statistics of the last step; the ONLY data-path collective is this final sum over ranks
+        # (RCCL), mirroring StatSingleReads (mapping.hpp:94-100)
+        times = leg["d_out"].view(torch.int32).view(n, 4)[:, 1]
+        vec = wdist.se_stats_vector(times, int(leg["stats"][0]))
+        vec_local = vec.cpu().numpy().astype(np.uint64)
+        if shared_gpu:
+            vec = vec.cpu()
+        st = wdist.allreduce_stats(vec)
+        total, uniq, amb, unm, short = [int(v) for v in st.tolist()]
+        c_abi = None
+        if world > 1 and not shared_gpu:  # the same sum through the C ABI (walt_stats_allreduce over RCCL)
             try:
-                t = json.load(open(tj))
-                # the stored PMC figure belongs to the headline workload only
-                if (t.get("reads_per_launch") == n and t.get("genome_bp") == int(sum(lens)) and args.read_len == 100
-                        and args.max_mismatches == 6 and args.bucket == 5000 and args.pattern == 3
-                        and not args.contigs and not os.environ.get("WALT_AMD_TABLE")):
-                    traffic = t["hbm_bytes_per_launch"]
-                    stored = t.get("algorithmic_per_read")
-            except (ValueError, KeyError):
-                pass
-        per_read, per_read_src = None, None
+                comm = wdist.c_abi_comm(local)
+                v2 = comm.stats_allreduce(vec_local)
+                comm.close()
+                c_abi = "equal" if [int(x) for x in v2.tolist()] == [total, uniq, amb, unm, short] else "DIFFERENT: %s" % v2.tolist()
+            except Exception as e:  # never let the cross-check break the line
+                c_abi = "failed: %s: %s" % (type(e).__name__, e)
+        if os.environ.get("WALT_AMD_STAMPS"):
+            buf = (ctypes.c_ulonglong * 16)()
+            if walt_amd.lib().walt_profile_stamps(buf) == 0:
+                tot = float(buf[8]) or 1.0
+                nm = ["read record", "care loads", "bloom/bad", "lookup", "masks", "own-lane verify", "coop regions",
+                      "store", "total"]
+                log("phase shares (s_memtime, drained at boundaries): " +
+                    ", ".join("%s %.1f%%" % (x, 100.0 * buf[i] / tot) for i, x in enumerate(nm[:8])))
+                if int(os.environ.get("WALT_AMD_ABLATE", "0")) & 8:
+                    log("danger-filter self-check: %d probe pairs checked, %d dangerous probes NOT flagged by the filter "
+                        "(must be 0)" % (buf[14], buf[15]))
+        log("deferred to the literal pass: %d reads; kernel ms/step: pack %.2f map %.2f (median)" % (
+            leg["n_deferred"], float(np.median(leg["pack_ms"])), float(np.median(leg["map_ms"]))))
+        log("device counters per step: probes %.2f, candidates %.2f per read, %d wave-cooperative regions" % (
+            leg["stats"][1] / n, leg["stats"][2] / n, leg["stats"][3]))
+        if rank == 0:
+            out = {
+                "metric": "mapped reads/sec (%d bp single-end%s, hg19-scale index, -m %d -b %d)%s" % (
+                    args.read_len, " -A" if args.ag else "", args.max_mismatches, args.bucket,
+                    "" if args.pattern == 3 else ", seed pattern %d" % args.pattern),
+                "value": world * n * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": "configs[%d]: %s, %d x %d bp single-end %s reads per GPU, -m %d -b %d" % (
+                               1 if world == 1 else 3, genome_desc, n, args.read_len, "G->A" if args.ag else "C->T",
+                               args.max_mismatches, args.bucket),
+                           "genome": args.genome, "genome_bp": int(sum(lens)), "sequences": len(lens), "reads_per_gpu": n,
+                           "read_len": args.read_len, "max_mismatches": args.max_mismatches, "bucket_cap": args.bucket,
+                           "reads": "both strands, 95 % C->T, 1 % substitutions" + (
+                               "; %d %% of the reads carry %d-%d %% errors (quality tail)" % (
+                                   100 * synth.LOWQ_SHARE, 100 * synth.LOWQ_LO, 100 * synth.LOWQ_HI) if lowq else ""),
+                           "index_dir_bits": idx.dir_bits, "index_hbm_gb": round(idx.device_bytes / 1e9, 2),
+                           "index_build_s": round(t_index, 1), "parallelism": "replica-per-gpu x%d" % world},
+                "mapping": {"total": total, "unique": uniq, "ambiguous": amb, "unmapped": unm, "too_short": short,
+                            "unique_frac": uniq / max(1, total)},
+                "kernel_ms": {"pack_reads": float(np.median(leg["pack_ms"])), "map_se": float(np.median(leg["map_ms"])),
+                              "map_se_min": float(np.min(leg["map_ms"])), "map_se_max": float(np.max(leg["map_ms"]))},
+                "device_counters_per_read": {"probes": float(leg["stats"][1]) / n, "candidates": float(leg["stats"][2]) / n,
+                                             "wave_cooperative_regions_per_step": int(leg["stats"][3]),
+                                             "deferred_to_literal_pass": int(leg["n_deferred"])},
+            }
+            if c_abi:
+                out["stats_allreduce_c_abi"] = c_abi
+        jobs = []
         if run_cpu:
-            ns = min(args.cpu_sample, n)
-            ref, work, cpu_s, cores = cpu_baseline(idx, reads_sample_host, args.read_len, ns, lens,
-                                                   args.max_mismatches, args.bucket)
-            got = d_out[:ns * 16].cpu().numpy().view(walt_amd.best_match_dtype)
-            same = all(np.array_equal(got[f], ref[f]) for f in ("genome_pos", "times", "strand", "mismatch"))
-            per_read = {"probes": float(work["probes"]) / ns, "search_steps": float(work["steps"]) / ns,
-                        "candidates": float(work["cands"]) / ns}
-            per_read_src = "oracle counters on this run's sample"
-            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d reads of rank 0's batch, both strand passes, oracle "
-                                             "restatement with OpenMP; index in host memory" % ns,
-                                   "bit_exact_vs_gpu": bool(same)}
-            if args.ref_sample > 0 and args.pattern == 3:
+            uni, hard = se_sample(cx, leg, n, args.cpu_sample, args.hard_sample)
+            sel = torch.cat([uni, hard])
+            jobs.append({"bases": d_bases.view(n, args.read_len)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
+                         "read_len": args.read_len, "max_mm": args.max_mismatches, "b": args.bucket, "ag": args.ag,
+                         "timed_first": int(uni.numel()), "sel": sel, "leg": leg, "n": n, "nu": int(uni.numel()),
+                         "traffic_key": "se%d" % args.read_len, "kernel": "k_map_se<%d> (+ literal pass)" % (7 if args.read_len <= 112 else 10),
+                         "target": out})
+        # ---- extra leg on the same index: 150 bp single-end at -m 10 (configs[4]'s read length on the C->T side)
+        leg150 = None
+        want_extra = rank == 0 and world == 1 and not args.no_extra and args.pattern == 3
+        if want_extra and not args.ag and args.read_len != 150:
+            n150 = max(1, n // 2)
+            b150, o150 = synth.make_reads(torch, dev, genome_ascii, n150, 150, seed=3000, lowq=lowq)
+            leg150 = se_leg(cx, idx, b150, o150, n150, 150, 10, args.bucket, False, args.extra_steps, 1, timed_barrier=False)
+            line = {"metric": "mapped reads/sec (150 bp single-end, hg19-scale index, -m 10 -b %d)" % args.bucket,
+                    "value": n150 * args.extra_steps / leg150["elapsed"], "unit": "reads/s", "n_gpus": 1,
+                    "steps": args.extra_steps, "warmup": 1, "ms_per_step": 1e3 * leg150["elapsed"] / args.extra_steps,
+                    "dtype": "u32", "data": "synthetic",
+                    "config": {"workload": "150 bp single-end C->T reads, -m 10 (read length and -m of configs[4]) on the "
+                                           "headline leg's index, %d reads" % n150}}
+            extra.append(line)
+            if run_cpu:
+                uni, hard = se_sample(cx, leg150, n150, max(1, args.cpu_sample // 4), max(1, args.hard_sample // 4))
+                sel = torch.cat([uni, hard])
+                jobs.append({"bases": b150.view(n150, 150)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
+                             "read_len": 150, "max_mm": 10, "b": args.bucket, "ag": False, "timed_first": int(uni.numel()),
+                             "sel": sel, "leg": leg150, "n": n150, "nu": int(uni.numel()), "traffic_key": "se150",
+                             "kernel": "k_map_se<10> (+ literal pass)", "target": line})
+            del b150, o150
+        if run_cpu and jobs:
+            t0 = time.perf_counter()
+            oracle_se_jobs(cx, idx, jobs, lens, (s0, s0 + 1))
+            log("oracle pass over %s sampled reads: %.1f s" % ([j["m"] for j in jobs], time.perf_counter() - t0))
+            for j in jobs:
+                cpu, roof = se_report(cx, args, j["leg"], j, j["n"], j["read_len"], j["max_mm"], j["b"], j["sel"], j["nu"],
+                                      j["traffic_key"], j["kernel"])
+                j["target"]["roofline"] = roof
+                j["target"]["cpu_baseline"] = cpu
+            if args.ref_sample > 0 and args.pattern == 3 and not args.ag:
                 # the real reference binary beside it (slower than the port: it also reads its index files)
                 try:
                     out["cpu_baseline"]["reference_binary"] = reference_binary_leg(
-                        idx, d_bases, d_out, args.read_len, min(args.ref_sample, n), args.max_mismatches,
-                        args.bucket, cores)
+                        cx, idx, d_bases, leg["d_out"], args.read_len, min(args.ref_sample, n), args.max_mismatches,
+                        args.bucket, jobs[0]["cores"])
                 except Exception as e:  # never let the extra leg break the bench line
                     out["cpu_baseline"]["reference_binary"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
-        elif stored and args.read_len == 100 and args.max_mismatches == 6 and args.bucket == 5000:
-            per_read = {k: float(stored[k]) for k in ("probes", "search_steps", "candidates")}
-            per_read_src = "profiles/traffic.json (oracle counters of the N=1 run of this workload)"
-        if per_read:
-            # Algorithmic bytes per read of the IMPLEMENTED search.  P probes and C verified
-            # candidates are the reference algorithm's own counts (oracle); per probe the
-            # directory/key search must read one directory pair and one run of entries, per candidate one
-            # genome window -- dependent random gathers, which HBM serves in whole 128-byte lines (every
-            # TCC_EA0_RDREQ of this kernel is a 128-byte request, profiles/): 2 P + C lines, plus the packed
-            # read (L/4 bytes) and the 16-byte result, which stream.  This is a lower bound of the traffic
-            # (measured: `traffic`), unlike SURVEY 8(d)'s formula, which prices the REFERENCE algorithm's
-            # ~540 binary-search steps per read and is kept below as `survey_8d` (it exceeds the peak because
-            # the directory replaces those steps).
-            P, S, C = per_read["probes"], per_read["search_steps"], per_read["candidates"]
-            table = bool(os.environ.get("WALT_AMD_TABLE", "0") not in ("", "0"))
-            lines = (1.0 if table else 2.0) * P + C  # with the slot table a probe can be served by one line
-            bytes_per_read = 128.0 * lines + args.read_len / 4.0 + 16
-            useful = args.read_len / 4.0 + 16 + P * (8 + 12) + C * 32.0  # the same accesses counted in useful bytes
-            kern_s = float(np.mean(map_ms)) / 1e3
-            achieved = bytes_per_read * n / kern_s  # this rank's kernel: bytes of ITS launch / ITS duration
-            survey = args.read_len + 16 + 8 * P + S * 4.25 + C * (4 + args.read_len / 4.0)
-            out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK, "traffic": traffic,
-                               "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
-                               "kernel": "k_map_se<7> (+ literal pass)" if args.pattern == 3 else "k_map_se_literal<7> (every read; literal search)",
-                               "algorithmic_bytes_per_read": bytes_per_read,
-                               "granularity": "128-byte line per dependent gather (%d per probe, 1 per candidate) + streamed read/result bytes" % (1 if table else 2),
-                               "useful_bytes_per_read": useful, "per_read": per_read,
-                               "per_read_source": per_read_src,
-                               "survey_8d": {"bytes_per_read": survey, "achieved": survey * n / kern_s / 1e9,
-                                             "frac": survey * n / kern_s / HBM_PEAK,
-                                             "note": "bytes of the reference algorithm (binary-search steps S); not a "
-                                                     "bound on this kernel, which replaces them by a directory lookup"}}
+        del jobs, leg, leg150, d_bases, d_off
+        idx.close()
+        torch.cuda.empty_cache()
+    # ---------------------------------------------------------------- paired-end legs (headline with --mode pe, else extra)
+    pe_cfgs = []
+    if args.mode == "pe":
+        pe_cfgs.append(("headline", n, args.read_len, args.max_mismatches, args.pbat, args.steps, args.warmup))
+    elif rank == 0 and world == 1 and not args.no_extra and args.pattern == 3:
+        npe = args.extra_pairs or n
+        pe_cfgs.append(("configs[2]", npe, 100, 6, False, args.extra_steps, 1))
+        pe_cfgs.append(("configs[4]", max(1, npe // 2), 150, 10, True, args.extra_steps, 1))
+    if pe_cfgs:
+        t0 = time.perf_counter()
+        idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local,
+                                          strands=walt_amd.STRANDS_ALL, dir_bits=args.dir_bits)
+        t_index4 = time.perf_counter() - t0
+        log("index (4 strands): %.1f GB in HBM, dir_bits %d (%.1f s)" % (idx.device_bytes / 1e9, idx.dir_bits, t_index4))
+        jobs = []
+        se_jobs = []
+        for tag, npairs, rl, mm, pbat, steps, warm in pe_cfgs:
+            d1, d2, d_off = synth.make_pairs(torch, dev, genome_ascii, npairs, rl, seed=2000 + rank + args.seed_offset + rl, lowq=lowq)
+            if pbat:
+                # a PBAT library's mate 1 is the A-rich read: the user's (-1, -2) files are what a directional
+                # library would call (mate 2, mate 1); bin/walt -P exchanges them for the mapping call, so does this
+                user1, user2 = d2, d1
+                d1, d2 = user2, user1
+            torch.cuda.synchronize()
+            headline = tag == "headline"
+            leg = pe_leg(cx, idx, d1, d2, d_off, npairs, rl, mm, args.bucket, args.top_k, args.frag_range, steps, warm,
+                         timed_barrier=headline)
+            elapsed = wdist.allreduce_max(leg["elapsed"], device=dev if not shared_gpu else "cpu") if headline else leg["elapsed"]
+            log("%s paired-end 2 x %d bp: %.1f ms/step; lists %s" % (tag, rl, 1e3 * elapsed / steps, leg["lists"]))
+            words = leg["d_out"].view(torch.int32).view(npairs, 16)
+            vec = wdist.pe_stats_vector(words, args.frag_range, int(leg["stats"][0]), int(leg["stats"][4]))
+            vec_local = vec.cpu().numpy().astype(np.uint64)
+            if headline:
+                if shared_gpu:
+                    vec = vec.cpu()
+                vec = wdist.allreduce_stats(vec)
+            v = [int(x) for x in vec.tolist()]
+            hist = np.array(v[14:], dtype=np.float64)
+            line = {"metric": "mapped read pairs/sec (2 x %d bp paired-end%s, hg19-scale index, -m %d -k %d -L %d)" % (
+                        rl, " PBAT (-P)" if pbat else "", mm, args.top_k, args.frag_range),
+                    "value": (world if headline else 1) * npairs * steps / elapsed, "unit": "pairs/s",
+                    "n_gpus": world if headline else 1, "steps": steps, "warmup": warm,
+                    "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "u32", "data": "synthetic",
+                    "config": {"workload": "%s: %s, %d pairs 2 x %d bp per GPU, fragment U[%d,500], -m %d -b %d -k %d -L %d%s" % (
+                                   tag if not headline else "configs[2]", genome_desc, npairs, rl, max(120, rl), mm, args.bucket,
+                                   args.top_k, args.frag_range, ", PBAT (-P): mates exchanged for mapping" if pbat else ""),
+                               "genome": args.genome, "genome_bp": int(sum(lens)), "pairs_per_gpu": npairs,
+                               "index_hbm_gb": round(idx.device_bytes / 1e9, 2), "index_dir_bits": idx.dir_bits},
+                    "mapping": {"pairs": v[0], "unique_pairs": v[1], "ambiguous_pairs": v[2], "unpaired": v[3],
+                                "mate1": dict(zip(wdist.SE_FIELDS, v[4:9])), "mate2": dict(zip(wdist.SE_FIELDS, v[9:14])),
+                                "frag_len_mean": float((hist * np.arange(hist.size)).sum() / max(1.0, hist.sum())),
+                                "unique_frac": v[1] / max(1, v[0])},
+                    "lists_last_pass": leg["lists"]}
+            if headline and world > 1 and not shared_gpu:
+                try:
+                    comm = wdist.c_abi_comm(local)
+                    v2 = comm.stats_allreduce(vec_local)
+                    comm.close()
+                    line["stats_allreduce_c_abi"] = "equal" if [int(x) for x in v2.tolist()] == v else "DIFFERENT"
+                except Exception as e:
+                    line["stats_allreduce_c_abi"] = "failed: %s: %s" % (type(e).__name__, e)
+            if headline:
+                out = line if rank == 0 else None
+            else:
+                extra.append(line)
+            if run_cpu:
+                uni, hard = pe_sample(cx, leg, npairs, max(1, args.cpu_sample // 10), max(1, args.hard_sample // 5))
+                sel = torch.cat([uni, hard])
+                jobs.append({"m1": d1.view(npairs, rl)[sel].cpu().numpy().reshape(-1),
+                             "m2": d2.view(npairs, rl)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()), "read_len": rl,
+                             "max_mm": mm, "b": args.bucket, "top_k": args.top_k, "frag_range": args.frag_range, "sel": sel,
+                             "leg": leg, "n": npairs, "nu": int(uni.numel()), "target": line,
+                             "traffic_key": "pe%d" % rl})
+            del d1, d2, d_off
+            torch.cuda.empty_cache()
+        # ---- configs[4]'s single-end half: 150 bp A-rich reads with -A on the _GA10/_GA11 indexes, -m 10
+        if args.mode != "pe" and len(pe_cfgs) > 1:
+            n150 = max(1, n // 2)
+            b150, o150 = synth.make_reads(torch, dev, genome_ascii, n150, 150, seed=4000, ag=True, lowq=lowq)
+            legA = se_leg(cx, idx, b150, o150, n150, 150, 10, args.bucket, True, args.extra_steps, 1, timed_barrier=False)
+            tA = legA["d_out"].view(torch.int32).view(n150, 4)[:, 1]
+            lineA = {"metric": "mapped reads/sec (150 bp single-end -A, hg19-scale index, -m 10 -b %d)" % args.bucket,
+                     "value": n150 * args.extra_steps / legA["elapsed"], "unit": "reads/s", "n_gpus": 1,
+                     "steps": args.extra_steps, "warmup": 1, "ms_per_step": 1e3 * legA["elapsed"] / args.extra_steps,
+                     "dtype": "u32", "data": "synthetic",
+                     "config": {"workload": "configs[4] single-end half: %d x 150 bp A-rich (G->A) reads, -A -m 10, on the "
+                                            "_GA10/_GA11 strands of the 4-strand index" % n150},
+                     "mapping": {"unique_frac": float((tA == 1).float().mean().item())}}
+            extra.append(lineA)
+            if run_cpu:
+                uni, hard = se_sample(cx, legA, n150, max(1, args.cpu_sample // 4), max(1, args.hard_sample // 4))
+                sel = torch.cat([uni, hard])
+                se_jobs.append({"bases": b150.view(n150, 150)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
+                                "read_len": 150, "max_mm": 10, "b": args.bucket, "ag": True, "timed_first": int(uni.numel()),
+                                "sel": sel, "leg": legA, "n": n150, "nu": int(uni.numel()), "traffic_key": "se150ag",
+                                "kernel": "k_map_se<10> (+ literal pass)", "target": lineA})
+            del b150, o150
+        if run_cpu and jobs:
+            t0 = time.perf_counter()
+            oracle_pe_jobs(cx, idx, jobs, lens)
+            log("oracle paired-end pass over %s sampled pairs: %.1f s" % ([j["m"] for j in jobs], time.perf_counter() - t0))
+            for j in jobs:
+                cpu, roof = pe_report(cx, args, j["leg"], j, j["n"], j["read_len"], j["sel"], j["nu"], j["traffic_key"])
+                j["target"]["cpu_baseline"] = cpu
+                j["target"]["roofline"] = roof
+        if run_cpu and se_jobs:
+            oracle_se_jobs(cx, idx, se_jobs, lens, (2, 3))
+            for j in se_jobs:
+                cpu, roof = se_report(cx, args, j["leg"], j, j["n"], j["read_len"], j["max_mm"], j["b"], j["sel"], j["nu"],
+                                      j["traffic_key"], j["kernel"])
+                j["target"]["roofline"] = roof
+                j["target"]["cpu_baseline"] = cpu
+        idx.close()
+    if rank == 0:
+        if extra:
+            out["extra_lines"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()  # ranks > 0 wait for rank 0's CPU baseline before tearing the group down
-    idx.close()
-    if world > 1:
+        dist.barrier()  # ranks > 0 wait for rank 0 before tearing the group down
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    if os.environ.get("WALT_AMD_BENCH_DRYRUN"):
+        dryrun(args)
+        return
+    worker(args)
 
 
 if __name__ == "__main__":

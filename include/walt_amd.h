@@ -131,6 +131,9 @@ int walt_index_dir_bits(const walt_index* idx);
  * makedb-built index), and chromosome-end entries ("outliers") around which probes do */
 uint64_t walt_index_bad_buckets(const walt_index* idx, int strand);
 uint64_t walt_index_outliers(const walt_index* idx, int strand);
+/* index entries whose genome window is also stored in slot order ("dense candidate windows": the regions of
+ * thousands of candidates that repeats produce are then verified from contiguous memory) */
+uint64_t walt_index_window_entries(const walt_index* idx, int strand);
 
 /* ---- single-end: replaces the strand loop + omp loop over SingleEndMapping,
  *      mapping.cpp:486-500 / 224-316 ------------------------------------- */
@@ -214,6 +217,31 @@ int walt_index_export_strand(const walt_index* idx, int strand, uint8_t* genome_
  * strand (a C->T-only index writes <path>, <path>_CT00 and <path>_CT01, which is
  * all the reference's single-end mode without -A reads, mapping.cpp:491-492). */
 int walt_index_write(const walt_index* idx, const char* dbindex_path);
+
+/* ---- multi-GPU: one process per GPU, the statistics block is the only exchange -----------------
+ *
+ * The reference is a single process; what it carries ACROSS reads is the statistics block that
+ * ProcessSingledEndReads / ProcessPairedEndReads accumulate and print as <out>.mapstats
+ * (StatSingleReads: total, unique, ambiguous, unmapped, too_short, mapping.hpp:94-100, updated at
+ * mapping.cpp:318-327,504; StatPairedReads: 4 pair counters + one StatSingleReads per mate +
+ * fragment_len_count[frag_range + 1], paired.hpp:96-105, updated at paired.cpp:519-547).  Reads shard
+ * over the ranks in contiguous blocks, every rank holds an index replica, and at the end of the run
+ * each rank hands its block to walt_stats_allreduce: ONE sum over RCCL (ncclAllReduce, uint64).
+ *
+ * walt_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId) and the caller distributes it out
+ * of band (a file, MPI, torch.distributed ...).  walt_comm_init: every rank joins with the same id
+ * (ncclCommInitRank; collective, blocks until all ranks have called).  walt_stats_allreduce sums v[0..n)
+ * over the ranks in place (host vector; collective, same n on every rank); with comm == NULL it is
+ * the identity, which is what a single process needs.  bin/walt, one process driving several GPUs,
+ * adds its per-device blocks on the host instead. */
+#define WALT_COMM_ID_BYTES 128
+typedef struct walt_comm walt_comm;
+int walt_comm_unique_id(void* id_out /* WALT_COMM_ID_BYTES */);
+int walt_comm_init(int device, int rank, int world, const void* id, walt_comm** out);
+int walt_stats_allreduce(walt_comm* comm, uint64_t* v, size_t n);
+int walt_comm_rank(const walt_comm* comm);
+int walt_comm_world(const walt_comm* comm);
+void walt_comm_close(walt_comm* comm);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------- */
 

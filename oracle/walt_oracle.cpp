@@ -141,6 +141,15 @@ typedef struct {
   uint64_t too_short;
 } orc_work;
 
+// Optional per-read trace (bench.py: which sampled reads met large regions / the -b cap), accumulated over
+// the strand passes.  region sizes are those IndexRegion returns (mapping.cpp:274), before the -b test.
+typedef struct {
+  uint32_t probes;      // probes into non-empty buckets
+  uint32_t cands;       // candidates verified
+  uint32_t max_region;  // largest region met, skipped ones included
+  uint32_t over_b;      // regions skipped by the -b cap (mapping.cpp:275-277)
+} orc_trace;
+
 static inline uint8_t gat(const orc_strand* x, uint64_t pos) {
   return pos < x->genome_len ? x->genome[pos] : 0;
 }
@@ -253,8 +262,14 @@ static uint32_t orc_count_mm(const orc_strand* x, const char* read, uint32_t rea
 }
 
 // SingleEndMapping, mapping.cpp:224-316, one (read, strand) call.
+void orc_se_map_read_trace(const orc_strand* x, const char* org_read, uint32_t read_len, char strand,
+                           int ag_wildcard, uint32_t b, orc_best* best, orc_work* work, orc_trace* tr);
 void orc_se_map_read(const orc_strand* x, const char* org_read, uint32_t read_len, char strand,
                      int ag_wildcard, uint32_t b, orc_best* best, orc_work* work) {
+  orc_se_map_read_trace(x, org_read, read_len, strand, ag_wildcard, b, best, work, NULL);
+}
+void orc_se_map_read_trace(const orc_strand* x, const char* org_read, uint32_t read_len, char strand,
+                           int ag_wildcard, uint32_t b, orc_best* best, orc_work* work, orc_trace* tr) {
   orc_tables_init();
   if (read_len < ORC_MINREAD) { ++work->too_short; return; }
   uint32_t repeats, seed_len;
@@ -272,6 +287,11 @@ void orc_se_map_read(const orc_strand* x, const char* org_read, uint32_t read_le
     if (first == second) continue;                     // 271-272
     ++work->probes;
     orc_index_region(x, seed, seed_len, &first, &second, &work->steps);
+    if (tr) {
+      ++tr->probes;
+      if (second - first + 1 > tr->max_region) tr->max_region = second - first + 1;
+      if (second - first + 1 > b) ++tr->over_b;
+    }
     if (second - first + 1 > b) continue;              // 275-277 (u32 wrap on the empty marker)
     for (uint32_t j = first; j <= second; ++j) {
       uint32_t gp = x->index[j];
@@ -280,6 +300,7 @@ void orc_se_map_read(const orc_strand* x, const char* org_read, uint32_t read_le
       gp -= seed_i;
       if (gp + read_len >= x->start_index[chr + 1]) continue;      // 285-286
       ++work->cands;
+      if (tr) ++tr->cands;
       uint32_t mm = orc_count_mm(x, read, read_len, gp, seed_i, repeats, best->mismatch);
       if (mm < best->mismatch) {                                   // 306-313
         best->genome_pos = gp; best->times = 1; best->strand = strand; best->mismatch = mm;
@@ -333,17 +354,25 @@ void orc_se_init(orc_best* out, uint32_t n, uint32_t max_mm) {
     out[j].mismatch = max_mm;
   }
 }
+void orc_se_map_strand_trace(const orc_strand* x, char strand, const char* bases, const uint64_t* offsets,
+                             uint32_t n, int ag_wildcard, uint32_t b, int threads, orc_best* out,
+                             orc_work* work_out, orc_trace* trace /* n entries, accumulated; may be NULL */);
 void orc_se_map_strand(const orc_strand* x, char strand, const char* bases, const uint64_t* offsets,
                        uint32_t n, int ag_wildcard, uint32_t b, int threads, orc_best* out,
                        orc_work* work_out) {
+  orc_se_map_strand_trace(x, strand, bases, offsets, n, ag_wildcard, b, threads, out, work_out, NULL);
+}
+void orc_se_map_strand_trace(const orc_strand* x, char strand, const char* bases, const uint64_t* offsets,
+                             uint32_t n, int ag_wildcard, uint32_t b, int threads, orc_best* out,
+                             orc_work* work_out, orc_trace* trace) {
   orc_tables_init();
   if (threads < 1) threads = 1;
   uint64_t p = 0, s = 0, c = 0, t = 0;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 256) reduction(+ : p, s, c, t)
   for (int64_t j = 0; j < (int64_t)n; ++j) {
     orc_work w = {0, 0, 0, 0};
-    orc_se_map_read(x, bases + offsets[j], (uint32_t)(offsets[j + 1] - offsets[j]), strand, ag_wildcard, b,
-                    &out[j], &w);
+    orc_se_map_read_trace(x, bases + offsets[j], (uint32_t)(offsets[j + 1] - offsets[j]), strand, ag_wildcard, b,
+                          &out[j], &w, trace ? &trace[j] : NULL);
     p += w.probes; s += w.steps; c += w.cands; t += w.too_short;
   }
   if (work_out) {

@@ -32,6 +32,7 @@ pair_dtype = np.dtype([("m1", best_dtype), ("m2", best_dtype), ("best_times", "<
 hpair_dtype = np.dtype([("m1", best_dtype), ("m2", best_dtype), ("best_times", "<u4"), ("frag_len", "<i4"),
                         ("best_i", "<i4"), ("best_j", "<i4"), ("pair_mm", "<u4"), ("pad", "V12")])
 work_dtype = np.dtype([("probes", "<u8"), ("steps", "<u8"), ("cands", "<u8"), ("too_short", "<u8")])
+trace_dtype = np.dtype([("probes", "<u4"), ("cands", "<u4"), ("max_region", "<u4"), ("over_b", "<u4")])  # orc_trace
 
 
 def _newer(target, sources):
@@ -132,6 +133,7 @@ def oracle():
         L.orc_se_map_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, ci, vp, vp]
         L.orc_se_init.argtypes = [vp, u32, u32]
         L.orc_se_map_strand.argtypes = [vp, ctypes.c_char, vp, vp, u32, ci, u32, ci, vp, vp]
+        L.orc_se_map_strand_trace.argtypes = [vp, ctypes.c_char, vp, vp, u32, ci, u32, ci, vp, vp, vp]
         L.orc_pe_topk_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, u32, ci, vp, vp, vp]
         L.orc_pe_merge_batch.argtypes = [vp, vp, vp, vp, u32, vp, vp, u32, vp, u32, ci, u32, vp]
         _oracle[PATTERN] = L

@@ -76,7 +76,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=4_000_000)
     ap.add_argument("--small", type=int, default=0, help="second, smaller run to subtract the index load time")
-    ap.add_argument("--genome-mbp", type=float, default=3095.677412)
+    ap.add_argument("--genome-mbp", type=float, default=0.0, help="0 = full scale")
+    ap.add_argument("--genome", choices=["hg19like", "easy"], default="hg19like")
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--mode", choices=["se", "pe"], default="se")
     ap.add_argument("--sam", action="store_true")
@@ -84,7 +85,8 @@ def main():
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
-    import bench
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import synth
     import walt_amd
     import torch
 
@@ -95,14 +97,15 @@ def main():
             raise SystemExit("missing " + b + " (run __graft_entry__.build() in the build container)")
     threads = args.threads or walt_amd.effective_cpus()
     dev = torch.device("cuda", 0)
-    scale = args.genome_mbp * 1e6 / sum(bench.HG19)
-    genome_ascii, lens = bench.make_genome(torch, dev, scale, seed=2)
+    full = synth.HG19_TOTAL if args.genome == 'hg19like' else sum(synth.HG19_CHROMS)
+    scale = args.genome_mbp * 1e6 / full if args.genome_mbp else 1.0
+    genome_ascii, lens, names = synth.make_genome(torch, dev, scale, seed=2, kind=args.genome)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     pe = args.mode == "pe"
     strands = walt_amd.STRANDS_ALL if pe else walt_amd.STRANDS_CT
     t0 = time.perf_counter()
-    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, bench.HG19_NAMES, device=0, strands=strands)
+    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=0, strands=strands)
     t_build = time.perf_counter() - t0
     n_str = 4 if pe else 2
     need = n_str * (sum(lens) + 4 * (idx.index_size(0) + (1 << 24) + 8)) + 4 * args.reads * (2 * args.read_len + 20)
@@ -120,11 +123,11 @@ def main():
             if not os.path.exists(dbi + sfx):
                 open(dbi + sfx, "wb").close()
         if pe:
-            b1, b2, _ = bench.make_pairs(torch, dev, genome_ascii, args.reads, args.read_len, seed=1000)
+            b1, b2, _ = synth.make_pairs(torch, dev, genome_ascii, args.reads, args.read_len, seed=1000)
             h1, h2 = b1.cpu().numpy(), b2.cpu().numpy()
             del b1, b2
         else:
-            b1, _ = bench.make_reads(torch, dev, genome_ascii, args.reads, args.read_len, seed=1000)
+            b1, _ = synth.make_reads(torch, dev, genome_ascii, args.reads, args.read_len, seed=1000)
             h1 = b1.cpu().numpy()
             del b1
         idx.close()

@@ -156,6 +156,8 @@ def lib(pattern=None):
     L.walt_index_bad_buckets.restype = u64
     L.walt_index_outliers.argtypes = [vp, ci]
     L.walt_index_outliers.restype = u64
+    L.walt_index_window_entries.argtypes = [vp, ci]
+    L.walt_index_window_entries.restype = u64
     L.walt_map_se_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, vp, vp]
     L.walt_se_workspace_bytes.argtypes = [u32, u32]
     L.walt_se_workspace_bytes.restype = c.c_size_t
@@ -173,6 +175,13 @@ def lib(pattern=None):
     L.walt_index_write.argtypes = [vp, c.c_char_p]
     L.walt_profile_enable.argtypes = [vp, ci]
     L.walt_profile_last.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_float)]
+    L.walt_comm_unique_id.argtypes = [vp]
+    L.walt_comm_init.argtypes = [ci, ci, ci, vp, c.POINTER(vp)]
+    L.walt_stats_allreduce.argtypes = [vp, vp, c.c_size_t]
+    L.walt_comm_rank.argtypes = [vp]
+    L.walt_comm_world.argtypes = [vp]
+    L.walt_comm_close.argtypes = [vp]
+    L.walt_comm_close.restype = None
     _libs[pattern] = L
     return L
 
@@ -203,6 +212,47 @@ def pack_reads(seqs):
         offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
     bases = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
     return bases, offsets
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128-byte RCCL id made by rank 0 (ncclGetUniqueId); the caller hands it to the other ranks."""
+    buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().walt_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of the one-process-per-GPU path; its only use is stats_allreduce()."""
+
+    def __init__(self, device, rank, world, unique_id):
+        self._L = lib()
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _check(self._L.walt_comm_init(int(device), int(rank), int(world), ctypes.cast(buf, ctypes.c_void_p),
+                                      ctypes.byref(h)))
+        self._h = h
+
+    def stats_allreduce(self, vec):
+        """Sum a vector of counters over the ranks (walt_stats_allreduce); returns a numpy uint64 array."""
+        v = np.ascontiguousarray(np.asarray(vec), dtype=np.uint64).copy()
+        _check(self._L.walt_stats_allreduce(self._h, v.ctypes.data, v.size))
+        return v
+
+    @property
+    def rank(self):
+        return self._L.walt_comm_rank(self._h)
+
+    @property
+    def world(self):
+        return self._L.walt_comm_world(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.walt_comm_close(self._h)
+            self._h = None
 
 
 class Index:
@@ -334,6 +384,9 @@ class Index:
 
     def outliers(self, strand):
         return self._L.walt_index_outliers(self._h, strand)
+
+    def window_entries(self, strand):
+        return self._L.walt_index_window_entries(self._h, strand)
 
     # -- single-end -----------------------------------------------------------
     def map_se_batch(self, bases, offsets, ag_wildcard=False, max_mismatches=6, b=5000):

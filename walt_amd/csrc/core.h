@@ -111,7 +111,26 @@ struct StrandView {
   const struct Outlier* outl;  // chromosome-end entries, sorted by bucket (see probe_is_dangerous)
   const uint32_t* outl_dir;    // open-addressing table bucket -> first outlier: pairs {bucket + 1 (0 = free), index}
   uint32_t outl_dir_mask;      // pairs - 1 (power of two); outl_dir == nullptr: binary search
+  // Dense candidate windows (DERIVED).  A region of thousands of candidates (satellites,
+  // young SINE / LINE copies: 2 % of the reads of an hg19-like genome own 90 % of all candidates) is a run of
+  // consecutive index slots, but the genome windows behind them are scattered: one random 128-byte line per
+  // candidate for 25 useful bytes, and the device serves ~48 G such lines per second whatever their size.
+  // For every 64-slot block of the index that lies inside ONE region of a 100-base read (same bucket, same
+  // first kWinKeyChars key characters) the windows are therefore stored once more, in slot order:
+  //   wblk[slot >> 6]  1 + number of the dense block, 0 = the block has none (take ent[] + g2[])
+  //   win              dense block d: 64 records of 8 words {pos, the 112 bases from genome position pos - kWinLead}
+  //   win2             dense block d: 64 records of 4 words, the following 64 bases (reads of 111..160 bases)
+  // so that the wavefront verifying such a region streams 32 (48) contiguous bytes per candidate.  A record is a
+  // copy of the g2 bits count_mismatch would read, so the mismatch counts are the same by construction.
+  const uint32_t* wblk;
+  const uint32_t* win;
+  const uint32_t* win2;
 };
+constexpr uint32_t kWinLead = kPat - 1;   // bases in front of pos: the largest seed shift (genome_pos = pos - seed_i)
+constexpr uint32_t kWinWords = 7, kWinWords2 = 4;
+constexpr uint32_t kWinKeyChars = kPat == 3 ? 20 : (kPat == 5 ? 26 : 32);  // key characters of a 100-base read's seed
+// reads of up to this many bases can be verified on the record(s): win alone / win + win2
+constexpr uint32_t kWinMaxLen1 = 16 * kWinWords - kWinLead, kWinMaxLen2 = 16 * (kWinWords + kWinWords2) - kWinLead;
 
 // An index entry whose care positions run over the end of its chromosome before
 // care character 44.  makedb sorted it as if every character from index q on
@@ -705,6 +724,20 @@ WALT_HD uint32_t count_mismatch(const uint32_t* g2, uint32_t gpos, const uint32_
     uint32_t x = funnel_r(cur, nxt, sh) ^ rd[w];
     mm += popc32((x | (x >> 1)) & mask[w]);
     cur = nxt;
+  }
+  return mm;
+}
+
+// the same count on NW + 1 window words held in registers, the window starting sh / 2 bases into g[0]
+template <int NW>
+WALT_HD uint32_t count_mismatch_regs(const uint32_t* g /*[NW + 1]*/, uint32_t sh, const uint32_t* rd, const uint32_t* mask) {
+  uint32_t mm = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int w = 0; w < NW; ++w) {
+    uint32_t x = funnel_r(g[w], g[w + 1], sh) ^ rd[w];
+    mm += popc32((x | (x >> 1)) & mask[w]);
   }
   return mm;
 }

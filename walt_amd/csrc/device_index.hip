@@ -435,6 +435,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   sv.outl = outl; sv.n_outl = n_outl;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
   sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1; sv.pre = pre; sv.tab = tab;
+  sv.wblk = nullptr; sv.win = nullptr; sv.win2 = nullptr;  // build_windows, once every strand is resident
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }
@@ -462,8 +463,138 @@ int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, con
   return finish_strand_device(idx, strand, g2, d_counter, d_index, index_size, stream);
 }
 
+// ---------------------------------------------------------------------------
+// Dense candidate windows (core.h StrandView::wblk / win / win2)
+// ---------------------------------------------------------------------------
+// flag[b] = 1 when the 64 slots of block b lie inside one region of a 100-base read: same bucket and same first
+// kWinKeyChars key characters at both ends (entries between two equal ends of a sorted bucket are equal too; a
+// chromosome-end entry out of order only changes which blocks are chosen, never what a record holds)
+__global__ void k_win_mark(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t index_size,
+                           uint32_t nblk, uint32_t* __restrict__ flag) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const uint64_t first = 64ull * b, last = first + 63;
+  uint32_t f = 0;
+  if (last < index_size) {
+    const Ent a = ent[first], z = ent[last];
+    if (((ent_key(a) ^ ent_key(z)) >> (64 - 2 * kWinKeyChars)) == 0 && hash_at_dev(g2, a.pos) == hash_at_dev(g2, z.pos)) f = 1;
+  }
+  flag[b] = f;
+}
+// flag + its exclusive scan -> wblk (in place over the scan): 1 + dense block number, 0 beyond the budget
+__global__ void k_win_assign(const uint32_t* __restrict__ flag, uint32_t* __restrict__ scan_wblk, uint32_t nblk,
+                             uint32_t cap_blocks) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const uint32_t d = scan_wblk[b];
+  scan_wblk[b] = (flag[b] && d < cap_blocks) ? d + 1 : 0u;
+}
+// one thread per record: {pos, 112 bases from pos - kWinLead} into win, the next 64 bases into win2.  The bases
+// are the g2 bits count_mismatch reads for a candidate at pos - seed_i (g2 carries kG2PadWords of slack);
+// bases in front of the genome's first (pos < kWinLead) are never compared and are stored as 0.
+__global__ void k_win_fill(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent,
+                           const uint32_t* __restrict__ wblk, uint32_t nblk, uint32_t* __restrict__ win,
+                           uint32_t* __restrict__ win2) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t b = t >> 6;
+  if (b >= nblk) return;
+  const uint32_t d1 = wblk[b];
+  if (!d1) return;
+  const uint32_t pos = ent[t].pos;  // slot 64 b + (t & 63) == t
+  constexpr int kAll = (int)(kWinWords + kWinWords2);
+  uint32_t w[kAll];
+  const int64_t start = (int64_t)pos - (int64_t)kWinLead;
+#pragma unroll
+  for (int i = 0; i < kAll; ++i) {
+    const int64_t q = start + 16 * i;
+    if (q >= 0) {
+      const uint64_t x = (uint64_t)q >> 4;
+      w[i] = funnel_r(g2[x], g2[x + 1], 2 * (uint32_t)(q & 15));
+    } else {
+      w[i] = g2[0] << (2 * (uint32_t)(-q));  // only i == 0: 16 > kWinLead
+    }
+  }
+  const uint64_t rec = (uint64_t)(d1 - 1) * 64 + (t & 63);
+  uint4 a, c, e;
+  a.x = pos; a.y = w[0]; a.z = w[1]; a.w = w[2];
+  c.x = w[3]; c.y = w[4]; c.z = w[5]; c.w = w[6];
+  e.x = w[7]; e.y = w[8]; e.z = w[9]; e.w = w[10];
+  reinterpret_cast<uint4*>(win)[2 * rec] = a;
+  reinterpret_cast<uint4*>(win)[2 * rec + 1] = c;
+  if (win2) reinterpret_cast<uint4*>(win2)[rec] = e;
+}
+
+// Windows for every resident strand, within what the device can spare: WALT_AMD_WIN_GB (default 16) per strand,
+// and never more than the free memory minus a reserve for the batches (40 GB, or WALT_AMD_WIN_RESERVE_GB).
+// WALT_AMD_WIN=0 switches them off (A/B measurements).
+static int build_windows(walt_index* idx) {
+  static_assert(kWinWords + kWinWords2 == 11 && kWinLead < 16, "record layout of k_win_fill");
+  if (const char* e = getenv("WALT_AMD_WIN")) if (atoi(e) == 0) return WALT_OK;
+  int n_strands = 0;
+  for (int s = 0; s < 4; ++s) n_strands += (idx->strand_mask >> s) & 1u;
+  if (!n_strands) return WALT_OK;
+  double cap_gb = 16.0, reserve_gb = 40.0;
+  if (const char* e = getenv("WALT_AMD_WIN_GB")) cap_gb = atof(e);
+  if (const char* e = getenv("WALT_AMD_WIN_RESERVE_GB")) reserve_gb = atof(e);
+  hipStream_t stream = nullptr;
+  for (int s = 0; s < 4; ++s) {
+    if (!((idx->strand_mask >> s) & 1u)) continue;
+    StrandView& sv = idx->view.s[s];
+    const uint32_t nblk = (uint32_t)(((uint64_t)sv.index_size + 63) / 64);
+    if (nblk == 0) { --n_strands; continue; }
+    size_t free_b = 0, total_b = 0;
+    WALT_HIP(hipMemGetInfo(&free_b, &total_b));
+    // a small index (tests, bacterial genomes) needs no reserve: its batches are small too
+    const double reserve = std::min(reserve_gb * 1e9, 0.25 * (double)total_b);
+    double budget = ((double)free_b - reserve - 8.0 * nblk) / n_strands;  // 8 nblk: flag + wblk
+    budget = std::min(budget, cap_gb * 1e9);
+    --n_strands;
+    const uint64_t block_bytes = 64ull * 4 * (kWinWords + 1 + kWinWords2);
+    if (budget < (double)block_bytes) continue;
+    const uint32_t cap_blocks = (uint32_t)std::min<double>(budget / (double)block_bytes, 4.0e9);
+    uint32_t *flag = nullptr, *wblk = nullptr;
+    int rc;
+    if ((rc = dev_alloc(idx, &wblk, (uint64_t)nblk + 1))) return rc;
+    WALT_HIP(hipMalloc(reinterpret_cast<void**>(&flag), ((uint64_t)nblk + 1) * 4));
+    hipLaunchKernelGGL(k_win_mark, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, sv.g2, sv.ent, sv.index_size, nblk, flag);
+    size_t tmp_bytes = 0;
+    hipError_t se = rocprim::exclusive_scan(nullptr, tmp_bytes, flag, wblk, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), stream);
+    void* tmp = nullptr;
+    if (se == hipSuccess) se = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+    if (se == hipSuccess) se = rocprim::exclusive_scan(tmp, tmp_bytes, flag, wblk, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), stream);
+    uint32_t last_scan = 0, last_flag = 0;
+    if (se == hipSuccess) se = hipMemcpyAsync(&last_scan, wblk + (nblk - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (se == hipSuccess) se = hipMemcpyAsync(&last_flag, flag + (nblk - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (se == hipSuccess) se = hipStreamSynchronize(stream);
+    if (tmp) hipFree(tmp);
+    if (se != hipSuccess) { hipFree(flag); WALT_HIP(se); }
+    const uint32_t want_blocks = last_scan + last_flag;
+    const uint32_t n_dense = want_blocks < cap_blocks ? want_blocks : cap_blocks;
+    hipLaunchKernelGGL(k_win_assign, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, flag, wblk, nblk, n_dense);
+    hipError_t sy = hipStreamSynchronize(stream);
+    hipFree(flag);
+    WALT_HIP(sy);
+    if (getenv("WALT_AMD_VERBOSE"))
+      fprintf(stderr, "[walt_amd index: strand %d: %u of %u 64-slot blocks lie inside one region (%.2f %% of the entries); dense windows "
+              "for %u of them, %.2f GB]\n", s, want_blocks, nblk, 100.0 * 64.0 * want_blocks / (double)sv.index_size, n_dense,
+              (double)n_dense * block_bytes / 1e9);
+    idx->window_blocks[s] = n_dense;
+    if (n_dense == 0) continue;
+    uint32_t *win = nullptr, *win2 = nullptr;
+    if ((rc = dev_alloc(idx, &win, (uint64_t)n_dense * 64 * (kWinWords + 1) + 16))) return rc;
+    if ((rc = dev_alloc(idx, &win2, (uint64_t)n_dense * 64 * kWinWords2 + 16))) return rc;
+    hipLaunchKernelGGL(k_win_fill, dim3((unsigned)(((uint64_t)nblk * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sv.g2,
+                       sv.ent, wblk, nblk, win, win2);
+    WALT_HIP(hipStreamSynchronize(stream));
+    WALT_HIP(hipGetLastError());
+    sv.wblk = wblk; sv.win = win; sv.win2 = win2;
+  }
+  return WALT_OK;
+}
+
 int finish_index_device(walt_index* idx) {
   int rc;
+  if ((rc = build_windows(idx))) return rc;
   const std::vector<uint32_t>& mt = compare_mask_table();
   if ((rc = dev_alloc(idx, &idx->d_mask_table, mt.size()))) return rc;
   WALT_HIP(hipMemcpy(idx->d_mask_table, mt.data(), mt.size() * 4, hipMemcpyHostToDevice));
@@ -792,6 +923,9 @@ uint64_t walt_index_bad_buckets(const walt_index* idx, int strand) {
 }
 uint64_t walt_index_outliers(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->outliers[strand] : 0;
+}
+uint64_t walt_index_window_entries(const walt_index* idx, int strand) {
+  return idx && strand >= 0 && strand < 4 ? 64ull * idx->window_blocks[strand] : 0;
 }
 
 }  // extern "C"

@@ -424,6 +424,75 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const Bloc
   if (ok) mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
 }
 
+// ---- candidates of a wave-cooperative region: G groups of 64 consecutive index slots per step ----
+// Lane `lane` takes slots l + base + 64 u + lane, u < G.  Three rounds of INDEPENDENT loads per step (a
+// listed / owner read has its whole wave to itself, nothing else hides the latency):
+//   1. wblk[slot >> 6] -- does the slot's block have dense candidate windows (core.h StrandView::win)?
+//   2. the dense record {pos, window} (32 contiguous bytes per candidate, 48 for reads above 110 bases), or
+//      the index entry's pos where there is none,
+//   3. for the latter the genome window (one scattered 128-byte line per candidate).
+// mm[u] = 0xFFFFFFFF where the slot is beyond the region or fails the edge filters of mapping.cpp:280-286.
+template <int NW>
+__device__ __forceinline__ bool win_usable(const StrandView& sv, uint32_t len) {
+  return NW <= 10 && sv.wblk != nullptr && len <= (NW <= 7 ? kWinMaxLen1 : kWinMaxLen2);
+}
+template <int NW, int G>
+__device__ __forceinline__ void coop_verify_groups(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
+                                                   uint32_t l, uint32_t size, uint32_t base, uint32_t seed_i,
+                                                   uint32_t len, const uint32_t* rd, const uint32_t* mk,
+                                                   uint32_t lane, bool dense, uint32_t* gp, uint32_t* mm) {
+  uint32_t wb[G], pos[G];
+  uint32_t win[G][NW <= 10 ? NW + 1 : 1];
+#pragma unroll
+  for (int u = 0; u < G; ++u) {
+    const uint32_t k = base + 64 * u + lane;
+    wb[u] = 0;
+    if (dense && k < size) wb[u] = sv.wblk[(l + k) >> 6];
+  }
+#pragma unroll
+  for (int u = 0; u < G; ++u) {
+    const uint32_t k = base + 64 * u + lane;
+    pos[u] = 0;
+    if constexpr (NW <= 10) {
+#pragma unroll
+      for (int w = 0; w <= NW; ++w) win[u][w] = 0;
+      if (wb[u]) {
+        const uint64_t rec = (uint64_t)(wb[u] - 1) * 64 + ((l + k) & 63u);
+        const uint4 a = reinterpret_cast<const uint4*>(sv.win)[2 * rec], c = reinterpret_cast<const uint4*>(sv.win)[2 * rec + 1];
+        pos[u] = a.x;
+        const uint32_t first[7] = {a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int w = 0; w < 7 && w <= NW; ++w) win[u][w] = first[w];
+        if constexpr (NW > 7) {
+          const uint4 e = reinterpret_cast<const uint4*>(sv.win2)[rec];
+          const uint32_t more[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+          for (int w = 7; w <= NW; ++w) win[u][w] = more[w - 7];
+        }
+      }
+    }
+    if (!wb[u] && k < size) pos[u] = sv.ent[l + k].pos;
+  }
+#pragma unroll
+  for (int u = 0; u < G; ++u) {
+    const uint32_t k = base + 64 * u + lane;
+    const uint32_t chr = chrom_id(si, n_chrom, pos[u]);
+    const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+    const uint32_t g = pos[u] - seed_i;
+    const bool ok = k < size && (pos[u] - c_lo >= seed_i) && (g + len < c_hi);
+    gp[u] = ok ? g : 0u;
+    uint32_t m = 0xFFFFFFFFu;
+    if (ok) {
+      if constexpr (NW <= 10) {
+        m = wb[u] ? count_mismatch_regs<NW>(win[u], 2 * (kWinLead - seed_i), rd, mk) : count_mismatch<NW>(sv.g2, g, rd, mk);
+      } else {
+        m = count_mismatch<NW>(sv.g2, g, rd, mk);
+      }
+    }
+    mm[u] = m;
+  }
+}
+
 // Append `value` to a device list for the lanes with `take` set: ONE atomic per wavefront (an assembly of
 // thousands of contigs defers a fifth of the reads, and ten million same-address atomics cost milliseconds).
 // All 64 lanes must call this.

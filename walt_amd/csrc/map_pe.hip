@@ -148,25 +148,13 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         // kCoopUnroll x 64 candidates per step: the slot loads of a step are independent, then the genome
         // windows are, so a step costs two memory round trips instead of 2 x kCoopUnroll (a listed read
         // owns its wave, nothing else hides the latency); pushes stay in slot order.
+        const bool dense = win_usable<NW>(sv, o_len);
         for (uint32_t base = 0; base < o_size; base += 64 * kCoopUnroll) {
-          uint32_t cpos[kCoopUnroll], cgp[kCoopUnroll], cmm[kCoopUnroll];
+          uint32_t cgp[kCoopUnroll], cmm[kCoopUnroll];
+          coop_verify_groups<NW, (int)kCoopUnroll>(sv, si, n_chrom, o_l, o_size, base, seed_i, o_len, o_rd, o_mk, lane, dense,
+                                                   cgp, cmm);  // paired.cpp:166-190
 #pragma unroll
-          for (uint32_t u = 0; u < kCoopUnroll; ++u) {
-            const uint32_t k = base + u * 64 + lane;
-            cpos[u] = sv.ent[o_l + (k < o_size ? k : o_size - 1)].pos;
-          }
-#pragma unroll
-          for (uint32_t u = 0; u < kCoopUnroll; ++u) {
-            const uint32_t k = base + u * 64 + lane;
-            const uint32_t chr = chrom_id(si, n_chrom, cpos[u]);
-            const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
-            const uint32_t g = cpos[u] - seed_i;
-            const bool ok = k < o_size && (cpos[u] - c_lo >= seed_i) && (g + o_len < c_hi);  // paired.cpp:166-171
-            cgp[u] = ok ? g : 0u;
-            const uint32_t m = count_mismatch<NW>(sv.g2, cgp[u], o_rd, o_mk);
-            cmm[u] = ok ? m : 0xFFFFFFFFu;
-            n_verified += ok ? 1u : 0u;
-          }
+          for (uint32_t u = 0; u < kCoopUnroll; ++u) n_verified += cmm[u] != 0xFFFFFFFFu ? 1u : 0u;
 #pragma unroll
           for (uint32_t u = 0; u < kCoopUnroll; ++u) {
             if (base + u * 64 >= o_size) break;

@@ -69,32 +69,30 @@ void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uin
 // All 64 lanes call this with the same (uniform) arguments broadcast from the
 // owner.  Returns the RegionSummary of the region in candidate order.
 // ---------------------------------------------------------------------------
+constexpr int kCoopGroupsSe = 1;  // 128 candidates per step (map_common.h coop_verify_groups)
 template <int NW>
 __device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
                                                      uint32_t l, uint32_t size, uint32_t seed_i, uint32_t len,
                                                      const uint32_t* rd, const uint32_t* mk, uint32_t lane,
                                                      uint32_t& n_verified) {
   RegionSummary acc = summary_empty();
-  for (uint32_t base = 0; base < size; base += 64) {
-    uint32_t k = base + lane;
-    uint32_t mm = 0xFFFFFFFFu, gp = 0;
-    if (k < size) {
-      uint32_t pos = sv.ent[l + k].pos;
-      uint32_t m;
-      if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, len, rd, mk, gp, m)) {
-        mm = m;
-        ++n_verified;
+  const bool dense = win_usable<NW>(sv, len);
+  for (uint32_t base = 0; base < size; base += 64 * kCoopGroupsSe) {
+    uint32_t gp[kCoopGroupsSe], mm[kCoopGroupsSe];
+    coop_verify_groups<NW, kCoopGroupsSe>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, dense, gp, mm);
+#pragma unroll
+    for (int u = 0; u < kCoopGroupsSe; ++u) {
+      n_verified += mm[u] != 0xFFFFFFFFu ? 1u : 0u;
+      const uint32_t mn = wave_min_u32(mm[u]);
+      if (mn != 0xFFFFFFFFu) {
+        const unsigned long long eq = __ballot(mm[u] == mn);
+        RegionSummary c;
+        c.min_mm = mn;
+        c.count = (uint32_t)__popcll(eq);
+        c.first = bcast(gp[u], (int)__ffsll((long long)eq) - 1);
+        c.last = bcast(gp[u], 63 - (int)__clzll((long long)eq));
+        acc = summary_merge(acc, c);
       }
-    }
-    uint32_t mn = wave_min_u32(mm);
-    if (mn != 0xFFFFFFFFu) {
-      unsigned long long eq = __ballot(mm == mn);
-      RegionSummary c;
-      c.min_mm = mn;
-      c.count = (uint32_t)__popcll(eq);
-      c.first = bcast(gp, (int)__ffsll((long long)eq) - 1);
-      c.last = bcast(gp, 63 - (int)__clzll((long long)eq));
-      acc = summary_merge(acc, c);
     }
   }
   return acc;

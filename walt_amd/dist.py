@@ -2,8 +2,9 @@
 rank holds a full index replica, and the ONLY collective is the final sum of the
 mapping statistics (StatSingleReads, mapping.hpp:94-100; StatPairedReads incl. the
 fragment-length histogram, paired.hpp:96-105) -- nccl (= RCCL over xGMI) on GPUs,
-gloo in the CPU tests.  torch is imported lazily: the single-GPU binding does
-not need it."""
+gloo in the CPU tests; the same sum is available without torch through the C ABI
+(walt_stats_allreduce, walt_amd.Comm).  torch is imported lazily: the single-GPU
+binding does not need it."""
 
 
 def shard_range(n_total, rank, world_size):
@@ -27,6 +28,43 @@ def se_stats_vector(times, too_short):
                         torch.tensor(int(too_short), device=t.device)]).to(torch.int64)
 
 
+def pe_stats_len(frag_range):
+    return 4 + 2 * 5 + int(frag_range) + 1
+
+
+def pe_stats_vector(pair_words, frag_range, too_short1=0, too_short2=0):
+    """StatPairedReads as ProcessPairedEndReads accumulates it (paired.hpp:96-105):
+         [0:4]    total_read_pairs, unique, ambiguous, unmapped pairs          (paired.cpp:519-539)
+         [4:9]    mate 1: total, unique, ambiguous, unmapped, too_short        (updated only for pairs
+         [9:14]   mate 2                                                        without a unique best pair, 546-547)
+         [14:]    fragment_len_count[0 .. frag_range]                          (paired.cpp:526)
+    pair_words: the walt_pair_result records of a batch viewed as an [n, 16] int32 tensor (numpy or torch):
+    m1 = words 0..3, m2 = 4..7 (times at +1), best_times = word 8, frag_len = word 9."""
+    import torch
+    w = torch.as_tensor(pair_words)
+    dev = w.device
+    bt = w[:, 8]
+    uniq = bt == 1
+    out = torch.zeros(pe_stats_len(frag_range), dtype=torch.int64, device=dev)
+    out[0] = w.shape[0]
+    out[1] = uniq.sum()
+    out[2] = (bt >= 2).sum()
+    out[3] = (bt == 0).sum()
+    rest = ~uniq
+    for k, (col, short) in enumerate(((1, too_short1), (5, too_short2))):
+        t = w[:, col][rest]
+        base = 4 + 5 * k
+        out[base] = t.numel()
+        out[base + 1] = (t == 1).sum()
+        out[base + 2] = (t >= 2).sum()
+        out[base + 3] = (t == 0).sum()
+        out[base + 4] = int(short)
+    fl = w[:, 9][uniq].to(torch.int64)
+    if fl.numel():
+        out[14:] = torch.bincount(fl.clamp(0, int(frag_range)), minlength=int(frag_range) + 1)
+    return out
+
+
 def allreduce_stats(vec, group=None):
     """Sum an int64 statistics vector over all ranks (no-op without a process group)."""
     import torch.distributed as dist
@@ -42,3 +80,16 @@ def allreduce_max(value, device="cpu", group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def c_abi_comm(device, group=None):
+    """walt_amd.Comm (RCCL through the C ABI) for the ranks of the initialised torch.distributed group:
+    rank 0 makes the unique id and torch.distributed carries it to the others (the out-of-band step
+    walt_comm_unique_id asks for)."""
+    import torch
+    import torch.distributed as dist
+    import walt_amd
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [walt_amd.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return walt_amd.Comm(device, rank, world, box[0])
