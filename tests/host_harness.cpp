@@ -122,7 +122,7 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
   s.view.bloom = nullptr; s.view.bloom_mask = 0; s.view.outl = s.outl.data(); s.view.n_outl = (uint32_t)s.outl.size();
   s.view.outl_dir_mask = build_outlier_dir(s.outl.data(), s.view.n_outl, s.outl_dir) - 1;
   s.view.outl_dir = s.outl_dir.data();
-  s.view.wblk = nullptr; s.view.win = nullptr; s.view.win2 = nullptr;
+  s.view.wbits = nullptr; s.view.wrank = nullptr; s.view.win = nullptr; s.view.win2 = nullptr; s.view.wcap = 0;
   h->view.s[strand] = s.view;
   h->view.start_index = h->start.data();
   h->present[strand] = true;

@@ -115,22 +115,61 @@ struct StrandView {
   // young SINE / LINE copies: 2 % of the reads of an hg19-like genome own 90 % of all candidates) is a run of
   // consecutive index slots, but the genome windows behind them are scattered: one random 128-byte line per
   // candidate for 25 useful bytes, and the device serves ~48 G such lines per second whatever their size.
-  // For every 64-slot block of the index that lies inside ONE region of a 100-base read (same bucket, same
-  // first kWinKeyChars key characters) the windows are therefore stored once more, in slot order:
-  //   wblk[slot >> 6]  1 + number of the dense block, 0 = the block has none (take ent[] + g2[])
-  //   win              dense block d: 64 records of 8 words {pos, the 112 bases from genome position pos - kWinLead}
-  //   win2             dense block d: 64 records of 4 words, the following 64 bases (reads of 111..160 bases)
+  // For every run of the index that lies inside ONE region of a 100-base read (same bucket, same first
+  // kWinKeyChars key characters) and holds at least one aligned 16-slot block -- i.e. every run of 31 slots or
+  // more, and some shorter ones -- the windows of ALL its slots are therefore stored once more, in slot order:
+  //   wbits[slot >> 6]  bit (slot & 63): the slot has a dense record
+  //   wrank[slot >> 6]  number of dense records in front of this 64-slot word (record of a slot = rank + popcount)
+  //   win               record r: 8 words {pos, the 112 bases from genome position pos - kWinLead}
+  //   win2              record r: 4 words, the following 64 bases (reads of 111..160 bases)
+  //   wcap              records that exist (the memory budget may end before the last run)
   // so that the wavefront verifying such a region streams 32 (48) contiguous bytes per candidate.  A record is a
-  // copy of the g2 bits count_mismatch would read, so the mismatch counts are the same by construction.
-  const uint32_t* wblk;
+  // copy of the g2 bits count_mismatch would read, so the mismatch counts are the same by construction.  A region
+  // of a read of 100 bases or more lies inside one run, its records are consecutive, and four words tell whether
+  // all of them exist (core.h dense_range); anything else takes ent[] + g2[] as before.
+  const unsigned long long* wbits;
+  const uint32_t* wrank;
   const uint32_t* win;
   const uint32_t* win2;
+  uint32_t wcap;
+  uint32_t wpad_;
 };
+constexpr uint32_t kWinShift = 4, kWinBlock = 1u << kWinShift;  // index slots per dense block
 constexpr uint32_t kWinLead = kPat - 1;   // bases in front of pos: the largest seed shift (genome_pos = pos - seed_i)
 constexpr uint32_t kWinWords = 7, kWinWords2 = 4;
 constexpr uint32_t kWinKeyChars = kPat == 3 ? 20 : (kPat == 5 ? 26 : 32);  // key characters of a 100-base read's seed
 // reads of up to this many bases can be verified on the record(s): win alone / win + win2
 constexpr uint32_t kWinMaxLen1 = 16 * kWinWords - kWinLead, kWinMaxLen2 = 16 * (kWinWords + kWinWords2) - kWinLead;
+// The part of a region [l, l + size) whose candidates have dense records: slots [lo, hi), record `rec` belongs
+// to slot lo (records of consecutive slots are consecutive).  All of the region or nothing (lo == hi == l).
+// Four independent loads.
+struct DenseRange {
+  uint32_t lo, hi;
+  uint64_t rec;
+};
+WALT_HD uint32_t popc64(unsigned long long x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__popcll(x);
+#else
+  return (uint32_t)__builtin_popcountll(x);
+#endif
+}
+WALT_HD DenseRange dense_range(const StrandView& sv, uint32_t l, uint32_t size, bool usable) {
+  DenseRange d;
+  d.lo = d.hi = l;
+  d.rec = 0;
+  if (usable && size) {
+    const uint32_t last = l + size - 1;
+    const unsigned long long b0 = sv.wbits[l >> 6], b1 = sv.wbits[last >> 6];
+    const uint32_t k0 = sv.wrank[l >> 6], k1 = sv.wrank[last >> 6];
+    const uint32_t r0 = k0 + popc64(b0 & ((1ull << (l & 63u)) - 1ull)), r1 = k1 + popc64(b1 & ((1ull << (last & 63u)) - 1ull));
+    if (((b0 >> (l & 63u)) & 1ull) && ((b1 >> (last & 63u)) & 1ull) && r1 - r0 == size - 1 && r1 < sv.wcap) {
+      d.hi = l + size;
+      d.rec = r0;
+    }
+  }
+  return d;
+}
 
 // An index entry whose care positions run over the end of its chromosome before
 // care character 44.  makedb sorted it as if every character from index q on
@@ -460,31 +499,71 @@ WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint
 constexpr uint32_t kScan = 4;
 constexpr uint32_t kLookupPos = 4;  // == kSmallRegion of the kernels
 
-// equal range [a,u] of masked key T among the sorted entries [lo,hi) by binary
-// search (slots longer than kScan); false when T is not present
-WALT_HD bool slot_binary_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a,
-                                uint32_t& u) {
-  uint32_t x = lo, y = hi;
-  while (x < y) {  // lower bound
-    uint32_t mid = x + ((y - x) >> 1);
-    if ((ent_key(sv.ent[mid]) & M) < T) x = mid + 1; else y = mid;
-  }
-  a = x;
-  if (a == hi || (ent_key(sv.ent[a]) & M) != T) return false;
-  u = a;
-  uint32_t probe = 0;  // upper end: short linear probe, then binary search
-  while (u + 1 < hi && probe < 4) {
-    if ((ent_key(sv.ent[u + 1]) & M) != T) break;
-    ++u; ++probe;
-  }
-  if (probe == 4 && u + 1 < hi) {
-    x = u + 1; y = hi;  // first index in [x,y) with masked key > T
-    while (x < y) {
-      uint32_t mid = x + ((y - x) >> 1);
-      if ((ent_key(sv.ent[mid]) & M) <= T) x = mid + 1; else y = mid;
+// equal range [a,u] of masked key T among the sorted entries [lo,hi) (slots longer than kScanMax: the slot of
+// a read from a satellite or a young repeat family holds thousands of entries); false when T is not present.
+// Two searches -- first entry >= T, first entry > T -- advance together, each round loading kKary pivots
+// per search with INDEPENDENT loads: ~log4(n) + 1 memory round trips instead of the ~2 log2(n) + 4 of two
+// binary searches (a 4,096-entry slot: 7 instead of 28), which every wavefront with such a lane waits for.
+constexpr uint32_t kKary = 4;
+WALT_HD bool slot_kary_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a,
+                              uint32_t& u) {
+  uint32_t x1 = lo, y1 = hi;  // first index whose masked key is >= T lies in [x1, y1]
+  uint32_t x2 = lo, y2 = hi;  // first index whose masked key is >  T lies in [x2, y2]
+  while (y1 > x1 || y2 > x2) {
+    const uint32_t n1 = y1 > x1 ? y1 - x1 : 0u, n2 = y2 > x2 ? y2 - x2 : 0u;  // (a range can only invert on an unsorted slot)
+    uint32_t i1[kKary], i2[kKary];
+    uint64_t k1[kKary], k2[kKary];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < kKary; ++i) {  // pivots at the odd eighths of the range (clamped copies when it is short)
+      i1[i] = x1 + (uint32_t)(((uint64_t)(2 * i + 1) * n1) / (2 * kKary));
+      i2[i] = x2 + (uint32_t)(((uint64_t)(2 * i + 1) * n2) / (2 * kKary));
     }
-    u = x - 1;
+    const bool same = x1 == x2 && y1 == y2;  // the two ranges part only when they are down to the size of the region
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < kKary; ++i) {
+      k1[i] = n1 ? ent_key(sv.ent[i1[i]]) & M : 0;
+      k2[i] = same ? k1[i] : (n2 ? ent_key(sv.ent[i2[i]]) & M : 0);
+    }
+    if (n1) {
+      uint32_t c = 0;  // pivots below T: a prefix of them (sorted slot)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (uint32_t i = 0; i < kKary; ++i) c += k1[i] < T ? 1u : 0u;
+      uint32_t nx = x1, ny = y1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (uint32_t i = 0; i < kKary; ++i) {
+        nx = (c == i + 1) ? i1[i] + 1 : nx;
+        ny = (c == i) ? i1[i] : ny;
+      }
+      x1 = nx; y1 = ny;
+    }
+    if (n2) {
+      uint32_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (uint32_t i = 0; i < kKary; ++i) c += k2[i] <= T ? 1u : 0u;
+      uint32_t nx = x2, ny = y2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (uint32_t i = 0; i < kKary; ++i) {
+        nx = (c == i + 1) ? i2[i] + 1 : nx;
+        ny = (c == i) ? i2[i] : ny;
+      }
+      x2 = nx; y2 = ny;
+    }
   }
+  if (x2 <= x1) return false;
+  a = x1;
+  u = x2 - 1;
   return true;
 }
 
@@ -658,7 +737,7 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     u = a + n_eq - 1;
     out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
   } else {
-    if (!slot_binary_search(sv, lo, hi, T, M, a, u)) return;
+    if (!slot_kary_search(sv, lo, hi, T, M, a, u)) return;
   }
   if (n > kKeyChars) {
     const uint32_t size = u - a + 1;

@@ -29,7 +29,7 @@ struct walt_index {
   uint64_t device_bytes = 0;
   uint64_t bad_buckets[4] = {0, 0, 0, 0};
   uint64_t outliers[4] = {0, 0, 0, 0};
-  uint32_t window_blocks[4] = {0, 0, 0, 0};  // 64-slot blocks with dense candidate windows (core.h StrandView::win)
+  uint32_t window_records[4] = {0, 0, 0, 0};  // index slots with a dense candidate window (core.h StrandView::win)
   unsigned strand_mask = 0;
   // measurement hooks (walt_profile_enable / walt_profile_last)
   bool profile = false;

@@ -435,7 +435,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   sv.outl = outl; sv.n_outl = n_outl;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
   sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1; sv.pre = pre; sv.tab = tab;
-  sv.wblk = nullptr; sv.win = nullptr; sv.win2 = nullptr;  // build_windows, once every strand is resident
+  sv.wbits = nullptr; sv.wrank = nullptr; sv.win = nullptr; sv.win2 = nullptr; sv.wcap = 0;  // build_windows, once every strand is resident
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }
@@ -466,14 +466,14 @@ int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, con
 // ---------------------------------------------------------------------------
 // Dense candidate windows (core.h StrandView::wblk / win / win2)
 // ---------------------------------------------------------------------------
-// flag[b] = 1 when the 64 slots of block b lie inside one region of a 100-base read: same bucket and same first
+// flag[b] = 1 when the kWinBlock slots of block b lie inside one region of a 100-base read: same bucket and same first
 // kWinKeyChars key characters at both ends (entries between two equal ends of a sorted bucket are equal too; a
 // chromosome-end entry out of order only changes which blocks are chosen, never what a record holds)
 __global__ void k_win_mark(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t index_size,
                            uint32_t nblk, uint32_t* __restrict__ flag) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
-  const uint64_t first = 64ull * b, last = first + 63;
+  const uint64_t first = (uint64_t)kWinBlock * b, last = first + kWinBlock - 1;
   uint32_t f = 0;
   if (last < index_size) {
     const Ent a = ent[first], z = ent[last];
@@ -481,26 +481,50 @@ __global__ void k_win_mark(const uint32_t* __restrict__ g2, const Ent* __restric
   }
   flag[b] = f;
 }
-// flag + its exclusive scan -> wblk (in place over the scan): 1 + dense block number, 0 beyond the budget
-__global__ void k_win_assign(const uint32_t* __restrict__ flag, uint32_t* __restrict__ scan_wblk, uint32_t nblk,
-                             uint32_t cap_blocks) {
+// bitmap of the slots with dense records: the 16 slots of every flagged block, and from a flagged block whose
+// neighbour is not flagged up to 15 slots further while they belong to the same run (same bucket, same first
+// kWinKeyChars key characters): the rest of a run that starts or ends inside a block
+__global__ void k_win_bits(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t index_size,
+                           const uint32_t* __restrict__ flag, uint32_t nblk, unsigned long long* __restrict__ bits) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nblk) return;
-  const uint32_t d = scan_wblk[b];
-  scan_wblk[b] = (flag[b] && d < cap_blocks) ? d + 1 : 0u;
+  if (b >= nblk || !flag[b]) return;
+  const uint64_t first = (uint64_t)kWinBlock * b;
+  atomicOr(&bits[first >> 6], (unsigned long long)((1u << kWinBlock) - 1u) << (first & 63u));
+  const Ent ref = ent[first];
+  const uint32_t h_ref = hash_at_dev(g2, ref.pos);
+  const uint64_t kref = ent_key(ref) >> (64 - 2 * kWinKeyChars);
+  if (b > 0 && !flag[b - 1]) {
+    for (uint64_t j = first; j-- > first - (kWinBlock - 1);) {
+      const Ent e = ent[j];
+      if ((ent_key(e) >> (64 - 2 * kWinKeyChars)) != kref || hash_at_dev(g2, e.pos) != h_ref) break;
+      atomicOr(&bits[j >> 6], 1ull << (j & 63u));
+    }
+  }
+  if (b + 1 >= nblk || !flag[b + 1]) {
+    for (uint64_t j = first + kWinBlock; j < first + 2 * kWinBlock - 1 && j < index_size; ++j) {
+      const Ent e = ent[j];
+      if ((ent_key(e) >> (64 - 2 * kWinKeyChars)) != kref || hash_at_dev(g2, e.pos) != h_ref) break;
+      atomicOr(&bits[j >> 6], 1ull << (j & 63u));
+    }
+  }
 }
-// one thread per record: {pos, 112 bases from pos - kWinLead} into win, the next 64 bases into win2.  The bases
+__global__ void k_win_popc(const unsigned long long* __restrict__ bits, uint32_t nw, uint32_t* __restrict__ cnt) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < nw) cnt[w] = (uint32_t)__popcll(bits[w]);
+}
+// one thread per index slot: {pos, 112 bases from pos - kWinLead} into win, the next 64 bases into win2.  The bases
 // are the g2 bits count_mismatch reads for a candidate at pos - seed_i (g2 carries kG2PadWords of slack);
 // bases in front of the genome's first (pos < kWinLead) are never compared and are stored as 0.
-__global__ void k_win_fill(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent,
-                           const uint32_t* __restrict__ wblk, uint32_t nblk, uint32_t* __restrict__ win,
-                           uint32_t* __restrict__ win2) {
+__global__ void k_win_fill(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t index_size,
+                           const unsigned long long* __restrict__ bits, const uint32_t* __restrict__ rank, uint32_t cap,
+                           uint32_t* __restrict__ win, uint32_t* __restrict__ win2) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t b = t >> 6;
-  if (b >= nblk) return;
-  const uint32_t d1 = wblk[b];
-  if (!d1) return;
-  const uint32_t pos = ent[t].pos;  // slot 64 b + (t & 63) == t
+  if (t >= index_size) return;
+  const unsigned long long wbits = bits[t >> 6];
+  if (!((wbits >> (t & 63u)) & 1ull)) return;
+  const uint32_t rec = rank[t >> 6] + (uint32_t)__popcll(wbits & ((1ull << (t & 63u)) - 1ull));
+  if (rec >= cap) return;
+  const uint32_t pos = ent[t].pos;
   constexpr int kAll = (int)(kWinWords + kWinWords2);
   uint32_t w[kAll];
   const int64_t start = (int64_t)pos - (int64_t)kWinLead;
@@ -514,14 +538,13 @@ __global__ void k_win_fill(const uint32_t* __restrict__ g2, const Ent* __restric
       w[i] = g2[0] << (2 * (uint32_t)(-q));  // only i == 0: 16 > kWinLead
     }
   }
-  const uint64_t rec = (uint64_t)(d1 - 1) * 64 + (t & 63);
   uint4 a, c, e;
   a.x = pos; a.y = w[0]; a.z = w[1]; a.w = w[2];
   c.x = w[3]; c.y = w[4]; c.z = w[5]; c.w = w[6];
   e.x = w[7]; e.y = w[8]; e.z = w[9]; e.w = w[10];
-  reinterpret_cast<uint4*>(win)[2 * rec] = a;
-  reinterpret_cast<uint4*>(win)[2 * rec + 1] = c;
-  if (win2) reinterpret_cast<uint4*>(win2)[rec] = e;
+  reinterpret_cast<uint4*>(win)[2ull * rec] = a;
+  reinterpret_cast<uint4*>(win)[2ull * rec + 1] = c;
+  reinterpret_cast<uint4*>(win2)[rec] = e;
 }
 
 // Windows for every resident strand, within what the device can spare: WALT_AMD_WIN_GB (default 16) per strand,
@@ -540,54 +563,63 @@ static int build_windows(walt_index* idx) {
   for (int s = 0; s < 4; ++s) {
     if (!((idx->strand_mask >> s) & 1u)) continue;
     StrandView& sv = idx->view.s[s];
-    const uint32_t nblk = (uint32_t)(((uint64_t)sv.index_size + 63) / 64);
+    const uint32_t nblk = (uint32_t)(((uint64_t)sv.index_size + kWinBlock - 1) >> kWinShift);
+    const uint32_t nw = (uint32_t)(((uint64_t)sv.index_size + 63) >> 6);
     if (nblk == 0) { --n_strands; continue; }
     size_t free_b = 0, total_b = 0;
     WALT_HIP(hipMemGetInfo(&free_b, &total_b));
     // a small index (tests, bacterial genomes) needs no reserve: its batches are small too
     const double reserve = std::min(reserve_gb * 1e9, 0.25 * (double)total_b);
-    double budget = ((double)free_b - reserve - 8.0 * nblk) / n_strands;  // 8 nblk: flag + wblk
+    double budget = ((double)free_b - reserve - 16.0 * nw - 4.0 * nblk) / n_strands;  // bitmap, ranks and the builder's temporaries
     budget = std::min(budget, cap_gb * 1e9);
     --n_strands;
-    const uint64_t block_bytes = 64ull * 4 * (kWinWords + 1 + kWinWords2);
-    if (budget < (double)block_bytes) continue;
-    const uint32_t cap_blocks = (uint32_t)std::min<double>(budget / (double)block_bytes, 4.0e9);
-    uint32_t *flag = nullptr, *wblk = nullptr;
+    const uint64_t rec_bytes = 4ull * (kWinWords + 1 + kWinWords2);
+    if (budget < 1024.0 * rec_bytes) continue;
+    // record numbers must fit 32 bits: the mapping kernels pass them between lanes as one word
+    const uint32_t cap_recs = (uint32_t)std::min<double>(budget / (double)rec_bytes, 4.0e9);
+    uint32_t *flag = nullptr, *rank = nullptr;
+    unsigned long long* bits = nullptr;
     int rc;
-    if ((rc = dev_alloc(idx, &wblk, (uint64_t)nblk + 1))) return rc;
+    if ((rc = dev_alloc(idx, &bits, (uint64_t)nw + 1))) return rc;
+    if ((rc = dev_alloc(idx, &rank, (uint64_t)nw + 1))) return rc;
     WALT_HIP(hipMalloc(reinterpret_cast<void**>(&flag), ((uint64_t)nblk + 1) * 4));
+    WALT_HIP(hipMemsetAsync(bits, 0, ((uint64_t)nw + 1) * 8, stream));
     hipLaunchKernelGGL(k_win_mark, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, sv.g2, sv.ent, sv.index_size, nblk, flag);
+    hipLaunchKernelGGL(k_win_bits, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, sv.g2, sv.ent, sv.index_size, flag, nblk, bits);
+    hipError_t se = hipStreamSynchronize(stream);
+    hipFree(flag);
+    WALT_HIP(se);
+    uint32_t* cnt = nullptr;
+    WALT_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), ((uint64_t)nw + 1) * 4));
+    hipLaunchKernelGGL(k_win_popc, dim3(grid_for(nw)), dim3(kBlock), 0, stream, bits, nw, cnt);
     size_t tmp_bytes = 0;
-    hipError_t se = rocprim::exclusive_scan(nullptr, tmp_bytes, flag, wblk, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), stream);
+    se = rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, rank, 0u, (size_t)nw, rocprim::plus<uint32_t>(), stream);
     void* tmp = nullptr;
     if (se == hipSuccess) se = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
-    if (se == hipSuccess) se = rocprim::exclusive_scan(tmp, tmp_bytes, flag, wblk, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), stream);
-    uint32_t last_scan = 0, last_flag = 0;
-    if (se == hipSuccess) se = hipMemcpyAsync(&last_scan, wblk + (nblk - 1), 4, hipMemcpyDeviceToHost, stream);
-    if (se == hipSuccess) se = hipMemcpyAsync(&last_flag, flag + (nblk - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (se == hipSuccess) se = rocprim::exclusive_scan(tmp, tmp_bytes, cnt, rank, 0u, (size_t)nw, rocprim::plus<uint32_t>(), stream);
+    uint32_t last_rank = 0, last_cnt = 0;
+    if (se == hipSuccess) se = hipMemcpyAsync(&last_rank, rank + (nw - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (se == hipSuccess) se = hipMemcpyAsync(&last_cnt, cnt + (nw - 1), 4, hipMemcpyDeviceToHost, stream);
     if (se == hipSuccess) se = hipStreamSynchronize(stream);
     if (tmp) hipFree(tmp);
-    if (se != hipSuccess) { hipFree(flag); WALT_HIP(se); }
-    const uint32_t want_blocks = last_scan + last_flag;
-    const uint32_t n_dense = want_blocks < cap_blocks ? want_blocks : cap_blocks;
-    hipLaunchKernelGGL(k_win_assign, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, flag, wblk, nblk, n_dense);
-    hipError_t sy = hipStreamSynchronize(stream);
-    hipFree(flag);
-    WALT_HIP(sy);
+    hipFree(cnt);
+    WALT_HIP(se);
+    const uint64_t want = (uint64_t)last_rank + last_cnt;
+    const uint32_t n_recs = (uint32_t)std::min<uint64_t>(want, cap_recs);
     if (getenv("WALT_AMD_VERBOSE"))
-      fprintf(stderr, "[walt_amd index: strand %d: %u of %u 64-slot blocks lie inside one region (%.2f %% of the entries); dense windows "
-              "for %u of them, %.2f GB]\n", s, want_blocks, nblk, 100.0 * 64.0 * want_blocks / (double)sv.index_size, n_dense,
-              (double)n_dense * block_bytes / 1e9);
-    idx->window_blocks[s] = n_dense;
-    if (n_dense == 0) continue;
+      fprintf(stderr, "[walt_amd index: strand %d: %llu of %u index slots (%.2f %%) lie in runs with dense candidate windows; records for "
+              "%u of them, %.2f GB]\n", s, (unsigned long long)want, sv.index_size, 100.0 * (double)want / (double)sv.index_size, n_recs,
+              (double)n_recs * rec_bytes / 1e9);
+    idx->window_records[s] = n_recs;
+    if (n_recs == 0) continue;
     uint32_t *win = nullptr, *win2 = nullptr;
-    if ((rc = dev_alloc(idx, &win, (uint64_t)n_dense * 64 * (kWinWords + 1) + 16))) return rc;
-    if ((rc = dev_alloc(idx, &win2, (uint64_t)n_dense * 64 * kWinWords2 + 16))) return rc;
-    hipLaunchKernelGGL(k_win_fill, dim3((unsigned)(((uint64_t)nblk * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sv.g2,
-                       sv.ent, wblk, nblk, win, win2);
+    if ((rc = dev_alloc(idx, &win, (uint64_t)n_recs * (kWinWords + 1) + 16))) return rc;
+    if ((rc = dev_alloc(idx, &win2, (uint64_t)n_recs * kWinWords2 + 16))) return rc;
+    hipLaunchKernelGGL(k_win_fill, dim3((unsigned)(((uint64_t)sv.index_size + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sv.g2,
+                       sv.ent, sv.index_size, bits, rank, n_recs, win, win2);
     WALT_HIP(hipStreamSynchronize(stream));
     WALT_HIP(hipGetLastError());
-    sv.wblk = wblk; sv.win = win; sv.win2 = win2;
+    sv.wbits = bits; sv.wrank = rank; sv.win = win; sv.win2 = win2; sv.wcap = n_recs;
   }
   return WALT_OK;
 }
@@ -925,7 +957,7 @@ uint64_t walt_index_outliers(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->outliers[strand] : 0;
 }
 uint64_t walt_index_window_entries(const walt_index* idx, int strand) {
-  return idx && strand >= 0 && strand < 4 ? 64ull * idx->window_blocks[strand] : 0;
+  return idx && strand >= 0 && strand < 4 ? idx->window_records[strand] : 0;
 }
 
 }  // extern "C"

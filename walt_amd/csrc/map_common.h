@@ -56,13 +56,24 @@ __device__ __forceinline__ bool prefilter_hit(const PreFilter& pf, uint32_t fi, 
   return (pf.bits[fi][h >> 5] >> (h & 31)) & 1u;
 }
 
+// Minimum over the 64 lanes, in every lane.  DPP moves inside the rows of 16 lanes (quad swaps, half-row and row
+// mirrors: a few cycles each) and four readlanes across the rows, instead of six ds_bpermute round trips through
+// the LDS crossbar: the wave-cooperative verification does one of these per 64 candidates, and with three waves per
+// SIMD its dependent chain was a visible part of a step.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    uint32_t o = __shfl_xor(v, off);
-    v = o < v ? o : v;
-  }
-  return v;
+  uint32_t o;
+  o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+  v = o < v ? o : v;
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+  return a < b ? a : b;
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -363,7 +374,7 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
     u = a + n_eq - 1;
     out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
   } else {
-    if (!slot_binary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
+    if (!slot_kary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
   }
   if (n > kKeyChars) {
     const uint32_t size = u - a + 1;
@@ -425,71 +436,101 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const Bloc
 }
 
 // ---- candidates of a wave-cooperative region: G groups of 64 consecutive index slots per step ----
-// Lane `lane` takes slots l + base + 64 u + lane, u < G.  Three rounds of INDEPENDENT loads per step (a
+// Lane `lane` takes slots l + base + 64 u + lane, u < G.  Two rounds of INDEPENDENT loads per step (a
 // listed / owner read has its whole wave to itself, nothing else hides the latency):
-//   1. wblk[slot >> 6] -- does the slot's block have dense candidate windows (core.h StrandView::win)?
-//   2. the dense record {pos, window} (32 contiguous bytes per candidate, 48 for reads above 110 bases), or
-//      the index entry's pos where there is none,
-//   3. for the latter the genome window (one scattered 128-byte line per candidate).
+//   1. the dense record {pos, window} (32 contiguous bytes per candidate, 48 for reads above 110 bases) of the
+//      slots inside the region's dense range (core.h dense_range: four loads per region), or the index
+//      entry's pos where there is none,
+//   2. for the latter the genome window (one scattered 128-byte line per candidate).
 // mm[u] = 0xFFFFFFFF where the slot is beyond the region or fails the edge filters of mapping.cpp:280-286.
 template <int NW>
 __device__ __forceinline__ bool win_usable(const StrandView& sv, uint32_t len) {
-  return NW <= 10 && sv.wblk != nullptr && len <= (NW <= 7 ? kWinMaxLen1 : kWinMaxLen2);
+  return NW <= 10 && sv.wbits != nullptr && len <= (NW <= 7 ? kWinMaxLen1 : kWinMaxLen2);
 }
 template <int NW, int G>
 __device__ __forceinline__ void coop_verify_groups(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
                                                    uint32_t l, uint32_t size, uint32_t base, uint32_t seed_i,
                                                    uint32_t len, const uint32_t* rd, const uint32_t* mk,
-                                                   uint32_t lane, bool dense, uint32_t* gp, uint32_t* mm) {
-  uint32_t wb[G], pos[G];
-  uint32_t win[G][NW <= 10 ? NW + 1 : 1];
+                                                   uint32_t lane, const DenseRange& dr, uint32_t* gp, uint32_t* mm) {
+  const uint32_t top_step = top_step_of(n_chrom);
+  if constexpr (NW <= 10) {
+    // EVERY lane issues EVERY load of a round (a lane without work reads the first words of g2: one broadcast
+    // line).  A load under `if (lane has work)` sits in a divergent branch whose results are copied out before
+    // the branch ends, i.e. the compiler waits for it there -- the G groups then took G round trips, not one.
+    bool dense[G];
+    uint4 ra[G], rc[G], re[G];
+    uint32_t epos[G], pos[G], g[G];
+    bool ok[G];
+    const uint4* const idle = reinterpret_cast<const uint4*>(sv.g2);
 #pragma unroll
-  for (int u = 0; u < G; ++u) {
-    const uint32_t k = base + 64 * u + lane;
-    wb[u] = 0;
-    if (dense && k < size) wb[u] = sv.wblk[(l + k) >> 6];
-  }
+    for (int u = 0; u < G; ++u) {
+      const uint32_t k = base + 64 * u + lane;
+      const uint32_t slot = l + (k < size ? k : size - 1);
+      dense[u] = k < size && slot >= dr.lo && slot < dr.hi;
+      const uint64_t rec = dr.rec + (slot - dr.lo);
+      const uint4* rp = dense[u] ? reinterpret_cast<const uint4*>(sv.win) + 2 * rec : idle;
+      ra[u] = rp[0];
+      rc[u] = rp[1];
+      if constexpr (NW > 7) re[u] = *(dense[u] ? reinterpret_cast<const uint4*>(sv.win2) + rec : idle);
+      const uint32_t* pp = dense[u] ? sv.g2 : &sv.ent[slot].pos;
+      epos[u] = *pp;
+    }
+    bool any_gather = false;
 #pragma unroll
-  for (int u = 0; u < G; ++u) {
-    const uint32_t k = base + 64 * u + lane;
-    pos[u] = 0;
-    if constexpr (NW <= 10) {
+    for (int u = 0; u < G; ++u) {
+      const uint32_t k = base + 64 * u + lane;
+      pos[u] = dense[u] ? ra[u].x : epos[u];
+      const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos[u]);  // fixed trip count: the G chains interleave
+      const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+      g[u] = pos[u] - seed_i;
+      ok[u] = k < size && (pos[u] - c_lo >= seed_i) && (g[u] + len < c_hi);  // mapping.cpp:280-286
+      gp[u] = ok[u] ? g[u] : 0u;
+      any_gather = any_gather || (ok[u] && !dense[u]);
+    }
+    uint32_t gw[G][NW + 1];
 #pragma unroll
-      for (int w = 0; w <= NW; ++w) win[u][w] = 0;
-      if (wb[u]) {
-        const uint64_t rec = (uint64_t)(wb[u] - 1) * 64 + ((l + k) & 63u);
-        const uint4 a = reinterpret_cast<const uint4*>(sv.win)[2 * rec], c = reinterpret_cast<const uint4*>(sv.win)[2 * rec + 1];
-        pos[u] = a.x;
-        const uint32_t first[7] = {a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    for (int u = 0; u < G; ++u)
 #pragma unroll
-        for (int w = 0; w < 7 && w <= NW; ++w) win[u][w] = first[w];
-        if constexpr (NW > 7) {
-          const uint4 e = reinterpret_cast<const uint4*>(sv.win2)[rec];
-          const uint32_t more[4] = {e.x, e.y, e.z, e.w};
+      for (int w = 0; w <= NW; ++w) gw[u][w] = 0;
+    if (__ballot(any_gather)) {  // wave-uniform: a step inside the dense range has no second round
 #pragma unroll
-          for (int w = 7; w <= NW; ++w) win[u][w] = more[w - 7];
+      for (int u = 0; u < G; ++u) {
+        const uint32_t* gwp = (ok[u] && !dense[u]) ? sv.g2 + (g[u] >> 4) : sv.g2;
+#pragma unroll
+        for (int w = 0; w <= NW; w += 4) {
+          constexpr int kAll = NW + 1;
+          const int cnt = kAll - w < 4 ? kAll - w : 4;
+          uint32_t q[4] = {0, 0, 0, 0};
+          __builtin_memcpy(q, gwp + w, 4 * cnt);
+#pragma unroll
+          for (int t = 0; t < cnt; ++t) gw[u][w + t] = q[t];
         }
       }
     }
-    if (!wb[u] && k < size) pos[u] = sv.ent[l + k].pos;
-  }
 #pragma unroll
-  for (int u = 0; u < G; ++u) {
-    const uint32_t k = base + 64 * u + lane;
-    const uint32_t chr = chrom_id(si, n_chrom, pos[u]);
-    const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
-    const uint32_t g = pos[u] - seed_i;
-    const bool ok = k < size && (pos[u] - c_lo >= seed_i) && (g + len < c_hi);
-    gp[u] = ok ? g : 0u;
-    uint32_t m = 0xFFFFFFFFu;
-    if (ok) {
-      if constexpr (NW <= 10) {
-        m = wb[u] ? count_mismatch_regs<NW>(win[u], 2 * (kWinLead - seed_i), rd, mk) : count_mismatch<NW>(sv.g2, g, rd, mk);
-      } else {
-        m = count_mismatch<NW>(sv.g2, g, rd, mk);
-      }
+    for (int u = 0; u < G; ++u) {
+      uint32_t wv[NW + 1];
+      const uint32_t first[11] = {ra[u].y, ra[u].z, ra[u].w, rc[u].x, rc[u].y, rc[u].z, rc[u].w,
+                                  NW > 7 ? re[u].x : 0u, NW > 7 ? re[u].y : 0u, NW > 7 ? re[u].z : 0u, NW > 7 ? re[u].w : 0u};
+#pragma unroll
+      for (int w = 0; w <= NW; ++w) wv[w] = dense[u] ? (w < 11 ? first[w] : 0u) : gw[u][w];
+      const uint32_t shv = dense[u] ? 2 * (kWinLead - seed_i) : 2 * (g[u] & 15u);
+      const uint32_t m = count_mismatch_regs<NW>(wv, shv, rd, mk);
+      mm[u] = ok[u] ? m : 0xFFFFFFFFu;
     }
-    mm[u] = m;
+  } else {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const uint32_t k = base + 64 * u + lane;
+      const uint32_t pos = sv.ent[l + (k < size ? k : size - 1)].pos;
+      const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos);
+      const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+      const uint32_t g = pos - seed_i;
+      const bool ok = k < size && (pos - c_lo >= seed_i) && (g + len < c_hi);
+      gp[u] = ok ? g : 0u;
+      mm[u] = 0xFFFFFFFFu;
+      if (ok) mm[u] = count_mismatch<NW>(sv.g2, g, rd, mk);
+    }
   }
 }
 

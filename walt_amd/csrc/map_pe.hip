@@ -148,10 +148,10 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         // kCoopUnroll x 64 candidates per step: the slot loads of a step are independent, then the genome
         // windows are, so a step costs two memory round trips instead of 2 x kCoopUnroll (a listed read
         // owns its wave, nothing else hides the latency); pushes stay in slot order.
-        const bool dense = win_usable<NW>(sv, o_len);
+        const DenseRange rb = dense_range(sv, o_l, o_size, win_usable<NW>(sv, o_len));
         for (uint32_t base = 0; base < o_size; base += 64 * kCoopUnroll) {
           uint32_t cgp[kCoopUnroll], cmm[kCoopUnroll];
-          coop_verify_groups<NW, (int)kCoopUnroll>(sv, si, n_chrom, o_l, o_size, base, seed_i, o_len, o_rd, o_mk, lane, dense,
+          coop_verify_groups<NW, (int)kCoopUnroll>(sv, si, n_chrom, o_l, o_size, base, seed_i, o_len, o_rd, o_mk, lane, rb,
                                                    cgp, cmm);  // paired.cpp:166-190
 #pragma unroll
           for (uint32_t u = 0; u < kCoopUnroll; ++u) n_verified += cmm[u] != 0xFFFFFFFFu ? 1u : 0u;

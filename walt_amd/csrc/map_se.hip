@@ -69,19 +69,34 @@ void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uin
 // All 64 lanes call this with the same (uniform) arguments broadcast from the
 // owner.  Returns the RegionSummary of the region in candidate order.
 // ---------------------------------------------------------------------------
-constexpr int kCoopGroupsSe = 1;  // 128 candidates per step (map_common.h coop_verify_groups)
+constexpr int kCoopGroupsSe = 2;  // 128 candidates per step (map_common.h coop_verify_groups)
 template <int NW>
 __device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
                                                      uint32_t l, uint32_t size, uint32_t seed_i, uint32_t len,
                                                      const uint32_t* rd, const uint32_t* mk, uint32_t lane,
-                                                     uint32_t& n_verified) {
+                                                     uint32_t& n_verified, const DenseRange* known = nullptr,
+                                                     uint32_t abl = 0) {
   RegionSummary acc = summary_empty();
-  const bool dense = win_usable<NW>(sv, len);
+  if (abl & 16u) return acc;  // diagnostic (WALT_AMD_ABLATE, results invalid): no cooperative verification at all
+  const DenseRange rb = known ? *known : dense_range(sv, l, size, win_usable<NW>(sv, len));
   for (uint32_t base = 0; base < size; base += 64 * kCoopGroupsSe) {
     uint32_t gp[kCoopGroupsSe], mm[kCoopGroupsSe];
-    coop_verify_groups<NW, kCoopGroupsSe>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, dense, gp, mm);
+    if (abl & 64u) {  // diagnostic: no loads
+#pragma unroll
+      for (int u = 0; u < kCoopGroupsSe; ++u) { gp[u] = base + lane; mm[u] = (base + 64 * u + lane) < size ? (lane & 7u) : 0xFFFFFFFFu; }
+    } else {
+      coop_verify_groups<NW, kCoopGroupsSe>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, rb, gp, mm);
+    }
+    if (abl & 32u) {  // diagnostic: loads and counts, no reduction
+      uint32_t x = 0;
+#pragma unroll
+      for (int u = 0; u < kCoopGroupsSe; ++u) x += mm[u] + gp[u];
+      acc.first += x;
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < kCoopGroupsSe; ++u) {
+      if (base + 64 * u >= size) break;
       n_verified += mm[u] != 0xFFFFFFFFu ? 1u : 0u;
       const uint32_t mn = wave_min_u32(mm[u]);
       if (mn != 0xFFFFFFFFu) {
@@ -286,18 +301,28 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 // ---------------------------------------------------------------------------
 // SlotProbe / probe_issue / probe_entries / probe_resolve / verify_nobranch live in map_common.h (shared with map_pe.hip)
 
-template <int NW, bool DIAG>
+constexpr uint32_t kMidRegion = 16;  // heavy pass: regions up to this size are verified by their own lane, in batches
+// HEAVY = false (pass 1, every read): a lane that meets heavy work -- a directory slot of more than kScanMax
+// entries (k-ary search) or a region of more than kSmallRegion candidates (wave-cooperative verification) --
+// stops and appends its read to the heavy list instead of making its 63 wave-mates wait: on an hg19-like
+// genome a tenth of the reads is like that, so nearly every wavefront held some, and the phase stamps showed
+// 37 % of the kernel in slot searches and 50 % in cooperative regions.  HEAVY = true (pass 1b, the heavy
+// list): the same code with those paths enabled; every lane of such a wave has heavy work.
+template <int NW, bool DIAG, bool HEAVY>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
                                                 const uint32_t* __restrict__ codes2, uint64_t o_first,
                                                 uint64_t o_read, uint64_t oe_read, uint32_t* __restrict__ err,
                                                 uint32_t r,
                                                 bool valid, uint32_t strand_base, uint32_t max_mm, uint32_t b,
                                                 BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
-                                                uint32_t* __restrict__ defer_list, MapCounters& ctr,
+                                                uint32_t* __restrict__ defer_list, uint32_t* __restrict__ heavy_count,
+                                                uint32_t* __restrict__ heavy_list, MapCounters& ctr_out,
                                                 uint32_t& len_out, uint32_t ablate_rt, StampsT<DIAG>& st) {
   const uint32_t ablate = DIAG ? ablate_rt : 0u;
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t top_step = top_step_of(n_chrom);
+  MapCounters ctr = {0, 0, 0};  // this read's work; counted once, by the pass that completes the read
+  bool heavy = false;
   const uint32_t lane = threadIdx.x & 63;
   const StrandView& svp = iv.s[strand_base];
   const StrandView& svm = iv.s[strand_base + 1];
@@ -356,6 +381,12 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     pp.ne = (need_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
     pm.ne = (need_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
     if (ablate & 2u) pp.ne = pm.ne = 0;
+    if (!HEAVY && (pp.ne > kScanMax || pm.ne > kScanMax)) {  // a long slot: the heavy pass searches it
+      heavy = true;
+      mappable = false;
+      need_p = need_m = false;
+      pp.ne = pm.ne = 0;
+    }
     probe_entries(svp, pp);
     probe_entries(svm, pm);
     Lookup lp, lm;
@@ -370,6 +401,11 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     if (size_p > b) size_p = 0;  // mapping.cpp:275-277
     if (size_m > b) size_m = 0;
     if (ablate & 1u) size_p = size_m = 0;
+    if (!HEAVY && (size_p > kSmallRegion || size_m > kSmallRegion)) {  // a large region: the heavy pass verifies it
+      heavy = true;
+      mappable = false;
+      size_p = size_m = 0;
+    }
     uint32_t mk[NW];
     make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
     stamp(st, 4);
@@ -401,13 +437,79 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       }
     }
     stamp(st, 5);
-    // large regions: the whole wave verifies one owner's region at a time ('+' then '-')
+    if constexpr (HEAVY) {
+    // In a heavy wave nearly every lane owns a region of more than kSmallRegion candidates, and taking the owners
+    // one at a time costs each of them three dependent round trips however small its region is (with ~70 such
+    // regions per 64 reads that was 20 of the heavy pass's 53 ms).  So:
+    //  * a lane with a large region fetches its dense range now (two loads, all lanes together);
+    //  * regions of up to kMidRegion candidates stay with their lane: all positions in one round of loads, then
+    //    the genome windows four at a time -- five round trips for ALL such lanes of the wave;
+    //  * only the larger ones take the whole wavefront.
+    DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, size_p > kMidRegion && win_usable<NW>(svp, lr.len));
+    DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, size_m > kMidRegion && win_usable<NW>(svm, lr.len));
 #pragma unroll 1
     for (uint32_t fi = 0; fi < 2; ++fi) {
       const StrandView& sv = fi ? svm : svp;
       const uint32_t my_size = fi ? size_m : size_p;
       const uint32_t my_l = fi ? lm.reg.l : lp.reg.l;
-      unsigned long long big = __ballot(my_size > kSmallRegion);
+      const uint32_t nmid = (my_size > kSmallRegion && my_size <= kMidRegion) ? my_size : 0u;
+      if (__ballot(nmid != 0)) {
+        uint32_t posb[kMidRegion];
+#pragma unroll
+        for (uint32_t k = 0; k < kMidRegion; ++k) {
+          posb[k] = 0;
+          if (k < nmid) posb[k] = sv.ent[my_l + k].pos;
+        }
+        RegionSummary acc = summary_empty();
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < kMidRegion; k0 += 4) {
+          if (!__ballot(k0 < nmid)) break;
+          bool ok[4];
+          uint32_t gpv[4], win[4][NW + 1];
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            // posb[k0 + j] by selects (k0 is not a compile-time constant: indexing would go to scratch)
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t k = j; k < kMidRegion; k += 4) pos = (k == k0 + j) ? posb[k] : pos;
+            uint32_t c_lo, c_hi;
+            if (n_chrom <= kLdsChroms) {
+              const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, pos);
+              c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
+            } else {
+              const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos);
+              c_lo = si[chr]; c_hi = si[chr + 1];
+            }
+            const uint32_t g = pos - seed_i;
+            ok[j] = k0 + j < nmid && (pos - c_lo >= seed_i) && (g + lr.len < c_hi);  // mapping.cpp:280-286
+            gpv[j] = ok[j] ? g : 0u;
+#pragma unroll
+            for (int w = 0; w <= NW; ++w) win[j][w] = 0;
+            if (ok[j]) {
+              const uint32_t* gw = sv.g2 + (g >> 4);
+#pragma unroll
+              for (int w = 0; w <= NW; w += 4) {
+                constexpr int kAll = NW + 1;
+                const int cnt = kAll - w < 4 ? kAll - w : 4;
+                uint32_t q[4] = {0, 0, 0, 0};
+                __builtin_memcpy(q, gw + w, 4 * cnt);
+#pragma unroll
+                for (int t = 0; t < cnt; ++t) win[j][w + t] = q[t];
+              }
+            }
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            if (ok[j]) {
+              const uint32_t mm = count_mismatch_regs<NW>(win[j], 2 * (gpv[j] & 15u), lr.rd, mk);
+              acc = summary_merge(acc, summary_one(mm, gpv[j]));
+              ++ctr.verified;
+            }
+          }
+        }
+        if (nmid) { if (fi) sum_m = acc; else sum_p = acc; }
+      }
+      unsigned long long big = __ballot(my_size > kMidRegion);
       while (big) {
         const int owner = (int)__ffsll((long long)big) - 1;
         big &= big - 1;
@@ -418,14 +520,19 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
           o_mk[w] = bcast(mk[w], owner);
         }
         const uint32_t o_l = bcast(my_l, owner), o_size = bcast(my_size, owner), o_len = bcast(lr.len, owner);
+        DenseRange o_dr;
+        o_dr.lo = bcast(fi ? dr_m.lo : dr_p.lo, owner);
+        o_dr.hi = bcast(fi ? dr_m.hi : dr_p.hi, owner);
+        o_dr.rec = bcast((uint32_t)(fi ? dr_m.rec : dr_p.rec), owner);  // record numbers stay below 2^32 (build_windows)
         uint32_t nv = 0;
-        RegionSummary s = coop_region<NW>(sv, si, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv);
-        ctr.verified += nv;
+        RegionSummary s = coop_region<NW>(sv, si, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv, &o_dr, ablate);
+        ctr_out.verified += nv;  // candidates of the OWNER's region that this lane verified
         if ((int)lane == owner) {
           if (fi) sum_m = s; else sum_p = s;
           ++ctr.big;
         }
       }
+    }
     }
     stamp(st, 6);
     fold_region(best, sum_p, '+');  // empty when the '+' probe was not needed
@@ -439,7 +546,9 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     if (best.mismatch > 1) fold_region(best, m2, '-');
   }
   wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, defer_count, defer_list);
-  if (!deferred && valid) out[r] = best;
+  if constexpr (!HEAVY) wave_append(heavy && !deferred, r, heavy_count, heavy_list);
+  if (!deferred && !heavy && valid) out[r] = best;
+  if (!deferred && !heavy) { ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big; }
   stamp(st, 7);
 }
 
@@ -543,19 +652,23 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 }
 
 #if WALT_SEEDPATTERN == 3
-// pass 1: every read of the batch, one per lane
-template <int NW, bool DIAG>
-__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
+// pass 1: every read of the batch, one per lane (HEAVY = false); pass 1b: the reads of the heavy list (HEAVY = true)
+template <int NW, bool DIAG, bool HEAVY>
+__global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
                                                     const uint64_t* __restrict__ offsets,
                                                     uint32_t* __restrict__ err,
-                                                    uint32_t n, uint32_t strand_base,
+                                                    uint32_t n_all, uint32_t strand_base,
                                                     uint32_t max_mm, uint32_t b,
                                                     const uint32_t* __restrict__ mask_table,
                                                     BestMatch* __restrict__ out,
                                                     unsigned long long* __restrict__ stats,
                                                     uint32_t* __restrict__ defer_count,
-                                                    uint32_t* __restrict__ defer_list, uint32_t ablate,
+                                                    uint32_t* __restrict__ defer_list,
+                                                    uint32_t* __restrict__ heavy_count,
+                                                    uint32_t* __restrict__ heavy_list, uint32_t ablate,
                                                     unsigned long long* __restrict__ stamps) {
+  const uint32_t n = HEAVY ? *heavy_count : n_all;
+  if (HEAVY && n == 0) return;
   __shared__ BlockShared sh;
   __shared__ PreFilter pf;
   prefilter_stage(pf, iv, strand_base);
@@ -575,24 +688,24 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   const uint64_t o_first = offsets[0];
   // this lane's read offsets are fetched one chunk ahead
   uint64_t o_nx = 0, oe_nx = 0;
-  if (c_lo < c_hi && c_lo * blockDim.x + threadIdx.x < n) {
-    o_nx = offsets[c_lo * blockDim.x + threadIdx.x];
-    oe_nx = offsets[c_lo * blockDim.x + threadIdx.x + 1];
-  }
+  uint32_t r_nx = 0;
+  auto fetch = [&](uint64_t i) {
+    r_nx = HEAVY ? heavy_list[i] : (uint32_t)i;
+    o_nx = offsets[r_nx];
+    oe_nx = offsets[(uint64_t)r_nx + 1];
+  };
+  if (c_lo < c_hi && c_lo * blockDim.x + threadIdx.x < n) fetch(c_lo * blockDim.x + threadIdx.x);
   for (uint64_t c = c_lo; c < c_hi; ++c) {
-    const uint64_t r64 = c * blockDim.x + threadIdx.x;
-    const bool valid = r64 < n;
-    const uint32_t r = valid ? (uint32_t)r64 : 0;
+    const uint64_t i64 = c * blockDim.x + threadIdx.x;
+    const bool valid = i64 < n;
+    const uint32_t r = valid ? r_nx : 0;
     const uint64_t o_cur = o_nx, oe_cur = oe_nx;
-    if (c + 1 < c_hi && r64 + blockDim.x < n) {
-      o_nx = offsets[r64 + blockDim.x];
-      oe_nx = offsets[r64 + blockDim.x + 1];
-    }
+    if (c + 1 < c_hi && i64 + blockDim.x < n) fetch(i64 + blockDim.x);
     uint32_t len;
-    se_process_dual<NW, DIAG>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
-                              out, defer_count, defer_list, ctr, len, ablate, st);
-    // too_short is counted once per strand pass (mapping.cpp:230-233)
-    shortv += (valid && len < kMinReadLen) ? 2u : 0u;
+    se_process_dual<NW, DIAG, HEAVY>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
+                                     out, defer_count, defer_list, heavy_count, heavy_list, ctr, len, ablate, st);
+    // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 sees every read
+    if (!HEAVY) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
   stamp_end(st);
   flush_counters(ctr, shortv, stats);
@@ -648,6 +761,14 @@ static uint32_t g_ablate = 0;
 static unsigned long long* g_stamps = nullptr;  // WALT_AMD_STAMPS=1: device buffer of kStampPhases sums (diagnostic)
 constexpr unsigned kLiteralGrid = 1024;  // blocks of the deferred-read pass (grid-stride)
 
+// WALT_AMD_SYNC_DEBUG=1 (diagnostic): wait after every launch of the single-end path and say which one returned
+static void debug_sync(const char* what, hipStream_t stream) {
+  static const bool on = getenv("WALT_AMD_SYNC_DEBUG") != nullptr;
+  if (!on) return;
+  const hipError_t e = hipStreamSynchronize(stream);
+  fprintf(stderr, "[walt_amd sync] %s: %s\n", what, hipGetErrorString(e));
+}
+
 template <int NW>
 static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
                          uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
@@ -669,19 +790,38 @@ static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const ui
   if (const char* e = getenv("WALT_AMD_GRID")) pg = atoi(e) > 0 ? (unsigned)atoi(e) : grid_for(n);  // diagnostic knob
   const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
   const bool diag = g_ablate != 0 || g_stamps != nullptr;  // diagnostic instantiation (stamps / ablation)
-  if (diag)
-    hipLaunchKernelGGL((k_map_se<NW, true>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
-                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, g_ablate,
-                       g_stamps);
+  uint32_t* heavy_count = defer_count + 24;   // control block word (zeroed with it)
+  uint32_t* heavy_list = defer_list + 2 * stride;
+  // WALT_AMD_STAMPS=2: phase stamps of the heavy pass only, 3: of pass 1 only (1: both, summed)
+  const char* sm = getenv("WALT_AMD_STAMPS");
+  const int stamp_mode = sm ? atoi(sm) : 0;
+  const bool diag1 = diag && stamp_mode != 2, diag2 = diag && stamp_mode != 3;
+  if (diag1)
+    hipLaunchKernelGGL((k_map_se<NW, true, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                       heavy_list, g_ablate, g_stamps);
   else
-    hipLaunchKernelGGL((k_map_se<NW, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
-                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, nullptr);
+    hipLaunchKernelGGL((k_map_se<NW, false, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                       heavy_list, 0u, nullptr);
+  debug_sync("pass 1", stream);
+  if (diag2)
+    hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                       heavy_list, g_ablate, g_stamps);
+  else
+    hipLaunchKernelGGL((k_map_se<NW, false, true>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                       heavy_list, 0u, nullptr);
+  debug_sync("heavy pass", stream);
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
+  debug_sync("bin", stream);
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
   hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted, 0u);
+  debug_sync("literal pass", stream);
   return WALT_OK;
 #endif
 }
@@ -698,8 +838,8 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   {
     const char* ab = getenv("WALT_AMD_ABLATE");
     g_ablate = ab ? (uint32_t)atoi(ab) : 0u;
-    if (g_ablate & 7u) fprintf(stderr, "[walt_amd] WALT_AMD_ABLATE=%u: DIAGNOSTIC RUN, mapping results are not valid\n", g_ablate);
-    if (getenv("WALT_AMD_STAMPS") && !g_stamps) {
+    if (g_ablate & ~8u) fprintf(stderr, "[walt_amd] WALT_AMD_ABLATE=%u: DIAGNOSTIC RUN, mapping results are not valid\n", g_ablate);
+    if ((getenv("WALT_AMD_STAMPS") || g_ablate) && !g_stamps) {  // the diagnostic kernels always write their stamps
       WALT_HIP(hipMalloc(reinterpret_cast<void**>(&g_stamps), 16 * sizeof(unsigned long long)));
       WALT_HIP(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
     }
@@ -712,12 +852,12 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   WALT_HIP(hipSetDevice(idx->device));
   const uint64_t stride = se_stride(n);
   // workspace: [64 words: read errors, deferral control] [statistic shards] [deferred list] [sorted deferred
-  // list] [dense 2-bit reads]
+  // list] [heavy list] [dense 2-bit reads]
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   unsigned long long* shards = reinterpret_cast<unsigned long long*>(err + 64);
   uint32_t* defer_count = err + 32;  // control block: [0] count, [8..15] bin counts, [16..23] bin cursors
   uint32_t* defer_list = err + 64 + kStatShardBytes / 4;
-  uint32_t* codes2 = defer_list + 2 * stride;
+  uint32_t* codes2 = defer_list + 3 * stride;  // deferred list, its sorted copy, heavy list
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
   const uint8_t* bases = reinterpret_cast<const uint8_t*>(d_bases);
   const uint64_t* offsets = reinterpret_cast<const uint64_t*>(d_offsets);
@@ -804,7 +944,7 @@ size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
   (void)nw;
-  return 64 * sizeof(uint32_t) + kStatShardBytes + 2 * se_stride(n) * sizeof(uint32_t) +
+  return 64 * sizeof(uint32_t) + kStatShardBytes + 3 * se_stride(n) * sizeof(uint32_t) +
          codes2_words((uint64_t)n * max_read_len) * sizeof(uint32_t);
 }
 
