@@ -158,7 +158,9 @@ int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d
 /* The device-resident calls are asynchronous, so invalid input cannot come back as their status.
  * walt_batch_check waits for `stream` and reports what the last call on `d_workspace` found:
  * WALT_EBASE (a read holds a non-ACGT base: the reference's getBits exits, util.hpp:117-119; its
- * record is left as initialised), WALT_EINVAL (a read longer than max_read_len), else WALT_OK.
+ * record is left as initialised), WALT_EINVAL (a read longer than max_read_len, or a batch of more than
+ * n x max_read_len bases -- the workspace is sized by that product: such reads are refused in the kernels, never
+ * converted or read beyond the workspace, their records left as initialised), else WALT_OK.
  * The host-buffer calls do this themselves. */
 int walt_batch_check(const void* d_workspace, void* stream);
 
@@ -174,6 +176,8 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
                       walt_pair_result* out, walt_candidate* ranked1, uint32_t* ranked_n1,
                       walt_candidate* ranked2, uint32_t* ranked_n2, walt_batch_stats* stats /*[2]*/);
 
+/* One paired-end call at a time per walt_index: the call's internal streams and events (mate 2 runs beside mate 1,
+ * passes alternate between two pipeline slots) belong to the index.  Different indexes (devices) are independent. */
 size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k);
 int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* d_offsets1,
                              const void* d_bases2, const void* d_offsets2, uint32_t n,

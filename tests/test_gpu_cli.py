@@ -136,21 +136,24 @@ def _swap_mapstats_mates(text):
     return "\n".join(lines[:i1] + ["mate1:"] + lines[i2 + 1:i3] + ["mate2:"] + lines[i1 + 1:i2] + lines[i3:])
 
 
-def test_cli_pbat_is_the_mate_swapped_run_put_back_in_user_order(cli_index, scratch):
+@pytest.mark.parametrize("kind,sam_case,mr_case,extra", [("pe", "pe_sam_au", "pe_mr_au", []),
+                                                         ("pe150", "pe150_sam_au_m10", "pe150_mr_au_m10", ["-m", "10"])])
+def test_cli_pbat_is_the_mate_swapped_run_put_back_in_user_order(cli_index, scratch, kind, sam_case, mr_case, extra):
     """-P has no implementation in the reference snapshot (parity unpinned).  It is defined by
     equivalence: `-P -1 X -2 Y` maps like `-1 Y -2 X`, then restores the user's order: X's record first,
     0x40 on X / 0x80 on Y, QNAME from X, _1 side files and the mate1 mapstats block for X.  So with
-    X = pe_2.fastq, Y = pe_1.fastq the expected files are a rewrite of the golden pe_1/pe_2 outputs."""
-    p1, p2 = os.path.join(refio.GOLDEN, "pe_1.fastq"), os.path.join(refio.GOLDEN, "pe_2.fastq")
+    X = pe_2.fastq, Y = pe_1.fastq the expected files are a rewrite of the golden pe_1/pe_2 outputs.
+    The second parameter set is BASELINE configs[4]: 2 x 150 bp, -m 10, PBAT."""
+    p1, p2 = os.path.join(refio.GOLDEN, kind + "_1.fastq"), os.path.join(refio.GOLDEN, kind + "_2.fastq")
 
     def qname(n):  # golden runs print pe_1's names ("…/1"); the PBAT run prints its own -1 file's ("…/2")
         assert n.endswith("/1")
         return n[:-1] + "2"
 
     # SAM
-    got = _run_cli(os.path.join(scratch, "pbat_sam"), ["-i", cli_index, "-o", "out.sam", "-P", "-1", p2, "-2", p1,
-                                                      "-sam", "-a", "-u"])
-    want_lines = refio.golden_file("pe_sam_au", "out.sam").splitlines()
+    got = _run_cli(os.path.join(scratch, "pbat_sam_" + kind), ["-i", cli_index, "-o", "out.sam", "-P", "-1", p2, "-2", p1,
+                                                              "-sam", "-a", "-u"] + extra)
+    want_lines = refio.golden_file(sam_case, "out.sam").splitlines()
     head = [ln for ln in want_lines if ln.startswith("@")]
     body = [ln for ln in want_lines if not ln.startswith("@")]
     assert len(body) % 2 == 0
@@ -162,33 +165,35 @@ def test_cli_pbat_is_the_mate_swapped_run_put_back_in_user_order(cli_index, scra
         fa[0], fb[0] = qname(fa[0]), qname(fb[0])
         exp += ["\t".join(fb), "\t".join(fa)]
     assert got["out.sam"].splitlines() == exp
-    assert got["out.sam.mapstats"] == _swap_mapstats_mates(refio.golden_file("pe_sam_au", "out.sam.mapstats"))
+    assert got["out.sam.mapstats"] == _swap_mapstats_mates(refio.golden_file(sam_case, "out.sam.mapstats"))
 
     # MR with side files
-    got = _run_cli(os.path.join(scratch, "pbat_mr"), ["-i", cli_index, "-o", "out.mr", "-P", "-1", p2, "-2", p1, "-a", "-u"])
+    got = _run_cli(os.path.join(scratch, "pbat_mr_" + kind), ["-i", cli_index, "-o", "out.mr", "-P", "-1", p2, "-2", p1, "-a", "-u"] + extra)
 
     def rename(line, col):
         f = line.split("\t")
         f[col] = ("FRAG:" + qname(f[col][5:])) if f[col].startswith("FRAG:") else qname(f[col])
         return "\t".join(f)
 
-    want_main = [rename(ln, 3) for ln in refio.golden_file("pe_mr_au", "out.mr").splitlines()]
+    want_main = [rename(ln, 3) for ln in refio.golden_file(mr_case, "out.mr").splitlines()]
     got_main = got["out.mr"].splitlines()
     frag = lambda ls: [ln for ln in ls if "\tFRAG:" in ln]
     single = lambda ls: sorted(ln for ln in ls if "\tFRAG:" not in ln)
     assert frag(got_main) == frag(want_main) and single(got_main) == single(want_main)
     assert len(frag(got_main)) > 100
     for mine, theirs in (("1", "2"), ("2", "1")):
-        for kind, col in (("ambiguous", 3), ("unmapped", 0)):
-            want = [rename(ln, col) for ln in refio.golden_file("pe_mr_au", "out.mr_%s_%s" % (theirs, kind)).splitlines()]
-            assert got["out.mr_%s_%s" % (mine, kind)].splitlines() == want, (mine, kind)
-    assert got["out.mr.mapstats"] == _swap_mapstats_mates(refio.golden_file("pe_mr_au", "out.mr.mapstats"))
+        for side, col in (("ambiguous", 3), ("unmapped", 0)):
+            want = [rename(ln, col) for ln in refio.golden_file(mr_case, "out.mr_%s_%s" % (theirs, side)).splitlines()]
+            assert got["out.mr_%s_%s" % (mine, side)].splitlines() == want, (mine, side)
+    assert got["out.mr.mapstats"] == _swap_mapstats_mates(refio.golden_file(mr_case, "out.mr.mapstats"))
 
     # single-end: -P is -A
-    ga = os.path.join(refio.GOLDEN, "se_ga.fastq")
-    a = _run_cli(os.path.join(scratch, "pbat_se_a"), ["-i", cli_index, "-o", "o.sam", "-A", "-r", ga, "-sam", "-a", "-u"])
-    b = _run_cli(os.path.join(scratch, "pbat_se_p"), ["-i", cli_index, "-o", "o.sam", "-P", "-r", ga, "-sam", "-a", "-u"])
+    ga = os.path.join(refio.GOLDEN, "se150_ga.fastq" if kind == "pe150" else "se_ga.fastq")
+    a = _run_cli(os.path.join(scratch, "pbat_se_a"), ["-i", cli_index, "-o", "o.sam", "-A", "-r", ga, "-sam", "-a", "-u"] + extra)
+    b = _run_cli(os.path.join(scratch, "pbat_se_p"), ["-i", cli_index, "-o", "o.sam", "-P", "-r", ga, "-sam", "-a", "-u"] + extra)
     assert a == b and len(a["o.sam"]) > 1000
+    if kind == "pe150":  # and that is the reference's own -A output for configs[4]'s single-end half
+        assert a["o.sam"] == refio.golden_file("se150_ag_sam_au_m10", "out.sam")
 
 
 def test_cli_makedb_on_gpu_writes_files_the_reference_binary_maps_from(scratch):

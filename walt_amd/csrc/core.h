@@ -189,7 +189,8 @@ struct IndexView {
   uint32_t n_chrom;
   uint32_t dir_bits;             // Bd: directory prefix length in code bits
   uint32_t dir_slots;            // S = 2^Bd modulo 2^32 (0 when Bd == 32; see dir_top)
-  uint32_t pad_;
+  uint32_t batch_max_len;        // per launch (the host fills its copy): the caller's max_read_len, and the bytes the
+  uint64_t batch_cap_bytes;      // dense 2-bit read array has room for; a read beyond either is refused, not read
 };
 
 // BestMatch, mapping.hpp:39-52.  Same 16-byte layout.

@@ -273,7 +273,12 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   if ((rc = dev_alloc(idx, &bad, kNumBuckets / 32))) return rc;
   if ((rc = dev_alloc(idx, &dir, (uint64_t)slots + 1))) return rc;
   if ((rc = dev_alloc(idx, &ent, (uint64_t)index_size + 1))) return rc;
-  WALT_HIP(hipMalloc(reinterpret_cast<void**>(&err), 4 * sizeof(uint32_t)));
+  struct Scoped {  // temporaries of this function: freed on every return path
+    void* p = nullptr;
+    ~Scoped() { if (p) hipFree(p); }
+  } err_buf, tmp_buf, cnt_buf;
+  WALT_HIP(hipMalloc(&err_buf.p, 4 * sizeof(uint32_t)));
+  err = reinterpret_cast<uint32_t*>(err_buf.p);
   WALT_HIP(hipMemsetAsync(err, 0, 4 * sizeof(uint32_t), stream));
   WALT_HIP(hipMemsetAsync(bad, 0, kNumBuckets / 8, stream));
   WALT_HIP(hipMemcpyAsync(cnt, d_counter, ((uint64_t)kNumBuckets + 1) * 4, hipMemcpyDeviceToDevice, stream));
@@ -289,7 +294,6 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipStreamSynchronize(stream));
   if (herr[1]) {
-    hipFree(err);
     return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[1]) +
                                   " index positions beyond the genome");
   }
@@ -312,8 +316,8 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     size_t tmp_bytes = 0;
     WALT_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, dir, dir, (size_t)(total < piece ? total : piece),
                                      rocprim::minimum<uint32_t>(), stream));
-    void* tmp = nullptr;
-    WALT_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    WALT_HIP(hipMalloc(&tmp_buf.p, tmp_bytes ? tmp_bytes : 16));
+    void* tmp = tmp_buf.p;
     hipError_t se = hipSuccess;
     for (uint64_t at = 0; at < total && se == hipSuccess; at += piece) {
       const uint64_t cnt = total - at < piece ? total - at : piece;
@@ -322,7 +326,6 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       se = rocprim::inclusive_scan(tmp, tb, dir + at, dir + at, (size_t)cnt, rocprim::minimum<uint32_t>(), stream);
     }
     hipError_t sy = hipStreamSynchronize(stream);
-    hipFree(tmp);
     WALT_HIP(se);
     WALT_HIP(sy);
   }
@@ -346,8 +349,8 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       WALT_HIP(hipGetLastError());
     }
   }
-  unsigned long long* d_cnt64 = nullptr;
-  WALT_HIP(hipMalloc(reinterpret_cast<void**>(&d_cnt64), sizeof(unsigned long long)));
+  WALT_HIP(hipMalloc(&cnt_buf.p, sizeof(unsigned long long)));
+  unsigned long long* d_cnt64 = reinterpret_cast<unsigned long long*>(cnt_buf.p);
   WALT_HIP(hipMemsetAsync(d_cnt64, 0, sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(k_popcount, dim3(grid_for(kNumBuckets / 32)), dim3(kBlock), 0, stream, bad, kNumBuckets / 32,
                      d_cnt64);
@@ -356,8 +359,6 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipStreamSynchronize(stream));
   WALT_HIP(hipGetLastError());
-  hipFree(d_cnt64);
-  hipFree(err);
   if (herr[2])
     return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[2]) +
                                   " index entries are not in the bucket of their hash");
@@ -898,7 +899,8 @@ int walt_index_from_host(uint32_t n_chrom, const uint32_t* chrom_len, const char
     head.names.push_back(chrom_names && chrom_names[i] ? chrom_names[i] : ("chr" + std::to_string(i)));
     total += chrom_len[i];
   }
-  if (total >= (1ull << 32)) return fail(WALT_EINVAL, "genome longer than 2^32 bases");
+  // positions and position + read length are 32-bit (like the reference's uint32_t); 0xFFFFFFFF marks a slot-table record
+  if (total >= (1ull << 32) - 256) return fail(WALT_EINVAL, "genome longer than 2^32 - 256 bases");
   head.genome_len = (uint32_t)total;
   for (int s = 0; s < 4; ++s)
     if (genome[s] && index_size[s] > head.max_index_size) head.max_index_size = index_size[s];

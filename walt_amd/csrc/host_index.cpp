@@ -120,6 +120,8 @@ int read_index_head(const std::string& path, IndexHead& head) {  // reference.cp
   uint64_t sum = 0;
   for (uint32_t l : head.lengths) sum += l;
   if (sum != head.genome_len) return fail(WALT_EFORMAT, "index head: chromosome lengths do not sum to genome length");
+  // positions and position + read length are 32-bit here as in the reference; the top 256 values stay free
+  if (head.genome_len >= 0xFFFFFF00u) return fail(WALT_EINVAL, "genome longer than 2^32 - 256 bases");
   return WALT_OK;
 }
 

@@ -129,12 +129,13 @@ __device__ __forceinline__ void ascii4_to_codes(uint32_t w, uint32_t& codes8, ui
 template <int NW>
 __device__ __forceinline__ void lane_load_read(LaneRead<NW>& lr, const uint32_t* __restrict__ codes2, uint64_t o0,
                                                uint64_t o, uint64_t oe, bool valid, uint32_t ga,
-                                               uint32_t* __restrict__ err) {
+                                               uint32_t* __restrict__ err, const IndexView& iv) {
   uint64_t len64 = valid ? oe - o : 0;
-  if (len64 > 16ull * NW) { atomicAdd(err + 1, 1u); len64 = 0; }
+  const uint64_t rel = valid ? o - o0 : 0;  // dense array starts at the first read of the batch
+  // longer than the caller's max_read_len (the workspace is sized by it), or beyond what k_ascii_to_2bit converted
+  if (len64 > 16ull * NW || len64 > iv.batch_max_len || rel + len64 > iv.batch_cap_bytes) { atomicAdd(err + 1, 1u); len64 = 0; }
   lr.len = (uint32_t)len64;
   lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
-  const uint64_t rel = valid ? o - o0 : 0;  // dense array starts at the first read of the batch
   const uint32_t* p = codes2 + (rel >> 4);
   const uint32_t sh = 2 * (uint32_t)(rel & 15);
   // 16-byte loads (the address is only 4-byte aligned, which global loads allow): a quarter of the per-lane
@@ -160,7 +161,7 @@ __device__ __forceinline__ void lane_load_read(LaneRead<NW>& lr, const uint32_t*
 }
 
 void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t* d_codes2,
-                          uint32_t* d_err, hipStream_t stream);
+                          uint64_t cap_bytes, uint32_t* d_err, hipStream_t stream);
 inline uint64_t codes2_words(uint64_t total_bytes) { return total_bytes / 16 + 10; }  // >= 8 words of slack behind the last word (zeroed by k_ascii_to_2bit)
 
 // Care string (chars at read offsets seed_i + 1 + 3 i, MSB first) of a seed shift

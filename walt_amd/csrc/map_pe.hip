@@ -77,7 +77,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
   {
     uint64_t o = 0, oe = 0;
     if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
-    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err);
+    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err, iv);
   }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
   {
     uint64_t o = 0, oe = 0;
     if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
-    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err);
+    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err, iv);
   }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
@@ -626,6 +626,7 @@ struct PeWorkspace {
   Candidate* ranked[2];
   uint64_t stride;
   uint64_t total_bytes;
+  uint32_t cap_reads;  // reads per mate the pass's codes2 / ranked arrays have room for
 };
 
 static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, uint32_t max_read_len) {
@@ -638,6 +639,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
     return q;
   };
   w.stride = align_up(chunk ? chunk : 1, 64);
+  w.cap_reads = chunk;
   // [0..1] pack errors, [64 + 32 m ...] deferral control of mate m, [128] heavy-pair count of the merge
   w.err = reinterpret_cast<uint32_t*>(take(192 * sizeof(uint32_t)));
   for (int m = 0; m < 2; ++m) w.shards[m] = reinterpret_cast<unsigned long long*>(take(kStatShardBytes));
@@ -650,7 +652,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
 }
 
 template <int NW>
-static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
+static int launch_pe_topk(const walt_index* idx, const IndexView& view, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
                           uint64_t stride, uint32_t n, uint32_t sb,
                           uint32_t max_mm, uint32_t b, uint32_t top_k, uint32_t* heap_n,
                           Candidate* ranked, unsigned long long* stats, uint32_t* ctl, uint32_t* defer_list,
@@ -665,18 +667,18 @@ static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const u
   (void)lit_sorted; (void)cplx_list; (void)cplx_count;
   // patterns 5 / 7: the strand-major list kernel over every read with the directory/key search, Bloom hits
   // deferred to the literal list
-  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(1536), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(1536), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, nullptr, nullptr, lit_count, lit_list, n);
-  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(1536), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(1536), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, nullptr, nullptr, 0u);
   return WALT_OK;
 #else
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
-  hipLaunchKernelGGL(k_pe_topk_dual<NW>, dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n, sb,
+  hipLaunchKernelGGL(k_pe_topk_dual<NW>, dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, cplx_count,
                      cplx_list);
   const unsigned g2 = 1536;  // x 4 waves: the list kernels size their per-wave share from the list length
-  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, cplx_count, cplx_list, lit_count,
                      lit_list, 0u);
   launch_bin_deferred(lit_count, lit_list, lit_sorted, stream);
@@ -685,10 +687,10 @@ static int launch_pe_topk(const walt_index* idx, const uint32_t* codes2, const u
   // area, which is free again, and are mapped with full heaps
   const uint32_t kSmallHeap = 8u | (getenv("WALT_AMD_SMALL_HEAPS") ? 0x80000000u : 0u);  // env: force (tests)
   uint32_t* over_count = ctl + 25;  // zeroed with the control block at the start of the pass
-  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr, 0u,
                      kSmallHeap, over_count, cplx_list);
-  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, sb,
+  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, over_count, cplx_list, nullptr, nullptr, 0u);
   return WALT_OK;
 #endif
@@ -729,18 +731,21 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     unsigned long long* st = w.shards[m];
     const uint32_t sb = m ? 2u : 0u;
     uint32_t* ctl = w.err + 64 + 32 * m;
-    launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], pack_err, stream);
+    IndexView view = idx->view;  // this launch's copy: the limits lane_load_read enforces (the pass's share of the workspace)
+    view.batch_max_len = max_read_len;
+    view.batch_cap_bytes = (uint64_t)w.cap_reads * max_read_len;
+    launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], view.batch_cap_bytes, pack_err, stream);
     int rc;
     switch (nw) {
-      case 7: rc = launch_pe_topk<7>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 8: rc = launch_pe_topk<8>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 7: rc = launch_pe_topk<7>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 8: rc = launch_pe_topk<8>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
 #if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
-      case 10: rc = launch_pe_topk<10>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 16: rc = launch_pe_topk<16>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 32: rc = launch_pe_topk<32>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      default: rc = launch_pe_topk<64>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 10: rc = launch_pe_topk<10>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 16: rc = launch_pe_topk<16>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 32: rc = launch_pe_topk<32>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      default: rc = launch_pe_topk<64>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
 #else
-      default: rc = launch_pe_topk<10>(idx, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      default: rc = launch_pe_topk<10>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
 #endif
     }
     if (rc) return rc;

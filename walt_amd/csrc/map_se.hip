@@ -24,9 +24,12 @@ namespace walt {
 // ... bytes that are not ACGT (getBits would exit, util.hpp:117-119).
 static __global__ __launch_bounds__(kBlock) void k_ascii_to_2bit(const uint8_t* __restrict__ bases,
                                                                   const uint64_t* __restrict__ offsets, uint32_t n,
-                                                                  uint32_t* __restrict__ codes2,
+                                                                  uint32_t* __restrict__ codes2, uint64_t cap_bytes,
                                                                   uint32_t* __restrict__ err) {
-  const uint64_t o0 = offsets[0], total = offsets[n] - o0;
+  // never beyond the room the workspace has (n x max_read_len bytes): a batch whose reads are longer than the
+  // caller said is refused (walt_batch_check: WALT_EINVAL), its surplus is not converted and not read
+  const uint64_t o0 = offsets[0], all = offsets[n] - o0, total = all < cap_bytes ? all : cap_bytes;
+  if (all > cap_bytes && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(err + 1, 1u);
   const uint8_t* src = bases + o0;
   const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15);  // 16-byte loads need an aligned address
   const uint64_t nwords = (total + 15) / 16;
@@ -60,8 +63,9 @@ static __global__ __launch_bounds__(kBlock) void k_ascii_to_2bit(const uint8_t* 
   if (blockIdx.x == 0 && threadIdx.x < 8) codes2[nwords + threadIdx.x] = 0;  // slack read by the last lanes
 }
 void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n, uint32_t* d_codes2,
-                          uint32_t* d_err, hipStream_t stream) {
-  hipLaunchKernelGGL(k_ascii_to_2bit, dim3(256 * 16), dim3(kBlock), 0, stream, d_bases, d_offsets, n, d_codes2, d_err);
+                          uint64_t cap_bytes, uint32_t* d_err, hipStream_t stream) {
+  hipLaunchKernelGGL(k_ascii_to_2bit, dim3(256 * 16), dim3(kBlock), 0, stream, d_bases, d_offsets, n, d_codes2, cap_bytes,
+                     d_err);
 }
 
 // ---------------------------------------------------------------------------
@@ -177,7 +181,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
   {
     uint64_t o = 0, oe = 0;
     if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
-    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err);
+    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err, iv);
   }
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
@@ -328,7 +332,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
   const StrandView& svm = iv.s[strand_base + 1];
   const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
   LaneRead<NW> lr;
-  lane_load_read<NW>(lr, codes2, o_first, o_read, oe_read, valid, ga, err);
+  lane_load_read<NW>(lr, codes2, o_first, o_read, oe_read, valid, ga, err, iv);
   len_out = lr.len;
   bool mappable = valid && lr.len >= kMinReadLen;
   bool deferred = false;
@@ -770,7 +774,7 @@ static void debug_sync(const char* what, hipStream_t stream) {
 }
 
 template <int NW>
-static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
+static int launch_map_se(const walt_index* idx, const IndexView& view, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
                          uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
                          hipStream_t stream) {
@@ -779,10 +783,10 @@ static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const ui
   // patterns 5 / 7: strand-major kernel over every read with the directory/key search, Bloom hits deferred
   // (untagged order) to the literal pass
   const unsigned g1 = grid_for(n) < 4 * kLiteralGrid ? grid_for(n) : 4 * kLiteralGrid;
-  hipLaunchKernelGGL((k_map_se_literal<NW, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
+  hipLaunchKernelGGL((k_map_se_literal<NW, false>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, n);
   const unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
-  hipLaunchKernelGGL((k_map_se_literal<NW, true>), dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
+  hipLaunchKernelGGL((k_map_se_literal<NW, true>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u);
   return WALT_OK;
 #else
@@ -797,20 +801,20 @@ static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const ui
   const int stamp_mode = sm ? atoi(sm) : 0;
   const bool diag1 = diag && stamp_mode != 2, diag2 = diag && stamp_mode != 3;
   if (diag1)
-    hipLaunchKernelGGL((k_map_se<NW, true, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+    hipLaunchKernelGGL((k_map_se<NW, true, false>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, g_ablate, g_stamps);
   else
-    hipLaunchKernelGGL((k_map_se<NW, false, false>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+    hipLaunchKernelGGL((k_map_se<NW, false, false>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, 0u, nullptr);
   debug_sync("pass 1", stream);
   if (diag2)
-    hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+    hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, g_ablate, g_stamps);
   else
-    hipLaunchKernelGGL((k_map_se<NW, false, true>), dim3(g1), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err, n,
+    hipLaunchKernelGGL((k_map_se<NW, false, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, 0u, nullptr);
   debug_sync("heavy pass", stream);
@@ -819,7 +823,7 @@ static int launch_map_se(const walt_index* idx, const uint32_t* codes2, const ui
   else defer_sorted = defer_list;
   debug_sync("bin", stream);
   unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
-  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, idx->view, codes2, offsets, err,
+  hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted, 0u);
   debug_sync("literal pass", stream);
   return WALT_OK;
@@ -862,21 +866,24 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   const uint8_t* bases = reinterpret_cast<const uint8_t*>(d_bases);
   const uint64_t* offsets = reinterpret_cast<const uint64_t*>(d_offsets);
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
-  launch_ascii_to_2bit(bases, offsets, n, codes2, err, stream);
+  IndexView view = idx->view;  // this launch's copy: the limits lane_load_read enforces
+  view.batch_max_len = max_read_len;
+  view.batch_cap_bytes = (uint64_t)n * max_read_len;
+  launch_ascii_to_2bit(bases, offsets, n, codes2, view.batch_cap_bytes, err, stream);
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[1], stream));
   BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
   const uint32_t sb = ag ? 2u : 0u;
   int rc;
   switch (nw) {
-    case 7: rc = launch_map_se<7>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 8: rc = launch_map_se<8>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 7: rc = launch_map_se<7>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 8: rc = launch_map_se<8>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
 #if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
-    case 10: rc = launch_map_se<10>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 16: rc = launch_map_se<16>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 32: rc = launch_map_se<32>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    default: rc = launch_map_se<64>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 10: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 16: rc = launch_map_se<16>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 32: rc = launch_map_se<32>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    default: rc = launch_map_se<64>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
 #else
-    default: rc = launch_map_se<10>(idx, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    default: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
 #endif
   }
   if (rc) return rc;
@@ -894,8 +901,8 @@ int check_read_errors(const void* d_workspace, hipStream_t stream) {
   uint32_t herr[2] = {0, 0};
   WALT_HIP(hipMemcpyAsync(herr, d_workspace, sizeof(herr), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipStreamSynchronize(stream));
-  if (herr[1]) return fail(WALT_EINVAL, std::to_string(herr[1]) + " reads longer than max_read_len");
-  if (herr[0]) return fail(WALT_EBASE, std::to_string(herr[0]) + " reads contain a non-ACGT nucleotide");
+  if (herr[1]) return fail(WALT_EINVAL, "reads longer than max_read_len, or more bases than n x max_read_len (" + std::to_string(herr[1]) + " refusals)");
+  if (herr[0]) return fail(WALT_EBASE, "the batch holds non-ACGT nucleotides (in " + std::to_string(herr[0]) + " of its 16-base words)");
   return WALT_OK;
 }
 
