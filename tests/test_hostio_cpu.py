@@ -144,3 +144,61 @@ def test_loader_empty_and_tiny_files(scratch):
         for threads in (1, 4):
             got, _ = cxx_dump(path, 10, "", threads, 0, scratch)
             assert got == want
+
+
+def test_clipping_of_short_reads_pinned_against_the_reference_binary(scratch, g1_index_path):
+    """util.hpp:202-216 computes `s.length() - head_length + 1` in size_t: for reads of 13 bases and more this is a
+    plain bound, and the loader must reproduce the reference's clipping exactly (checked through the _unmapped file
+    of the REAL binary, which prints the clipped and N-replaced sequence of every too-short read); for reads of
+    fewer than 13 bases the difference wraps, the reference reads far outside its string and dies -- the loader
+    leaves such reads alone."""
+    if not os.path.exists(refio.REF_WALT):
+        pytest.skip("oracle/_ref/walt not built")
+    import subprocess
+    ad = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    rng = __import__("random").Random(9)
+    recs = []
+    for L in (13, 14, 15, 16, 18, 20, 25, 30, 37, 38, 45, 60):
+        for keep in (L, L - 3, L - 4, L - 5, L - 6, L - 9, L - 13, L - 14, 0, 1, 2):
+            if keep < 0:
+                continue
+            body = "".join(rng.choice("ACGT") for _ in range(keep))
+            tail = ad[:L - keep]
+            if len(tail) > 5 and rng.random() < 0.5:  # one error inside the adaptor part
+                k = rng.randrange(len(tail))
+                tail = tail[:k] + rng.choice([c for c in "ACGT" if c != tail[k]]) + tail[k + 1:]
+            recs.append(("r%d_%d_%d" % (len(recs), L, keep), (body + tail)[:L]))
+    fq = os.path.join(scratch, "clip_short.fastq")
+    with open(fq, "w") as f:
+        for nm, sq in recs:
+            f.write("@%s\n%s\n+\n%s\n" % (nm, sq, "I" * len(sq)))
+    wd = os.path.join(scratch, "clip_short_ref")
+    os.makedirs(wd, exist_ok=True)
+    out = os.path.join(wd, "o.mr")
+    subprocess.run([refio.REF_WALT, "-i", g1_index_path, "-r", fq, "-o", out, "-C", ad, "-u", "-a", "-m", "0"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ref_seq = {}
+    for side in ("_unmapped", "_ambiguous", ""):
+        for ln in open(out + side):
+            f = ln.rstrip("\n").split("\t")
+            if side == "_unmapped":
+                ref_seq[f[0]] = f[1]
+            else:
+                ref_seq[f[3]] = f[6] if f[5] == "+" else refio.revcomp(f[6])
+    got = cxx_dump(fq, 10 ** 6, ad, 3, 0, scratch)[0].decode()
+    mine = {ln.split("\t")[0]: ln.split("\t")[1] for ln in got.splitlines() if not ln.startswith("#")}
+    assert len(ref_seq) == len(recs) and sorted(mine) == sorted(ref_seq)
+    clipped = 0
+    for (nm, sq) in recs:
+        assert mine[nm] == ref_seq[nm], (nm, sq, mine[nm], ref_seq[nm])
+        clipped += mine[nm] != sq
+    assert clipped > 40
+    # below 13 bases: the reference binary does not survive the wrap; the loader does, and clips nothing
+    fq2 = os.path.join(scratch, "clip_tiny.fastq")
+    with open(fq2, "w") as f:
+        f.write("@t0\nACGTAGATCGGA\n+\nIIIIIIIIIIII\n@t1\nAGATCGG\n+\nIIIIIII\n")
+    r = subprocess.run([refio.REF_WALT, "-i", g1_index_path, "-r", fq2, "-o", os.path.join(wd, "t.mr"), "-C", ad, "-u"],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert r.returncode != 0, "the reference was expected to die on the unsigned wrap (util.hpp:203)"
+    got = cxx_dump(fq2, 10 ** 6, ad, 2, 0, scratch)[0].decode()
+    assert [ln.split("\t")[1] for ln in got.splitlines() if not ln.startswith("#")] == ["ACGTAGATCGGA", "AGATCGG"]

@@ -989,21 +989,14 @@ WALT_HD void best4single(const Candidate* r, int n, BestMatch& best) {  // paire
     }
   }
 }
+// length of a reported fragment (the `len` OutputBestPairedResults returns, paired.cpp:210-243): from mate 1's 5'
+// end to mate 2's, i.e. the same span GetFragmentLength measured when the pair was accepted
 WALT_HD int pair_len(const Candidate& r1, const Candidate& r2, uint32_t len1, uint32_t len2,
-                     const uint32_t* start_index, uint32_t n_chrom) {  // paired.cpp:210-243
-  uint32_t c1 = chrom_id(start_index, n_chrom, r1.genome_pos);
-  uint32_t c2 = chrom_id(start_index, n_chrom, r2.genome_pos);
+                     const uint32_t* start_index, uint32_t n_chrom) {
   uint32_t s1, e1, s2, e2;
-  forward_pos(r1.genome_pos, r1.strand, c1, len1, start_index, s1, e1);
-  forward_pos(r2.genome_pos, r2.strand, c2, len2, start_index, s2, e2);
-  uint32_t ov_s = s1 > s2 ? s1 : s2;
-  uint32_t ov_e = e1 < e2 ? e1 : e2;
-  bool plus = r1.strand == '+';
-  uint32_t one_l = plus ? s1 : (ov_e > s1 ? ov_e : s1);
-  uint32_t one_r = plus ? (ov_s < e1 ? ov_s : e1) : e1;
-  uint32_t two_l = plus ? (ov_e > s2 ? ov_e : s2) : s2;
-  uint32_t two_r = plus ? e2 : (ov_s < e2 ? ov_s : e2);
-  return plus ? (int)(two_r - one_l) : (int)(one_r - two_l);
+  forward_pos(r1.genome_pos, r1.strand, chrom_id(start_index, n_chrom, r1.genome_pos), len1, start_index, s1, e1);
+  forward_pos(r2.genome_pos, r2.strand, chrom_id(start_index, n_chrom, r2.genome_pos), len2, start_index, s2, e2);
+  return r1.strand == '+' ? (int)(e2 - s1) : (int)(e1 - s2);
 }
 // Tail of MergePairedEndResults (paired.cpp:515-545): a unique best pair is reported as such, otherwise each
 // mate falls back to its own best candidate (GetBestMatch4Single).

@@ -8,9 +8,9 @@
 //   * the N -> rand()%4 draws (util.hpp:156-163, srand(0) per batch,
 //     mapping.cpp:73) are applied by ONE thread in file order after the
 //     parallel copy has listed the characters that need one;
-//   * inputs the parallel scanner cannot treat exactly (a line of 999+ bytes,
-//     which fgets would split; a file that cannot be mmapped) go through a
-//     serial loader that is a plain restatement of the reference loop.
+//   * a line of 999+ bytes, which fgets would split, makes the SAME scanner run over the
+//     rest of the file as one chunk on one thread with the split rule applied; a file
+//     that cannot be mmapped (a pipe) is read into memory first and scanned there.
 #ifndef WALT_AMD_HOSTIO_H_
 #define WALT_AMD_HOSTIO_H_
 #include <fcntl.h>
@@ -144,12 +144,11 @@ struct OutFile {
 // ---------------------------------------------------------------- read batches
 struct Batch {
   uint32_t n = 0;
-  const char* base = nullptr;            // the mapped file, or `arena` in serial mode
+  const char* base = nullptr;            // the input file's bytes (mapped, or read into memory)
   std::vector<uint64_t> name_v, score_v, seq_v;  // (offset << 16) | length
   char* bases = nullptr;                 // sanitised sequences, packed; pinned host memory
   uint64_t* offsets = nullptr;           // n + 1
   size_t bases_cap = 0, off_cap = 0;
-  std::string arena;
   Batch() {}
   Batch(const Batch&) = delete;
   Batch& operator=(const Batch&) = delete;
@@ -177,23 +176,28 @@ struct Batch {
   }
 };
 
-// adaptor clipping, util.hpp:189-218 (the std::string arithmetic, including its
-// unsigned wrap for reads shorter than the 14-character head, is kept as is)
-static const size_t head_length = 14, sufficient_head_match = 11, min_overlap = 5;
-inline size_t similarity(const std::string& s, size_t pos, const std::string& adaptor) {
-  const size_t lim = std::min(std::min(s.length() - pos, adaptor.length()), head_length);
-  size_t count = 0;
-  for (size_t i = 0; i < lim; ++i) count += (s[pos + i] == adaptor[i]);
-  return count;
-}
-inline size_t clip_adaptor_from_read(const std::string& adaptor, std::string& s) {
-  size_t lim1 = s.length() - head_length + 1;
-  for (size_t i = 0; i < lim1; ++i)
-    if (similarity(s, i, adaptor) >= sufficient_head_match) { std::fill(s.begin() + i, s.end(), 'N'); return s.length() - i; }
-  const size_t lim2 = s.length() - min_overlap + 1;
-  for (size_t i = lim1; i < lim2; ++i)
-    if (similarity(s, i, adaptor) >= s.length() - i - 1) { std::fill(s.begin() + i, s.end(), 'N'); return s.length() - i; }
-  return 0;
+// ---------------------------------------------------------------- adaptor clipping (-C)
+// What util.hpp:189-218 decides, stated per start position: the read's tail from `at` on is taken for adaptor
+// when, of the first min(tail, adaptor, 14) characters of the adaptor, at least 11 agree with it (tails of 14
+// bases or more), or all but one of the whole tail do (tails of 13 down to 5 bases).  Returns the first such
+// `at`, or the read's length when there is none; the caller writes 'N' from there on (the loader then draws
+// random bases for them like for any other non-ACGT character).
+// The reference computes its loop bounds as size_t differences, which wrap for reads of fewer than 13 bases and
+// send it reading far outside the string (it crashes: tests/test_hostio_cpu.py pins both sides of that limit
+// against the reference binary); such reads are left alone here.
+static const uint32_t kAdaptorHead = 14, kAdaptorHeadHits = 11, kAdaptorMinTail = 5;
+inline uint32_t adaptor_clip_point(View read, View adaptor) {
+  if (read.len < kAdaptorHead - 1) return read.len;
+  for (uint32_t at = 0; at + kAdaptorMinTail <= read.len; ++at) {
+    const uint32_t tail = read.len - at;
+    const uint32_t window = std::min(std::min(tail, adaptor.len), kAdaptorHead);
+    const uint32_t need = tail >= kAdaptorHead ? kAdaptorHeadHits : tail - 1;
+    if (window < need) continue;
+    uint32_t hits = 0;
+    for (uint32_t k = 0; k < window; ++k) hits += read.p[at + k] == adaptor.p[k] ? 1u : 0u;
+    if (hits >= need) return at;
+  }
+  return read.len;
 }
 
 inline bool is_acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
@@ -233,8 +237,9 @@ struct FastqReader {
   std::string path;
   const char* data = nullptr;
   size_t size = 0, pos = 0;
-  FILE* fin = nullptr;  // serial mode
-  bool serial = false;
+  bool mapped = false;
+  std::vector<char> slurped;  // contents of an input that cannot be mmapped
+  bool serial = false;        // a long line was met: one chunk, one thread from there on (kept for the tests)
   int threads = 1;
 
   void open(const std::string& p, int nthreads) {
@@ -248,79 +253,91 @@ struct FastqReader {
       if (m != MAP_FAILED) {
         data = static_cast<const char*>(m);
         size = (size_t)st.st_size;
+        mapped = true;
         madvise(m, size, MADV_SEQUENTIAL);
       }
     }
+    if (!data) {  // pipe, empty file, or WALT_AMD_SERIAL_IO (tests): read it all, then scan the copy on one thread
+      char buf[1 << 16];
+      for (;;) {
+        const ssize_t got = ::read(fd, buf, sizeof buf);
+        if (got < 0) { ::close(fd); throw std::runtime_error("cannot read input file " + p); }
+        if (got == 0) break;
+        slurped.insert(slurped.end(), buf, buf + got);
+      }
+      data = slurped.data();
+      size = slurped.size();
+      serial = true;
+    }
     ::close(fd);
-    if (!data) to_serial();
   }
   void close() {
-    if (data) munmap(const_cast<char*>(data), size);
-    if (fin) fclose(fin);
+    if (mapped) munmap(const_cast<char*>(data), size);
     data = nullptr;
-    fin = nullptr;
-  }
-  void to_serial() {
-    serial = true;
-    fin = fopen(path.c_str(), "r");
-    if (!fin) throw std::runtime_error("cannot open input file " + path);
-    if (pos) fseeko(fin, (off_t)pos, SEEK_SET);
+    mapped = false;
+    slurped.clear();
   }
 
-  // ---- one fgets line starting at s: [s, e) are the bytes fgets would return
+  // ---- one fgets(cline, 1000, f) call of the reference (mapping.cpp:81) starting at s: the bytes [s, e) it returns --
+  // up to and including the next newline, but never more than 999 of them
   inline size_t line_end(size_t s) const {
-    const void* nl = memchr(data + s, '\n', size - s);
-    return nl ? (size_t)(static_cast<const char*>(nl) - data) + 1 : size;
+    const size_t lim = std::min(size, s + (kMaxLine - 1));
+    const void* nl = memchr(data + s, '\n', lim - s);
+    return nl ? (size_t)(static_cast<const char*>(nl) - data) + 1 : lim;
   }
+  // first line start at or behind a chunk boundary (only used while no line is long enough to be split)
   inline size_t first_line_at_or_after(size_t a, size_t batch_start) const {
     if (a <= batch_start) return batch_start;
     if (a >= size) return size;
     if (data[a - 1] == '\n') return a;
-    return line_end(a);
+    const void* nl = memchr(data + a, '\n', size - a);
+    return nl ? (size_t)(static_cast<const char*>(nl) - data) + 1 : size;
   }
 
   // LoadReadsFromFastqFile, mapping.cpp:65-121
   void load(uint32_t n_per_batch, const std::string& adaptor, Batch& bt) {
-    if (serial) { load_serial(n_per_batch, adaptor, bt); return; }
     const uint64_t lim = (uint64_t)n_per_batch * 4;
     const size_t start = pos;
     bt.n = 0;
     bt.base = data;
     if (start >= size || lim == 0) { finish_sequences(adaptor, bt); return; }
-    // pass 1: count the non-empty lines that start in each chunk, chunk waves until `lim` lines or EOF
-    const size_t chunk = 1u << 20;
     double tm = now_s();
-    std::vector<uint64_t> lines;  // per chunk
+    std::vector<uint64_t> lines;  // non-empty lines that start in each chunk
     uint64_t total = 0;
-    bool long_line = false;
-    size_t covered = start;
-    size_t wave = 1;  // 1, 2, 4, ... chunks per wave: a small -N must not scan far beyond its batch
-    while (total < lim && covered < size) {
-      const size_t first = lines.size();
-      const size_t want = std::min<size_t>((size - covered + chunk - 1) / chunk, wave);
-      wave = std::min<size_t>(wave * 2, (size_t)threads * 4);
-      lines.resize(first + want, 0);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(|| : long_line)
-      for (long c = 0; c < (long)want; ++c) {
-        const size_t a = start + (first + c) * chunk, b = std::min(a + chunk, size);
-        size_t s = first_line_at_or_after(a, start);
-        uint64_t cnt = 0;
-        const uint64_t stop = (first + c == 0) ? lim : ~0ull;  // the batch's first chunk may stop at `lim` lines
-        while (s < b && cnt < stop) {
-          const size_t e = line_end(s);
-          if (e - s > kMaxLine - 1) long_line = true;
-          cnt += (e - s) > 1;  // fgets line minus its last character is non-empty (mapping.cpp:82-85)
-          s = e;
+    size_t covered = start, chunk = 1u << 20;
+    for (;;) {
+      // pass 1: count lines per chunk, in waves of chunks until `lim` lines or the end of the file
+      const int T = serial ? 1 : threads;
+      if (serial) chunk = size - start + 1;  // one chunk: the scan follows the split rule from the batch's first byte
+      lines.clear();
+      total = 0;
+      covered = start;
+      bool long_line = false;
+      size_t wave = 1;  // 1, 2, 4, ... chunks per wave: a small -N must not scan far beyond its batch
+      while (total < lim && covered < size) {
+        const size_t first = lines.size();
+        const size_t want = std::min<size_t>((size - covered + chunk - 1) / chunk, wave);
+        wave = std::min<size_t>(wave * 2, (size_t)T * 4);
+        lines.resize(first + want, 0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(T) reduction(|| : long_line)
+        for (long c = 0; c < (long)want; ++c) {
+          const size_t a = start + (first + c) * chunk, b = std::min(a + chunk, size);
+          size_t s = first_line_at_or_after(a, start);
+          uint64_t cnt = 0;
+          const uint64_t stop = (first + c == 0) ? lim : ~0ull;  // the batch's first chunk may stop at `lim` lines
+          while (s < b && cnt < stop) {
+            const size_t e = line_end(s);
+            if (e - s >= kMaxLine - 1 && data[e - 1] != '\n') long_line = true;  // fgets filled its buffer: the line goes on
+            cnt += (e - s) > 1;  // the piece minus its last character is non-empty (mapping.cpp:82-85)
+            s = e;
+          }
+          lines[first + c] = cnt;
         }
-        lines[first + c] = cnt;
+        for (size_t c = first; c < first + want; ++c) total += lines[c];
+        covered = std::min(size, start + (first + want) * chunk);
       }
-      for (size_t c = first; c < first + want; ++c) total += lines[c];
-      covered = std::min(size, start + (first + want) * chunk);
-    }
-    if (long_line) {  // fgets would split such a line: take the restated serial loop from here on
-      to_serial();
-      load_serial(n_per_batch, adaptor, bt);
-      return;
+      if (!long_line || serial) break;
+      serial = true;  // chunk starts are not piece starts once a line is split: scan again as one chunk
     }
     t_scan += now_s() - tm;
     tm = now_s();
@@ -332,7 +349,7 @@ struct FastqReader {
     // pass 2: record name / sequence / quality views; line L belongs to read L/4, role L%4
     size_t next_pos = covered;
     const uint64_t n_lines_used = (uint64_t)bt.n * 4;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(serial ? 1 : threads)
     for (long c = 0; c < (long)lines.size(); ++c) {
       uint64_t L = first_line[c];
       if (L >= lim) continue;
@@ -377,6 +394,7 @@ struct FastqReader {
     const uint32_t n = bt.n;
     bt.reserve_reads(n + 1);
     const int T = threads;
+    const View ad{adaptor.data(), (uint32_t)adaptor.size()};
     std::vector<uint64_t> part(T + 1, 0);
     auto lo_of = [&](int t) { return (uint32_t)((uint64_t)n * t / T); };
 #pragma omp parallel for schedule(static, 1) num_threads(T)
@@ -394,19 +412,15 @@ struct FastqReader {
 #pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < T; ++t) {
       uint64_t o = part[t];
-      std::string tmp;
       for (uint32_t j = lo_of(t); j < lo_of(t + 1); ++j) {
         const char* src = bt.base + (bt.seq_v[j] >> 16);
         const uint32_t len = (uint32_t)(bt.seq_v[j] & 0xFFFF);
         bt.offsets[j] = o;
-        if (!adaptor.empty()) {
-          tmp.assign(src, len);
-          clip_adaptor_from_read(adaptor, tmp);
-          src = tmp.data();
-        }
+        // -C: the adaptor part becomes 'N' (mapping.cpp:97-99), i.e. one more kind of character that needs a draw
+        const uint32_t keep = ad.len ? adaptor_clip_point(View{src, len}, ad) : len;
         char* dst = bt.bases + o;
         for (uint32_t i = 0; i < len; ++i) {
-          const char c = src[i];
+          const char c = i < keep ? src[i] : 'N';
           dst[i] = c;
           if (!is_acgt(c)) fix[t].push_back(o + i);
         }
@@ -420,42 +434,6 @@ struct FastqReader {
     for (int t = 0; t < T; ++t)
       for (uint64_t at : fix[t]) bt.bases[at] = "ACGT"[rand() % 4];  // toACGT, util.hpp:156-163
     t_rng += now_s() - tm;
-  }
-
-  // the reference loop as written, for inputs the scanner above hands over
-  void load_serial(uint32_t n_per_batch, const std::string& adaptor, Batch& bt) {
-    char cline[kMaxLine];
-    std::string line;
-    int line_code = 0;
-    uint64_t line_count = 0;
-    const uint64_t lim = (uint64_t)n_per_batch * 4;
-    bt.n = 0;
-    bt.arena.clear();
-    std::vector<uint64_t> nv, sv, qv;
-    while (line_count < lim && fgets(cline, kMaxLine, fin)) {
-      cline[strlen(cline) - 1] = 0;
-      line = cline;
-      if (line.size() == 0) continue;
-      switch (line_code) {
-        case 0: {
-          size_t sp = line.find_first_of(' ');
-          std::string nm = sp == std::string::npos ? line.substr(1) : line.substr(1, sp - 1);
-          nv.push_back(Batch::pack(bt.arena.size(), nm.size()));
-          bt.arena += nm;
-          break;
-        }
-        case 1: sv.push_back(Batch::pack(bt.arena.size(), line.size())); bt.arena += line; break;
-        case 2: break;
-        case 3: qv.push_back(Batch::pack(bt.arena.size(), line.size())); bt.arena += line; bt.n++; break;
-      }
-      ++line_count;
-      if (++line_code == 4) line_code = 0;
-    }
-    pos = (size_t)ftello(fin);
-    bt.reserve_reads(bt.n + 1);
-    for (uint32_t j = 0; j < bt.n; ++j) { bt.name_v[j] = nv[j]; bt.seq_v[j] = sv[j]; bt.score_v[j] = qv[j]; }
-    bt.base = bt.arena.data();
-    finish_sequences(adaptor, bt);
   }
 };
 

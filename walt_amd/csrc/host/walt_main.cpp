@@ -98,11 +98,18 @@ static bool valid_suffix(const string& fn) {  // walt.cpp:58-64 (checks .fastq /
 }
 static bool exists(const string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
-static void extract_adaptors(const string& adaptor, string& t_ad, string& a_ad) {  // util.hpp:220-232
-  const size_t sep = adaptor.find_first_of(":");
-  if (adaptor.find_last_of(":") != sep) die("ERROR: adaptor format \"T_adaptor[:A_adaptor]\"");
-  if (sep == string::npos) t_ad = a_ad = adaptor;
-  else { t_ad = adaptor.substr(0, sep); a_ad = adaptor.substr(sep + 1); }
+// -C "T_adaptor[:A_adaptor]" (walt.cpp:150-152): one adaptor serves both mates, two are split at the colon
+struct AdaptorPair {
+  string mate1, mate2;
+};
+static AdaptorPair split_adaptor_option(const string& opt) {
+  const size_t colons = (size_t)std::count(opt.begin(), opt.end(), ':');
+  if (colons > 1) die("ERROR: adaptor format \"T_adaptor[:A_adaptor]\"");
+  AdaptorPair ap;
+  const size_t cut = colons ? opt.find(':') : opt.size();
+  ap.mate1 = opt.substr(0, cut);
+  ap.mate2 = colons ? opt.substr(cut + 1) : ap.mate1;
+  return ap;
 }
 
 // ---------------------------------------------------------------- genome info + helpers
@@ -149,19 +156,23 @@ struct SeCounts {  // StatSingleReads, mapping.hpp:55-108
   void add(const SeCounts& o) {
     total += o.total; unique += o.unique; ambiguous += o.ambiguous; unmapped += o.unmapped; too_short += o.too_short;
   }
-  string tostring(size_t n_tabs = 0) const {  // mapping.cpp:47-63
-    string t;
-    for (size_t i = 0; i < n_tabs; ++i) t += "    ";
-    std::ostringstream oss;
-    oss << t << "total_reads: " << total << std::endl
-        << t << "mapped:" << std::endl
-        << t << "    unique: " << unique << std::endl
-        << t << "    percent_unique: " << (100.0 * unique) / total << std::endl
-        << t << "    ambiguous: " << ambiguous << std::endl
-        << t << "unmapped: " << unmapped << std::endl
-        << t << "min_read_length: " << MINIMALREADLEN << std::endl
-        << t << "too_short: " << too_short;
-    return oss.str();
+  // the block StatSingleReads prints into <out>.mapstats (mapping.cpp:47-63): `depth` levels of four spaces in front
+  // of every line, no newline behind the last; percent_unique in the stream's default %g form (0 reads: "-nan")
+  void put_block(Sink& f, int depth) const {
+    auto line = [&](int extra, const char* key) {
+      for (int i = 0; i < 4 * (depth + extra); ++i) f.ch(' ');
+      f.lit(key);
+    };
+    char pct[40];
+    snprintf(pct, sizeof pct, "%g", (100.0 * unique) / total);
+    line(0, "total_reads: "); f.u32(total); f.ch('\n');
+    line(0, "mapped:\n");
+    line(1, "unique: "); f.u32(unique); f.ch('\n');
+    line(1, "percent_unique: "); f.lit(pct); f.ch('\n');
+    line(1, "ambiguous: "); f.u32(ambiguous); f.ch('\n');
+    line(0, "unmapped: "); f.u32(unmapped); f.ch('\n');
+    line(0, "min_read_length: "); f.u32(MINIMALREADLEN); f.ch('\n');
+    line(0, "too_short: "); f.u32(too_short);
   }
 };
 struct SideFiles {  // the _ambiguous / _unmapped files of StatSingleReads (mapping.hpp:75-87)
@@ -304,8 +315,15 @@ static void process_se(const Options& o, const string& reads_file, const string&
   fout.close();
   side.close();
   walt_host_free(res);
-  std::ofstream mapstats(out_file + ".mapstats", std::ios::app);
-  mapstats << st.tostring() << std::endl;
+  {
+    Sink ms;
+    st.put_block(ms, 0);
+    ms.ch('\n');
+    OutFile mf;
+    if (!mf.open_append(out_file + ".mapstats")) die("cannot open input file " + out_file + ".mapstats");
+    mf.write(ms.p, ms.n);
+    mf.close();
+  }
   walt_index_close(idx);
   if (o.verbose)
     fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, format %.2f s, write %.2f s]\n", T,
@@ -319,59 +337,54 @@ static void forward_pos(uint32_t gp, char strand, uint32_t chr, uint32_t read_le
   s = strand == '+' ? s : g.length[chr] - s - read_len;
   e = s + read_len;
 }
-static string revcomp_str(View v) {
-  string r(v.len, 'N');
-  for (uint32_t i = 0; i < v.len; ++i) {
-    char c = v.p[v.len - 1 - i];
-    r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
-  }
-  return r;
+// A uniquely paired fragment (OutputBestPairedResults, paired.cpp:210-294): its length, and in MR mode the FRAG line.
+// Both mates are laid over the fragment, which is written in mate 1's reading direction: position x of the line is
+// base x of mate 1 and base j2(x) of the reverse-complemented mate 2.  Where only one mate covers x its base is
+// printed; where both do, the base of the mate with more informative positions (length minus Ns minus mismatches;
+// mate 1 on a tie); where neither does (mates that do not meet), 'N' with quality 'B'.
+static inline char comp_base(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c; }
+static uint32_t count_n(View v) {
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < v.len; ++i) n += v.p[i] == 'N';
+  return n;
 }
-static string rev_str(View v) { return string(std::reverse_iterator<const char*>(v.p + v.len), std::reverse_iterator<const char*>(v.p)); }
-// OutputBestPairedResults, paired.cpp:210-294
-static int out_best_pair(const walt_candidate& r1, const walt_candidate& r2, int frag_range, const GenomeInfo& g,
-                         View name, View vseq1, View vscr1, View vseq2, View vscr2, bool sam, Sink& fout) {
-  const uint32_t len1 = vseq1.len, len2 = vseq2.len;
-  uint32_t c1 = chrom_id(g, r1.genome_pos), c2 = chrom_id(g, r2.genome_pos);
+static int put_fragment(const walt_candidate& r1, const walt_candidate& r2, int frag_range, const GenomeInfo& g, View name,
+                        View seq1, View scr1, View seq2, View scr2, bool length_only, Sink& fout) {
+  const uint32_t c1 = chrom_id(g, r1.genome_pos), c2 = chrom_id(g, r2.genome_pos);
   uint32_t s1, s2, e1, e2;
-  forward_pos(r1.genome_pos, r1.strand, c1, len1, g, s1, e1);
-  forward_pos(r2.genome_pos, r2.strand, c2, len2, g, s2, e2);
-  uint32_t ov_s = std::max(s1, s2), ov_e = std::min(e1, e2);
-  const bool plus = r1.strand == '+';
-  uint32_t one_l = plus ? s1 : std::max(ov_e, s1);
-  uint32_t one_r = plus ? std::min(ov_s, e1) : e1;
-  uint32_t two_l = plus ? std::max(ov_e, s2) : s2;
-  uint32_t two_r = plus ? e2 : std::min(ov_s, e2);
-  int len = plus ? (int)(two_r - one_l) : (int)(one_r - two_l);
-  if (sam) return len;
-  const string seq1(vseq1.p, vseq1.len), scr1(vscr1.p, vscr1.len);
-  const string seq2r = revcomp_str(vseq2), scr2r = rev_str(vscr2);
-  string seq(len, 'N'), scr(len, 'B');
-  if (len > 0 && len <= frag_range) {
-    uint32_t lim_one = one_r - one_l;
-    std::copy(seq1.begin(), seq1.begin() + lim_one, seq.begin());
-    std::copy(scr1.begin(), scr1.begin() + lim_one, scr.begin());
-    uint32_t lim_two = two_r - two_l;
-    std::copy(seq2r.end() - lim_two, seq2r.end(), seq.end() - lim_two);
-    std::copy(scr2r.end() - lim_two, scr2r.end(), scr.end() - lim_two);
-    if (ov_s < ov_e) {
-      int info_one = (int)len1 - ((int)std::count(seq1.begin(), seq1.end(), 'N') + (int)r1.mismatch);
-      int info_two = (int)len2 - ((int)std::count(seq2r.begin(), seq2r.end(), 'N') + (int)r2.mismatch);
-      if (info_one >= info_two) {
-        uint32_t a = plus ? (ov_s - s1) : (e1 - ov_e), b = plus ? (ov_e - s1) : (e1 - ov_s);
-        std::copy(seq1.begin() + a, seq1.begin() + b, seq.begin() + lim_one);
-        std::copy(scr1.begin() + a, scr1.begin() + b, scr.begin() + lim_one);
-      } else {
-        uint32_t a = plus ? (ov_s - s2) : (e2 - ov_e), b = plus ? (ov_e - s2) : (e2 - ov_s);
-        std::copy(seq2r.begin() + a, seq2r.begin() + b, seq.begin() + lim_one);
-        std::copy(scr2r.begin() + a, scr2r.begin() + b, scr.begin() + lim_one);
-      }
-    }
-  }
-  uint32_t start_pos = plus ? s1 : s2;
+  forward_pos(r1.genome_pos, r1.strand, c1, seq1.len, g, s1, e1);
+  forward_pos(r2.genome_pos, r2.strand, c2, seq2.len, g, s2, e2);
+  const bool fwd = r1.strand == '+';
+  // the fragment runs from mate 1's 5' end to mate 2's: [s1, e2) read upwards, or [s2, e1) read downwards
+  const int len = fwd ? (int)(e2 - s1) : (int)(e1 - s2);
+  if (length_only) return len;
+  const bool lay = len > 0 && len <= frag_range;
+  const int info1 = (int)seq1.len - (int)(count_n(seq1) + r1.mismatch);
+  const int info2 = (int)seq2.len - (int)(count_n(seq2) + r2.mismatch);
+  const bool mate1_wins = info1 >= info2;
+  // index into the reverse-complemented mate 2 of line position x: (s1 + x) - s2 upwards, e2 - 1 - (e1 - 1 - x) downwards
+  const int64_t shift = fwd ? (int64_t)s1 - (int64_t)s2 : (int64_t)e2 - (int64_t)e1;
+  const uint32_t start_pos = fwd ? s1 : s2;
   fout.put(g.name[c1]); fout.ch('\t'); fout.u32(start_pos); fout.ch('\t'); fout.u32(start_pos + len);
   fout.lit("\tFRAG:"); fout.put(name); fout.ch('\t'); fout.u32(r1.mismatch + r2.mismatch); fout.ch('\t');
-  fout.ch(r1.strand); fout.ch('\t'); fout.put(seq); fout.ch('\t'); fout.put(scr); fout.ch('\n');
+  fout.ch(r1.strand); fout.ch('\t');
+  for (int pass = 0; pass < 2; ++pass) {  // bases, then qualities
+    char* out = fout.grow((size_t)len);
+    for (int x = 0; x < len; ++x) {
+      const int64_t j2 = (int64_t)x + shift;
+      const bool in1 = lay && (uint32_t)x < seq1.len, in2 = lay && j2 >= 0 && j2 < (int64_t)seq2.len;
+      char ch = pass ? 'B' : 'N';
+      if (in1 && (!in2 || mate1_wins)) {
+        ch = pass ? scr1.p[x] : seq1.p[x];
+      } else if (in2) {
+        const uint32_t k = seq2.len - 1 - (uint32_t)j2;  // the reverse complement is never materialised
+        ch = pass ? scr2.p[k] : comp_base(seq2.p[k]);
+      }
+      out[x] = ch;
+    }
+    fout.n += (size_t)len;
+    fout.ch(pass ? '\n' : '\t');
+  }
   return len;
 }
 static int sam_flag(bool paired_mapped, bool unmapped, bool next_unmapped, bool rev, bool next_rev, bool first,
@@ -447,8 +460,8 @@ static void process_pe(const Options& o, const string& file1, const string& file
   hostio::FastqReader rd[2];
   rd[0].open(f1, T);
   rd[1].open(f2, T);
-  string adaptors[2];
-  extract_adaptors(o.adaptor, adaptors[0], adaptors[1]);
+  const AdaptorPair ap = split_adaptor_option(o.adaptor);
+  const string adaptors[2] = {ap.mate1, ap.mate2};
   OutFile fout;
   if (!fout.open_append(out_file)) die("cannot open input file " + out_file);
   SideFiles side1, side2;  // StatPairedReads, paired.hpp:78-106
@@ -509,7 +522,7 @@ static void process_pe(const Options& o, const string& file1, const string& file
           a.unique_pairs++;
           walt_candidate r1 = {p.m1.genome_pos, p.m1.strand, {0, 0, 0}, p.m1.mismatch};
           walt_candidate r2 = {p.m2.genome_pos, p.m2.strand, {0, 0, 0}, p.m2.mismatch};
-          len = out_best_pair(r1, r2, o.frag_range, g, name, q1, k1, q2, k2, o.sam, s[kMain]);
+          len = put_fragment(r1, r2, o.frag_range, g, name, q1, k1, q2, k2, o.sam, s[kMain]);
           a.frag_count[len]++;
           if (o.sam) { is_paired = true; bm1 = p.m1; bm2 = p.m2; }
         } else {
@@ -551,25 +564,31 @@ static void process_pe(const Options& o, const string& file1, const string& file
   fout.close();
   side1.close(); side2.close();
   walt_host_free(pr);
-  std::ofstream mapstats(out_file + ".mapstats", std::ios::app);  // StatPairedReads::tostring, paired.cpp:52-77
-  std::ostringstream oss;
-  oss << "pairs:" << std::endl
-      << "    total_read_pairs: " << total_pairs << std::endl
-      << "    mapped:" << std::endl
-      << "        unique: " << unique_pairs << std::endl
-      << "        percent_unique: " << (100.0 * unique_pairs) / total_pairs << std::endl
-      << "        ambiguous: " << ambiguous_pairs << std::endl
-      << "    unmapped: " << unmapped_pairs << std::endl
-      << "mate1:" << std::endl << (pbat ? st2 : st1).tostring(1) << std::endl
-      << "mate2:" << std::endl << (pbat ? st1 : st2).tostring(1) << std::endl;
-  oss << "frag_len_distribution:" << std::endl;
-  double total = 0.0;
-  for (size_t i = 0; i < frag_count.size(); ++i) {
-    oss << "    " << i << ": " << frag_count[i] << std::endl;
-    total += (i * frag_count[i]);
+  {  // the block StatPairedReads prints (paired.cpp:52-77): pair counters, one mate block each, the fragment histogram
+    Sink ms;
+    char num[48];
+    ms.lit("pairs:\n    total_read_pairs: "); ms.u32(total_pairs);
+    ms.lit("\n    mapped:\n        unique: "); ms.u32(unique_pairs);
+    snprintf(num, sizeof num, "%g", (100.0 * unique_pairs) / total_pairs);
+    ms.lit("\n        percent_unique: "); ms.lit(num);
+    ms.lit("\n        ambiguous: "); ms.u32(ambiguous_pairs);
+    ms.lit("\n    unmapped: "); ms.u32(unmapped_pairs);
+    ms.lit("\nmate1:\n"); (pbat ? st2 : st1).put_block(ms, 1);
+    ms.lit("\nmate2:\n"); (pbat ? st1 : st2).put_block(ms, 1);
+    ms.lit("\nfrag_len_distribution:\n");
+    double weighted = 0.0, pairs_in_hist = 0.0;
+    for (size_t i = 0; i < frag_count.size(); ++i) {
+      ms.lit("    "); ms.u32((uint32_t)i); ms.lit(": "); ms.u32(frag_count[i]); ms.ch('\n');
+      weighted += (double)i * frag_count[i];
+      pairs_in_hist += frag_count[i];
+    }
+    snprintf(num, sizeof num, "%g", weighted / pairs_in_hist);
+    ms.lit("frag_len_mean: "); ms.lit(num); ms.ch('\n');
+    OutFile mf;
+    if (!mf.open_append(out_file + ".mapstats")) die("cannot open input file " + out_file + ".mapstats");
+    mf.write(ms.p, ms.n);
+    mf.close();
   }
-  oss << "frag_len_mean: " << total / std::accumulate(frag_count.begin(), frag_count.end(), 0.0);
-  mapstats << oss.str() << std::endl;
   walt_index_close(idx);
   if (o.verbose)
     fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, output %.2f s]\n", T, t_index,
