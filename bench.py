@@ -201,7 +201,7 @@ def oracle_se_jobs(cx, idx, jobs, lens, strands):
                 orc.orc_se_map_strand_trace(ctypes.addressof(x), ch, j["bases"].ctypes.data + lo * L,
                                             (offs[:hi - lo + 1]).ctypes.data, hi - lo, int(j["ag"]), j["b"], cores,
                                             j["out"].ctypes.data + lo * 16, w.ctypes.data,
-                                            j["trace"].ctypes.data + lo * 16)
+                                            j["trace"].ctypes.data + lo * 32)
                 if timed:
                     j["cpu_s"] += time.perf_counter() - t0
         del g, cnt, ix, x
@@ -239,15 +239,20 @@ def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, tr
                                               ">1000": float((reg_of_unique > 1000).mean()) if reg_of_unique.size else 0.0,
                                               ">5000": float((reg_of_unique > 5000).mean()) if reg_of_unique.size else 0.0}}
     # Algorithmic bytes per read of the IMPLEMENTED search.  P probes and C verified
-    # candidates are the reference algorithm's own counts (oracle); per probe the directory/key
-    # search must read one directory pair and one run of entries, per candidate one genome window --
-    # dependent random gathers, which HBM serves in whole 128-byte lines: 2 P + C lines, plus 12 bytes per
-    # candidate for its index entry (the entries of a region are contiguous, so they stream), the packed
-    # read (L/4 bytes) and the 16-byte result.  SURVEY 8(d)'s formula prices the REFERENCE algorithm's
-    # binary-search steps and is kept as `survey_8d`.
+    # candidates are the reference algorithm's own counts (oracle).  Per probe the directory/key
+    # search must read one directory pair and one run of entries: two dependent random gathers, which HBM
+    # serves in whole 128-byte lines.  Per candidate it must read the genome window: for the C_big candidates
+    # of regions of more than 16 slots the index holds the window once more in slot order (dense candidate
+    # windows), so they stream at 32 bytes per candidate (48 above 110 bases); the other
+    # C - C_big cost a 12-byte entry and one scattered 128-byte line each.  Plus the packed read (L/4 bytes) and
+    # the 16-byte result.  SURVEY 8(d)'s formula prices the REFERENCE algorithm's binary-search steps and is
+    # kept as `survey_8d`.
     table = bool(os.environ.get("WALT_AMD_TABLE", "0") not in ("", "0"))
-    lines = (1.0 if table else 2.0) * P + C
-    bytes_per_read = 128.0 * lines + 12.0 * C + read_len / 4.0 + 16
+    dense_on = os.environ.get("WALT_AMD_WIN", "1") not in ("0",) and read_len <= 174 and args.pattern == 3
+    C_big = float(tu["cands_big"].sum()) / nu if dense_on else 0.0
+    rec_bytes = 32.0 if read_len <= 110 else 48.0
+    lines = (1.0 if table else 2.0) * P + (C - C_big)
+    bytes_per_read = 128.0 * lines + 12.0 * (C - C_big) + rec_bytes * C_big + read_len / 4.0 + 16
     useful = read_len / 4.0 + 16 + P * (8 + 12) + C * (12 + read_len / 4.0 + 8)
     kern_s = float(np.median(leg["map_ms"])) / 1e3
     achieved = bytes_per_read * n / kern_s
@@ -267,10 +272,11 @@ def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, tr
             "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
             "kernel": kernel_name, "kernel_ms_median": kern_s * 1e3, "kernel_ms_min": float(np.min(leg["map_ms"])),
             "algorithmic_bytes_per_read": bytes_per_read,
-            "granularity": "128-byte line per dependent gather (%d per probe, 1 per candidate) + 12-byte entry per "
-                           "candidate + streamed read/result bytes" % (1 if table else 2),
+            "granularity": "128-byte line per dependent gather (%d per probe, 1 per candidate outside the dense windows) + "
+                           "12-byte entry / %d-byte dense record per candidate + streamed read/result bytes" % (
+                               1 if table else 2, int(rec_bytes)),
             "useful_bytes_per_read": useful,
-            "per_read": {"probes": P, "search_steps": S, "candidates": C},
+            "per_read": {"probes": P, "search_steps": S, "candidates": C, "candidates_in_regions_gt16": C_big},
             "per_read_source": "oracle counters on this run's uniform sample",
             "survey_8d": {"bytes_per_read": survey, "achieved": survey * n / kern_s / 1e9,
                           "frac": survey * n / kern_s / HBM_PEAK,
@@ -420,7 +426,7 @@ def oracle_pe_jobs(cx, idx, jobs, lens):
             j["cpu_s"] += time.perf_counter() - t0
             j["ranked"].append(r)
             j["counts"].append(c)
-            j["works"].append((float(work[0]["probes"]), float(work[0]["cands"])))
+            j["works"].append((float(work[0]["probes"]), float(work[0]["cands"]), float(work[0]["cands_big"])))
         del keep, arr
     for j in jobs:
         m, L = j["m"], j["read_len"]
@@ -463,12 +469,16 @@ def pe_report(cx, args, leg, job, n, read_len, sel_all, nu, traffic_key):
                      "host memory at a time" % (nu, m_all - nu),
            "bit_exact_vs_gpu": bool(same)}
     # Same accounting as the single-end line: per pair, P probes and C candidates over both mates (oracle
-    # counters) -> 2 P + C dependent gathers of one 128-byte line each + 12-byte entries, plus per mate the
-    # ranked list written by the top-k kernel and read back by the merge (one line each way), the packed reads and
-    # the 64-byte pair record.  Time = the whole step (the mates' kernels overlap on several streams).
+    # counters) -> 2 P dependent gathers of one 128-byte line each; a candidate of a region of more than 16 slots
+    # streams as a dense record (32 bytes, 48 above 110 bases), any other costs a 12-byte entry and a scattered
+    # 128-byte line; plus per mate the ranked list written by the top-k kernel and read back by the merge (one
+    # line each way), the packed reads and the 64-byte pair record.  Time = the whole step (the mates' kernels
+    # overlap on several streams).
     P = sum(w[0] for w in job["works"]) / m_all
     C = sum(w[1] for w in job["works"]) / m_all
-    bytes_per_pair = 128.0 * (2.0 * P + C + 4.0) + 12.0 * C + 2 * read_len / 4.0 + 64
+    C_big = sum(w[2] for w in job["works"]) / m_all if (os.environ.get("WALT_AMD_WIN", "1") != "0" and read_len <= 174) else 0.0
+    rec_bytes = 32.0 if read_len <= 110 else 48.0
+    bytes_per_pair = 128.0 * (2.0 * P + (C - C_big) + 4.0) + 12.0 * (C - C_big) + rec_bytes * C_big + 2 * read_len / 4.0 + 64
     step_s = float(np.median(leg["per_step"]))
     traffic = None
     try:
@@ -484,9 +494,10 @@ def pe_report(cx, args, leg, job, n, read_len, sel_all, nu, traffic_key):
             "kernel": "whole paired-end step (k_pe_topk_dual + list kernels of both mates, k_pe_merge)",
             "step_ms_median": step_s * 1e3, "step_ms_min": float(np.min(leg["per_step"])) * 1e3,
             "algorithmic_bytes_per_pair": bytes_per_pair,
-            "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate, 2 per mate for the ranked "
-                           "list) + 12-byte entry per candidate + streamed reads / pair record",
-            "per_pair": {"probes": P, "candidates": C}}
+            "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate outside the dense windows, 2 per "
+                           "mate for the ranked list) + 12-byte entry / %d-byte dense record per candidate + streamed reads / "
+                           "pair record" % int(rec_bytes),
+            "per_pair": {"probes": P, "candidates": C, "candidates_in_regions_gt16": C_big}}
     return cpu, roof
 
 
@@ -663,7 +674,7 @@ def worker(args):
             jobs.append({"bases": d_bases.view(n, args.read_len)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
                          "read_len": args.read_len, "max_mm": args.max_mismatches, "b": args.bucket, "ag": args.ag,
                          "timed_first": int(uni.numel()), "sel": sel, "leg": leg, "n": n, "nu": int(uni.numel()),
-                         "traffic_key": "se%d" % args.read_len, "kernel": "k_map_se<%d> (+ literal pass)" % (7 if args.read_len <= 112 else 10),
+                         "traffic_key": "se%d%s" % (args.read_len, "ag" if args.ag else ""), "kernel": "k_map_se<%d> (+ literal pass)" % (7 if args.read_len <= 112 else 10),
                          "target": out})
         # ---- extra leg on the same index: 150 bp single-end at -m 10 (configs[4]'s read length on the C->T side)
         leg150 = None

@@ -139,6 +139,7 @@ typedef struct {
   uint64_t steps;
   uint64_t cands;
   uint64_t too_short;
+  uint64_t cands_big;  // of cands: those in regions of more than 16 slots
 } orc_work;
 
 // Optional per-read trace (bench.py: which sampled reads met large regions / the -b cap), accumulated over
@@ -148,6 +149,8 @@ typedef struct {
   uint32_t cands;       // candidates verified
   uint32_t max_region;  // largest region met, skipped ones included
   uint32_t over_b;      // regions skipped by the -b cap (mapping.cpp:275-277)
+  uint32_t cands_big;   // of cands: those in regions of more than 16 slots (bench.py prices them as streamed records)
+  uint32_t pad_[3];
 } orc_trace;
 
 static inline uint8_t gat(const orc_strand* x, uint64_t pos) {
@@ -300,7 +303,8 @@ void orc_se_map_read_trace(const orc_strand* x, const char* org_read, uint32_t r
       gp -= seed_i;
       if (gp + read_len >= x->start_index[chr + 1]) continue;      // 285-286
       ++work->cands;
-      if (tr) ++tr->cands;
+      if (second - first + 1 > 16) ++work->cands_big;
+      if (tr) { ++tr->cands; if (second - first + 1 > 16) ++tr->cands_big; }
       uint32_t mm = orc_count_mm(x, read, read_len, gp, seed_i, repeats, best->mismatch);
       if (mm < best->mismatch) {                                   // 306-313
         best->genome_pos = gp; best->times = 1; best->strand = strand; best->mismatch = mm;
@@ -325,20 +329,20 @@ void orc_se_map_batch(const orc_strand* strands /*[2]*/, const char* bases,
     out[j].pad_[0] = out[j].pad_[1] = out[j].pad_[2] = 0;
     out[j].mismatch = max_mm;
   }
-  orc_work total = {0, 0, 0, 0};
+  orc_work total = {0, 0, 0, 0, 0};
   if (threads < 1) threads = 1;
   for (int fi = 0; fi < 2; ++fi) {
     const orc_strand* x = &strands[fi];
     char strand = fi == 0 ? '+' : '-';
-    uint64_t p = 0, s = 0, c = 0, t = 0;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 256) reduction(+ : p, s, c, t)
+    uint64_t p = 0, s = 0, c = 0, t = 0, g = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 256) reduction(+ : p, s, c, t, g)
     for (int64_t j = 0; j < (int64_t)n; ++j) {
-      orc_work w = {0, 0, 0, 0};
+      orc_work w = {0, 0, 0, 0, 0};
       orc_se_map_read(x, bases + offsets[j], (uint32_t)(offsets[j + 1] - offsets[j]), strand,
                       ag_wildcard, b, &out[j], &w);
-      p += w.probes; s += w.steps; c += w.cands; t += w.too_short;
+      p += w.probes; s += w.steps; c += w.cands; t += w.too_short; g += w.cands_big;
     }
-    total.probes += p; total.steps += s; total.cands += c; total.too_short += t;
+    total.probes += p; total.steps += s; total.cands += c; total.too_short += t; total.cands_big += g;
   }
   if (work_out) *work_out = total;
 }
@@ -367,16 +371,16 @@ void orc_se_map_strand_trace(const orc_strand* x, char strand, const char* bases
                              orc_work* work_out, orc_trace* trace) {
   orc_tables_init();
   if (threads < 1) threads = 1;
-  uint64_t p = 0, s = 0, c = 0, t = 0;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 256) reduction(+ : p, s, c, t)
+  uint64_t p = 0, s = 0, c = 0, t = 0, g = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 256) reduction(+ : p, s, c, t, g)
   for (int64_t j = 0; j < (int64_t)n; ++j) {
-    orc_work w = {0, 0, 0, 0};
+    orc_work w = {0, 0, 0, 0, 0};
     orc_se_map_read_trace(x, bases + offsets[j], (uint32_t)(offsets[j + 1] - offsets[j]), strand, ag_wildcard, b,
                           &out[j], &w, trace ? &trace[j] : NULL);
-    p += w.probes; s += w.steps; c += w.cands; t += w.too_short;
+    p += w.probes; s += w.steps; c += w.cands; t += w.too_short; g += w.cands_big;
   }
   if (work_out) {
-    work_out->probes += p; work_out->steps += s; work_out->cands += c; work_out->too_short += t;
+    work_out->probes += p; work_out->steps += s; work_out->cands += c; work_out->too_short += t; work_out->cands_big += g;
   }
 }
 
@@ -428,6 +432,7 @@ static void orc_pe_map_read(const orc_strand* x, const char* org_read, uint32_t 
       gp -= seed_i;
       if (gp + read_len >= x->start_index[chr + 1]) continue;
       ++work->cands;
+      if (second - first + 1 > 16) ++work->cands_big;
       uint32_t mm = orc_count_mm(x, read, read_len, gp, seed_i, repeats, cur_max);
       if (mm > max_mm) continue;                                   // 192-194
       orc_cand c; c.genome_pos = gp; c.strand = strand; c.pad_[0] = c.pad_[1] = c.pad_[2] = 0;
@@ -449,20 +454,20 @@ void orc_pe_topk_batch(const orc_strand* strands /*[2]*/, const char* bases,
                        uint32_t* ranked_n, orc_work* work_out) {
   orc_tables_init();
   if (threads < 1) threads = 1;
-  uint64_t p = 0, s = 0, c = 0, t = 0;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 64) reduction(+ : p, s, c, t)
+  uint64_t p = 0, s = 0, c = 0, t = 0, g = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 64) reduction(+ : p, s, c, t, g)
   for (int64_t j = 0; j < (int64_t)n; ++j) {
     OrcTop top; top.max_size = top_k;
-    orc_work w = {0, 0, 0, 0};
+    orc_work w = {0, 0, 0, 0, 0};
     for (int fi = 0; fi < 2; ++fi)
       orc_pe_map_read(&strands[fi], bases + offsets[j], (uint32_t)(offsets[j + 1] - offsets[j]),
                       fi == 0 ? '+' : '-', ag_wildcard, max_mm, b, &top, &w);
     uint32_t k = 0;
     while (!top.pq.empty()) { ranked[(uint64_t)j * top_k + k++] = top.pq.top(); top.pq.pop(); }
     ranked_n[j] = k;
-    p += w.probes; s += w.steps; c += w.cands; t += w.too_short;
+    p += w.probes; s += w.steps; c += w.cands; t += w.too_short; g += w.cands_big;
   }
-  if (work_out) { work_out->probes = p; work_out->steps = s; work_out->cands = c; work_out->too_short = t; }
+  if (work_out) { work_out->probes = p; work_out->steps = s; work_out->cands = c; work_out->too_short = t; work_out->cands_big = g; }
 }
 
 // ForwardChromPosition, paired.cpp:98-104.

@@ -31,8 +31,9 @@ pair_dtype = np.dtype([("m1", best_dtype), ("m2", best_dtype), ("best_times", "<
                        ("best_i", "<i4"), ("best_j", "<i4"), ("pair_mm", "<u4")])
 hpair_dtype = np.dtype([("m1", best_dtype), ("m2", best_dtype), ("best_times", "<u4"), ("frag_len", "<i4"),
                         ("best_i", "<i4"), ("best_j", "<i4"), ("pair_mm", "<u4"), ("pad", "V12")])
-work_dtype = np.dtype([("probes", "<u8"), ("steps", "<u8"), ("cands", "<u8"), ("too_short", "<u8")])
-trace_dtype = np.dtype([("probes", "<u4"), ("cands", "<u4"), ("max_region", "<u4"), ("over_b", "<u4")])  # orc_trace
+work_dtype = np.dtype([("probes", "<u8"), ("steps", "<u8"), ("cands", "<u8"), ("too_short", "<u8"), ("cands_big", "<u8")])
+trace_dtype = np.dtype([("probes", "<u4"), ("cands", "<u4"), ("max_region", "<u4"), ("over_b", "<u4"), ("cands_big", "<u4"),
+                        ("pad", "V12")])  # orc_trace
 
 
 def _newer(target, sources):

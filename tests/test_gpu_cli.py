@@ -52,6 +52,28 @@ def test_cli_output_files_identical_to_reference(cli_index, scratch, case):
             assert False, "%s/%s differs" % (case, fn)
 
 
+@pytest.mark.parametrize("case", ["se_sam_au_N100", "se_ag_mr_au", "se_clip_mr_au_N100", "pe_sam_au_N250", "pe_mr_au", "pe150_sam_au_m10"])
+def test_cli_several_gpus_share_each_batch(cli_index, scratch, case):
+    """-g 0,0: two index replicas (here on the one GPU of the box), every -N batch cut into two contiguous shares
+    after the loader's N replacement, mapped side by side, records back in read order, statistics added on the
+    host: the files must still be the reference's, byte for byte."""
+    info = META["cases"][case]
+    wd = os.path.join(scratch, "cli2_" + case)
+    os.makedirs(wd, exist_ok=True)
+    out = os.path.join(wd, "out.sam" if "-sam" in info["args"] else "out.mr")
+    cmd = [WALT_BIN, "-i", cli_index, "-o", out, "-g", "0,0", "-t", "5"] + list(info["args"])
+    kind = info["kind"]
+    if kind.startswith("pe"):
+        cmd += ["-1", os.path.join(refio.GOLDEN, kind + "_1.fastq"), "-2", os.path.join(refio.GOLDEN, kind + "_2.fastq")]
+    else:
+        cmd += ["-r", os.path.join(refio.GOLDEN, kind + ".fastq")]
+    subprocess.run(cmd, check=True, cwd=wd, stderr=subprocess.DEVNULL)
+    assert sorted(os.listdir(wd)) == sorted(info["files"])
+    for fn in info["files"]:
+        with open(os.path.join(wd, fn)) as f:
+            assert f.read() == refio.golden_file(case, fn), "%s/%s differs with -g 0,0" % (case, fn)
+
+
 def test_cli_rejects_bad_arguments(cli_index, scratch):
     r = subprocess.run([WALT_BIN, "-i", cli_index, "-r", os.path.join(refio.GOLDEN, "se_ct.fastq"), "-o",
                         os.path.join(scratch, "x.sam"), "-k", "1"], capture_output=True, text=True)

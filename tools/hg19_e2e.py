@@ -66,10 +66,14 @@ def run_timed(cmd):
     dt = time.perf_counter() - t0
     if p.returncode != 0:
         raise SystemExit("command failed (%d): %s\n%s" % (p.returncode, " ".join(cmd), p.stdout[-2000:]))
-    for ln in p.stdout.splitlines():
-        if ln.startswith("[walt_amd"):
-            log(ln)
+    global LAST_STAGES
+    LAST_STAGES = [ln for ln in p.stdout.splitlines() if ln.startswith("[walt_amd")]
+    for ln in LAST_STAGES:
+        log(ln)
     return dt
+
+
+LAST_STAGES = []
 
 
 def main():
@@ -83,6 +87,9 @@ def main():
     ap.add_argument("--sam", action="store_true")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gpu-reads", type=int, default=0,
+                    help="an additional run of bin/walt alone on this many reads (the reference would take minutes): end-to-end rate")
+    ap.add_argument("--batch", type=int, default=10_000_000, help="-N of the additional run")
     args = ap.parse_args()
 
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -168,6 +175,24 @@ def main():
             res["main_bytes"] = os.path.getsize(os.path.join(scratch, "%s_ref.out" % tag))
             res["mapstats"] = open(os.path.join(scratch, "%s_ref.out.mapstats" % tag)).read().split("\n")[:8]
             out[tag] = res
+        if args.gpu_reads:
+            # bin/walt alone on a larger input: several -N batches, so the loader's prefetch and the persistent device
+            # buffers matter; rate = reads / (wall - index load), stage times from -v
+            n_big = args.gpu_reads
+            if pe:
+                b1, b2, _ = synth.make_pairs(torch, dev, synth.make_genome(torch, dev, scale, seed=2, kind=args.genome)[0], n_big, args.read_len, seed=1001)
+                h1, h2 = b1.cpu().numpy(), b2.cpu().numpy()
+                del b1, b2
+            else:
+                b1, _ = synth.make_reads(torch, dev, synth.make_genome(torch, dev, scale, seed=2, kind=args.genome)[0], n_big, args.read_len, seed=1001)
+                h1 = b1.cpu().numpy()
+                del b1
+            torch.cuda.empty_cache()
+            inp = files(n_big, "big")
+            o = os.path.join(scratch, "big_gpu.out")
+            dt = run_timed([our_bin] + inp + ["-o", o] + common + ["-v", "-N", str(args.batch)])
+            out["gpu_only"] = {"reads": n_big, "wall_s": round(dt, 2), "batch": args.batch, "stages": LAST_STAGES,
+                               "output_bytes": os.path.getsize(o)}
         if args.small:
             dn = args.reads - args.small
             for who in ("gpu", "ref"):

@@ -40,7 +40,29 @@ struct walt_index {
   hipStream_t pe_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   hipEvent_t pe_fork[2] = {nullptr, nullptr}, pe_join[2] = {nullptr, nullptr}, pe_done[2] = {nullptr, nullptr};
   hipEvent_t pe_start = nullptr;
+  // device buffers of the host-buffer entry points (walt_map_se_batch / walt_map_pe_batch), kept between calls and
+  // grown on demand: the reference's driver calls once per -N batch (mapping.cpp:479-517), and a hipMalloc /
+  // hipFree pair per buffer and call costs milliseconds each.  One call at a time per index.
+  void* host_api_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t host_api_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+namespace walt {
+// grow-only device buffer `slot` of idx (freed by walt_index_close)
+inline hipError_t host_api_buffer(walt_index* idx, int slot, size_t bytes, void** out) {
+  if (idx->host_api_cap[slot] < bytes) {
+    if (idx->host_api_buf[slot]) (void)hipFree(idx->host_api_buf[slot]);
+    idx->host_api_buf[slot] = nullptr;
+    idx->host_api_cap[slot] = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    const hipError_t e = hipMalloc(&idx->host_api_buf[slot], want);
+    if (e != hipSuccess) return e;
+    idx->host_api_cap[slot] = want;
+  }
+  *out = idx->host_api_buf[slot];
+  return hipSuccess;
+}
+}  // namespace walt
 
 namespace walt {
 

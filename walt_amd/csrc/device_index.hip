@@ -929,6 +929,8 @@ void walt_index_close(walt_index* idx) {
   if (!idx) return;
   hipSetDevice(idx->device);
   for (void* p : idx->allocs) hipFree(p);
+  for (void* p : idx->host_api_buf)
+    if (p) hipFree(p);
   for (int i = 0; i < 3; ++i)
     if (idx->ev[i]) hipEventDestroy(idx->ev[i]);
   for (int k = 0; k < 2; ++k) {

@@ -17,12 +17,14 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/walt_amd.h"
@@ -46,11 +48,19 @@ struct Options {
   string index_file, se_csv, pe1_csv, pe2_csv, out_csv, adaptor;
   bool sam = false, ambiguous = false, unmapped = false, ag = false, verbose = false, pbat = false;
   uint32_t max_mismatches = 6, batch_size = 10000000, b = 5000, top_k = 50;
-  int frag_range = 1000, threads = 0, device = 0;
+  int frag_range = 1000, threads = 0;
+  std::vector<int> devices;  // -g 0,1,...: every listed GPU holds an index replica and maps a contiguous share of each batch
 };
 
 static bool is_opt(const string& a, const char* s, const char* l) { return a == string("-") + s || a == string("-") + l || a == string("--") + l; }
 
+static vector<string> split_csv(const string& s) {
+  vector<string> out;
+  std::istringstream is(s);
+  string tok;
+  while (std::getline(is, tok, ',')) if (!tok.empty()) out.push_back(tok);
+  return out;
+}
 static Options parse(int argc, const char** argv) {
   Options o;
   for (int i = 1; i < argc; ++i) {
@@ -77,21 +87,18 @@ static Options parse(int argc, const char** argv) {
     else if (a == "-sam" || a == "--sam") o.sam = true;
     else if (is_opt(a, "v", "verbose")) o.verbose = true;
     else if (is_opt(a, "t", "thread")) o.threads = atoi(val().c_str());
-    else if (is_opt(a, "g", "gpu")) o.device = atoi(val().c_str());  // extension: device ordinal
+    else if (is_opt(a, "g", "gpu")) {  // extension: device ordinal(s), comma separated
+      o.devices.clear();
+      for (const string& t : split_csv(val())) o.devices.push_back(atoi(t.c_str()));
+    }
     else die("unknown option " + a);
   }
   if (o.index_file.empty() || o.out_csv.empty()) die("options -i and -o are required");
+  if (o.devices.empty()) o.devices.push_back(0);
   if (o.pbat && !o.se_csv.empty()) o.ag = true;  // single-end PBAT reads are A-rich: same as -A
   return o;
 }
 
-static vector<string> split_csv(const string& s) {
-  vector<string> out;
-  std::istringstream is(s);
-  string tok;
-  while (std::getline(is, tok, ',')) if (!tok.empty()) out.push_back(tok);
-  return out;
-}
 static bool valid_suffix(const string& fn) {  // walt.cpp:58-64 (checks .fastq / .fq)
   auto ends = [&](const string& sfx) { return fn.size() >= sfx.size() && fn.compare(fn.size() - sfx.size(), sfx.size(), sfx) == 0; };
   return ends(".fastq") || ends(".fq");
@@ -243,14 +250,77 @@ static double now_s() {
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+// ---------------------------------------------------------------- the GPUs of a run (-g)
+// Every device holds a full index replica (opened side by side); a batch is cut into contiguous shares AFTER the
+// loader has replaced its non-ACGT characters (the draws depend on the -N batch, not on the share: mapping.cpp:73),
+// each share is mapped by its device from the same host arrays, and the records land in read order.  The
+// statistics of the shares are added on the host -- this is one process; across processes the same sum is
+// walt_stats_allreduce (include/walt_amd.h).
+struct DeviceSet {
+  vector<int> ids;
+  vector<walt_index*> idx;
+  void open(const Options& o, unsigned strands) {
+    ids = o.devices;
+    idx.assign(ids.size(), nullptr);
+    vector<string> err(ids.size());
+    vector<std::thread> th;
+    for (size_t d = 0; d < ids.size(); ++d)
+      th.emplace_back([&, d]() {
+        if (walt_index_open(o.index_file.c_str(), ids[d], strands, -1, &idx[d]) != WALT_OK) err[d] = walt_last_error();
+      });
+    for (auto& t : th) t.join();
+    for (const string& e : err) if (!e.empty()) { close(); die(e); }
+  }
+  void close() {
+    for (walt_index*& i : idx) { if (i) walt_index_close(i); i = nullptr; }
+  }
+  size_t size() const { return ids.size(); }
+  void share(uint32_t n, size_t d, uint32_t& lo, uint32_t& hi) const {
+    lo = (uint32_t)((uint64_t)n * d / ids.size());
+    hi = (uint32_t)((uint64_t)n * (d + 1) / ids.size());
+  }
+  // fn(d, lo, hi) -> status, run for every device at once; the first failure is reported
+  template <class F>
+  void for_each_share(uint32_t n, F fn) const {
+    if (ids.size() == 1) { uint32_t lo, hi; share(n, 0, lo, hi); if (fn(0, lo, hi) != WALT_OK) die(walt_last_error()); return; }
+    vector<string> err(ids.size());
+    vector<std::thread> th;
+    for (size_t d = 0; d < ids.size(); ++d)
+      th.emplace_back([&, d]() {
+        uint32_t lo, hi;
+        share(n, d, lo, hi);
+        if (hi > lo && fn(d, lo, hi) != WALT_OK) err[d] = walt_last_error();
+      });
+    for (auto& t : th) t.join();
+    for (const string& e : err) if (!e.empty()) die(e);
+  }
+};
+
+// The next batch is read while the current one is mapped and written: the loader runs on its own thread with a
+// share of the host threads (its N draws use rand(), which nothing else in the process calls meanwhile).
+struct Prefetch {
+  std::thread th;
+  std::exception_ptr err;
+  template <class F>
+  void start(F fn) {
+    err = nullptr;
+    th = std::thread([this, fn]() { try { fn(); } catch (...) { err = std::current_exception(); } });
+  }
+  void wait() {
+    if (th.joinable()) th.join();
+    if (err) std::rethrow_exception(err);
+  }
+};
+
 // ProcessSingledEndReads, mapping.cpp:421-526
 static void process_se(const Options& o, const string& reads_file, const string& out_file) {
   const int T = host_threads(o);
+  const int T_bg = std::max(1, T / 4);  // the loader's share while a batch is being formatted
   double t0 = now_s();
-  walt_index* idx = nullptr;
-  check(walt_index_open(o.index_file.c_str(), o.device, o.ag ? WALT_STRANDS_GA : WALT_STRANDS_CT, -1, &idx));
+  DeviceSet dev;
+  dev.open(o, o.ag ? WALT_STRANDS_GA : WALT_STRANDS_CT);
   double t_index = now_s() - t0, t_load = 0, t_map = 0, t_out = 0, t_write = 0;
-  GenomeInfo g = genome_of(idx);
+  GenomeInfo g = genome_of(dev.idx[0]);
   hostio::FastqReader rd;
   rd.open(reads_file, T);
   OutFile fout;
@@ -260,17 +330,24 @@ static void process_se(const Options& o, const string& reads_file, const string&
   SeCounts st;
   if (o.verbose) std::cerr << "input_file: " << reads_file << std::endl << "output_file: " << out_file << std::endl;
   if (o.sam) { string h = sam_head(g); fout.write(h.data(), h.size()); }
-  Batch bt;
+  Batch bt[2];
   walt_best_match* res = nullptr;
   size_t res_cap = 0;
   vector<Sink> sinks((size_t)T * kSinks);
   vector<SeCounts> acc(T);
-  for (;;) {
-    t0 = now_s();
-    rd.load(o.batch_size, o.adaptor, bt);
-    t_load += now_s() - t0;
-    if (bt.n == 0) break;
-    const uint32_t n = bt.n;
+  Prefetch pre;
+  t0 = now_s();
+  rd.load(o.batch_size, o.adaptor, bt[0]);
+  t_load += now_s() - t0;
+  for (int cur = 0;; cur ^= 1) {
+    Batch& b = bt[cur];
+    if (b.n == 0) break;
+    const uint32_t n = b.n;
+    const bool more = n == o.batch_size;  // mapping.cpp:515-516: a short batch is the last one
+    if (more) {
+      rd.threads = T_bg;
+      pre.start([&, cur]() { rd.load(o.batch_size, o.adaptor, bt[cur ^ 1]); });
+    }
     if (res_cap < n) {
       walt_host_free(res);
       res = nullptr;
@@ -278,10 +355,15 @@ static void process_se(const Options& o, const string& reads_file, const string&
       check(walt_host_alloc(res_cap * sizeof(walt_best_match), (void**)&res));
     }
     t0 = now_s();
-    walt_batch_stats bs;
-    check(walt_map_se_batch(idx, bt.bases, bt.offsets, n, o.ag, o.max_mismatches, o.b, res, &bs));
+    vector<uint64_t> short_of(dev.size(), 0);
+    dev.for_each_share(n, [&](size_t d, uint32_t lo, uint32_t hi) {
+      walt_batch_stats bs;
+      const int rc = walt_map_se_batch(dev.idx[d], b.bases, b.offsets + lo, hi - lo, o.ag, o.max_mismatches, o.b, res + lo, &bs);
+      short_of[d] = bs.too_short;
+      return rc;
+    });
+    for (uint64_t v : short_of) st.too_short += (uint32_t)v;
     t_map += now_s() - t0;
-    st.too_short += (uint32_t)bs.too_short;
     t0 = now_s();
 #pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < T; ++t) {
@@ -290,12 +372,12 @@ static void process_se(const Options& o, const string& reads_file, const string&
       SeCounts c;
       const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
       // one allocation per thread and batch instead of doubling: name + 2 x read + fixed fields per line
-      s[kMain].grow((bt.offsets[hi] - bt.offsets[lo]) * 2 + (size_t)(hi - lo) * 96);
+      s[kMain].grow((b.offsets[hi] - b.offsets[lo]) * 2 + (size_t)(hi - lo) * 96);
       for (uint32_t j = lo; j < hi; ++j) {
         c.update(res[j].times);
-        if (!o.sam) out_single_results(res[j], bt.name(j), bt.seq(j), bt.score(j), g, o.ag, side.out_amb, side.out_unm,
+        if (!o.sam) out_single_results(res[j], b.name(j), b.seq(j), b.score(j), g, o.ag, side.out_amb, side.out_unm,
                                        s[kMain], s[kAmb1], s[kUnm1]);
-        else out_single_sam(res[j], bt.name(j), bt.seq(j), bt.score(j), g, side.out_amb, side.out_unm, s[kMain]);
+        else out_single_sam(res[j], b.name(j), b.seq(j), b.score(j), g, side.out_amb, side.out_unm, s[kMain]);
       }
       acc[t] = c;
     }
@@ -306,7 +388,10 @@ static void process_se(const Options& o, const string& reads_file, const string&
     side.amb.write_sinks(sinks, kSinks, kAmb1, T);
     side.unm.write_sinks(sinks, kSinks, kUnm1, T);
     t_write += now_s() - t0;
-    if (n < o.batch_size) break;
+    if (!more) break;
+    t0 = now_s();
+    pre.wait();  // what is still left of the next batch's ingest
+    t_load += now_s() - t0;
   }
   if (o.verbose)
     fprintf(stderr, "[walt_amd ingest: line scan %.2f s, views %.2f s, buffers %.2f s, copy %.2f s, N draws %.2f s]\n",
@@ -324,10 +409,10 @@ static void process_se(const Options& o, const string& reads_file, const string&
     mf.write(ms.p, ms.n);
     mf.close();
   }
-  walt_index_close(idx);
+  dev.close();
   if (o.verbose)
-    fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, format %.2f s, write %.2f s]\n", T,
-            t_index, t_load, t_map, t_out, t_write);
+    fprintf(stderr, "[walt_amd: %d host threads, %zu GPU(s); index %.2f s, ingest not hidden behind the previous batch %.2f s, map %.2f s, "
+            "format %.2f s, write %.2f s]\n", T, dev.size(), t_index, t_load, t_map, t_out, t_write);
 }
 
 // ---------------------------------------------------------------- paired-end writers
@@ -452,11 +537,12 @@ static void process_pe(const Options& o, const string& file1, const string& file
   const string& f2 = pbat ? file1 : file2;  // slot 1: the A-rich mate, mapped on _GA10/_GA11
   const int name_slot = pbat ? 1 : 0;       // paired.cpp:694 prints the -1 file's name for both records
   const int T = host_threads(o);
+  const int T_bg = std::max(1, T / 4);
   double t0 = now_s();
-  walt_index* idx = nullptr;
-  check(walt_index_open(o.index_file.c_str(), o.device, WALT_STRANDS_ALL, -1, &idx));
+  DeviceSet dev;
+  dev.open(o, WALT_STRANDS_ALL);
   double t_index = now_s() - t0, t_load = 0, t_map = 0, t_out = 0;
-  GenomeInfo g = genome_of(idx);
+  GenomeInfo g = genome_of(dev.idx[0]);
   hostio::FastqReader rd[2];
   rd[0].open(f1, T);
   rd[1].open(f2, T);
@@ -473,22 +559,32 @@ static void process_pe(const Options& o, const string& file1, const string& file
   fprintf(stderr, "[MAPPING PAIRED-END READS FROM THE FOLLOWING TWO FILES]\n   %s (AND)\n   %s\n", file1.c_str(), file2.c_str());
   fprintf(stderr, "[OUTPUT MAPPING RESULTS TO %s]\n", out_file.c_str());
   if (o.sam) { string h = sam_head(g); fout.write(h.data(), h.size()); }
-  Batch bt[2];
+  Batch bts[2][2];  // [buffer][mate]: one pair of batches is mapped and written while the next is read
   walt_pair_result* pr = nullptr;
   size_t pr_cap = 0;
   vector<Sink> sinks((size_t)T * kSinks);
   vector<PeAcc> acc(T);
-  for (;;) {
-    t0 = now_s();
-    rd[0].load(o.batch_size, adaptors[0], bt[0]);
-    if (bt[0].n) rd[1].load(o.batch_size, adaptors[1], bt[1]); else bt[1].n = 0;
-    t_load += now_s() - t0;
+  Prefetch pre;
+  auto load_pair = [&](Batch* b) {  // mate 1's file, then mate 2's: each load starts its own srand(0) sequence (paired.cpp:648)
+    rd[0].load(o.batch_size, adaptors[0], b[0]);
+    if (b[0].n) rd[1].load(o.batch_size, adaptors[1], b[1]); else b[1].n = 0;
+  };
+  t0 = now_s();
+  load_pair(bts[0]);
+  t_load += now_s() - t0;
+  for (int cur = 0;; cur ^= 1) {
+    Batch* bt = bts[cur];
     if (bt[0].n && bt[0].n != bt[1].n) {
       fprintf(stderr, "The number of reads in paired-end files should be the same.\n");
       exit(EXIT_FAILURE);
     }
     if (bt[0].n == 0) break;
     const uint32_t n = bt[0].n;
+    const bool more = n == o.batch_size;
+    if (more) {
+      rd[0].threads = rd[1].threads = T_bg;
+      pre.start([&, cur]() { load_pair(bts[cur ^ 1]); });
+    }
     total_pairs += n;
     if (pr_cap < n) {
       walt_host_free(pr);
@@ -497,13 +593,18 @@ static void process_pe(const Options& o, const string& file1, const string& file
       check(walt_host_alloc(pr_cap * sizeof(walt_pair_result), (void**)&pr));
     }
     t0 = now_s();
-    walt_batch_stats bs[2];
     // the best pair's two candidates come back inside walt_pair_result (m1/m2), so the ranked lists stay on the GPU
-    check(walt_map_pe_batch(idx, bt[0].bases, bt[0].offsets, bt[1].bases, bt[1].offsets, n, o.max_mismatches, o.b,
-                            o.top_k, o.frag_range, pr, nullptr, nullptr, nullptr, nullptr, bs));
+    vector<uint64_t> short1(dev.size(), 0), short2(dev.size(), 0);
+    dev.for_each_share(n, [&](size_t d, uint32_t lo, uint32_t hi) {
+      walt_batch_stats bs[2];
+      const int rc = walt_map_pe_batch(dev.idx[d], bt[0].bases, bt[0].offsets + lo, bt[1].bases, bt[1].offsets + lo, hi - lo,
+                                       o.max_mismatches, o.b, o.top_k, o.frag_range, pr + lo, nullptr, nullptr, nullptr, nullptr, bs);
+      short1[d] = bs[0].too_short;
+      short2[d] = bs[1].too_short;
+      return rc;
+    });
+    for (size_t d = 0; d < dev.size(); ++d) { st1.too_short += (uint32_t)short1[d]; st2.too_short += (uint32_t)short2[d]; }
     t_map += now_s() - t0;
-    st1.too_short += (uint32_t)bs[0].too_short;
-    st2.too_short += (uint32_t)bs[1].too_short;
     t0 = now_s();
 #pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < T; ++t) {
@@ -558,7 +659,10 @@ static void process_pe(const Options& o, const string& file1, const string& file
     side2.amb.write_sinks(sinks, kSinks, kAmb2, T);
     side2.unm.write_sinks(sinks, kSinks, kUnm2, T);
     t_out += now_s() - t0;
-    if (n < o.batch_size) break;
+    if (!more) break;
+    t0 = now_s();
+    pre.wait();
+    t_load += now_s() - t0;
   }
   rd[0].close(); rd[1].close();
   fout.close();
@@ -589,16 +693,16 @@ static void process_pe(const Options& o, const string& file1, const string& file
     mf.write(ms.p, ms.n);
     mf.close();
   }
-  walt_index_close(idx);
+  dev.close();
   if (o.verbose)
-    fprintf(stderr, "[walt_amd: %d host threads; index %.2f s, ingest %.2f s, map %.2f s, output %.2f s]\n", T, t_index,
-            t_load, t_map, t_out);
+    fprintf(stderr, "[walt_amd: %d host threads, %zu GPU(s); index %.2f s, ingest not hidden behind the previous batch %.2f s, map %.2f s, "
+            "output %.2f s]\n", T, dev.size(), t_index, t_load, t_map, t_out);
 }
 
 int main(int argc, const char** argv) {
   try {
     if (argc == 1) {
-      fprintf(stderr, "Usage: walt -i <index> -r <reads> | -1 <reads1> -2 <reads2> -o <out> [-m -N -a -u -C -A -P -b -k -L -sam -v -t -g]\n");
+      fprintf(stderr, "Usage: walt -i <index> -r <reads> | -1 <reads1> -2 <reads2> -o <out> [-m -N -a -u -C -A -P -b -k -L -sam -v -t -g <gpu>[,<gpu>...]]\n");
       return EXIT_SUCCESS;
     }
     Options o = parse(argc, argv);

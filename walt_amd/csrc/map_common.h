@@ -80,6 +80,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+// exclusive prefix sum over the lanes (and the total, in every lane)
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t lane, uint32_t& total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, off);
+    x += lane >= (uint32_t)off ? y : 0u;
+  }
+  total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  return x - v;
+}
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {  // lane is wave-uniform
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }

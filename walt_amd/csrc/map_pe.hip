@@ -50,7 +50,7 @@ static inline uint32_t pe_chunk_pairs(uint32_t n, uint32_t top_k) {
   }
   return n < c ? n : (uint32_t)c;
 }
-constexpr uint32_t kCoopUnroll = 4;    // 64-candidate groups of a large region verified per step
+constexpr uint32_t kCoopUnroll = 2;    // 64-candidate groups of a large region verified per step (4 cost a wave per SIMD in registers)
 
 // One read per lane.  LITERAL as in map_se.hip: pass 1 defers reads that hit a
 // BAD bucket, pass 2 maps them from scratch (their heap restarts empty).
@@ -271,6 +271,11 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
     }
     pp.ne = (need && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
     pm.ne = (need && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
+    if (pp.ne > kScanMax || pm.ne > kScanMax) {  // a long slot (repeat family): searched by the list kernel, not here
+      cplx = true;
+      mappable = false;
+      pp.ne = pm.ne = 0;
+    }
     probe_entries(svp, pp);
     probe_entries(svm, pm);
     Lookup lp, lm;
@@ -860,38 +865,33 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
   WALT_HIP(hipSetDevice(idx->device));
   const char* bases[2] = {bases1, bases2};
   void *d_bases[2] = {nullptr, nullptr}, *d_off[2] = {nullptr, nullptr}, *d_out = nullptr, *d_stats = nullptr, *d_ws = nullptr;
-  auto cleanup = [&]() {
-    for (int m = 0; m < 2; ++m) { hipFree(d_bases[m]); hipFree(d_off[m]); }
-    hipFree(d_out); hipFree(d_stats); hipFree(d_ws);
-  };
   hipError_t e = hipSuccess;
   for (int m = 0; m < 2 && e == hipSuccess; ++m) {
     const uint64_t nbytes = offs[m][n] - offs[m][0];
-    std::vector<uint64_t> rel(n + 1);
-    for (uint32_t i = 0; i <= n; ++i) rel[i] = offs[m][i] - offs[m][0];
-    if ((e = hipMalloc(&d_bases[m], nbytes + 16)) != hipSuccess) break;
-    if ((e = hipMalloc(&d_off[m], (n + 1) * sizeof(uint64_t))) != hipSuccess) break;
+    const uint64_t* off_src = offs[m];
+    std::vector<uint64_t> rel;
+    if (offs[m][0] != 0) {  // a slice of a larger batch (several devices share one)
+      rel.resize((size_t)n + 1);
+      for (uint32_t i = 0; i <= n; ++i) rel[i] = offs[m][i] - offs[m][0];
+      off_src = rel.data();
+    }
+    if ((e = host_api_buffer(idx, m, nbytes + 16, &d_bases[m])) != hipSuccess) break;
+    if ((e = host_api_buffer(idx, 2 + m, ((size_t)n + 1) * sizeof(uint64_t), &d_off[m])) != hipSuccess) break;
     if ((e = hipMemcpy(d_bases[m], bases[m] + offs[m][0], nbytes, hipMemcpyHostToDevice)) != hipSuccess) break;
-    e = hipMemcpy(d_off[m], rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+    e = hipMemcpy(d_off[m], off_src, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
   }
   const uint32_t chunk = pe_chunk_pairs(n, top_k);
   const size_t ws_bytes = carve_pe(nullptr, chunk, nw, top_k, max_len).total_bytes;
-  if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * sizeof(walt_pair_result));
-  if (e == hipSuccess) e = hipMalloc(&d_stats, 2 * sizeof(walt_batch_stats));
-  if (e == hipSuccess) e = hipMalloc(&d_ws, ws_bytes);
+  if (e == hipSuccess) e = host_api_buffer(idx, 4, (size_t)n * sizeof(walt_pair_result), &d_out);
+  if (e == hipSuccess) e = host_api_buffer(idx, 5, 2 * sizeof(walt_batch_stats), &d_stats);
+  if (e == hipSuccess) e = host_api_buffer(idx, 6, ws_bytes, &d_ws);
   if (e == hipSuccess) e = hipMemset(d_stats, 0, 2 * sizeof(walt_batch_stats));
-  if (e != hipSuccess) {
-    cleanup();
-    return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
-  }
+  if (e != hipSuccess) return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
   PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k, max_len);
-  if ((rc = pe_streams(idx))) { cleanup(); return rc; }
+  if ((rc = pe_streams(idx))) return rc;
   e = hipMemset(w.err, 0, 128 * sizeof(uint32_t));
   for (int m = 0; m < 2 && e == hipSuccess; ++m) e = hipMemset(w.shards[m], 0, kStatShardBytes);
-  if (e != hipSuccess) {
-    cleanup();
-    return fail(WALT_EHIP, std::string("workspace setup failed: ") + hipGetErrorString(e));
-  }
+  if (e != hipSuccess) return fail(WALT_EHIP, std::string("workspace setup failed: ") + hipGetErrorString(e));
   for (uint32_t start = 0; start < n && !rc; start += chunk) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;
     rc = pe_chunk(idx, reinterpret_cast<const uint8_t*>(d_bases[0]), reinterpret_cast<const uint64_t*>(d_off[0]) + start,
@@ -917,7 +917,6 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     if (!rc && stats && hipMemcpy(stats, d_stats, 2 * sizeof(walt_batch_stats), hipMemcpyDeviceToHost) != hipSuccess)
       rc = fail(WALT_EHIP, "download of the statistics failed");
   }
-  cleanup();
   return rc;
 }
 

@@ -376,10 +376,22 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       if (need_p) atomicAdd(&st.buf[14], 1ull);  // probes checked
     }
     if (bad_p || bad_m) {
-      deferred = true;
-      mappable = false;
-      need_p = need_m = false;
-      defer_iter = seed_i + (bad_p ? 0u : 3u);
+      if constexpr (!HEAVY) {
+        // a filter hit is a SUPERSET of the dangerous probes (1.3 % of the reads of a 93-sequence genome against
+        // ~0.3 % truly dangerous ones): the heavy pass applies the exact test before anything goes to the literal pass
+        heavy = true;
+        mappable = false;
+        need_p = need_m = false;
+      } else {
+        const bool dng_p = bad_p && probe_is_dangerous(svp, care, seed_len_of(lr.repeats));
+        const bool dng_m = bad_m && probe_is_dangerous(svm, care, seed_len_of(lr.repeats));
+        if (dng_p || dng_m) {
+          deferred = true;
+          mappable = false;
+          need_p = need_m = false;
+          defer_iter = seed_i + (dng_p ? 0u : 3u);
+        }
+      }
     }
     stamp(st, 2);
     pp.ne = (need_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
@@ -977,26 +989,27 @@ int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offset
   }
   const uint64_t nbytes = offsets[n] - offsets[0];
   void *d_bases = nullptr, *d_off = nullptr, *d_out = nullptr, *d_stats = nullptr, *d_ws = nullptr;
-  auto cleanup = [&]() {
-    hipFree(d_bases); hipFree(d_off); hipFree(d_out); hipFree(d_stats); hipFree(d_ws);
-  };
   int rc = WALT_OK;
   hipError_t e;
-  std::vector<uint64_t> rel(n + 1);
-  for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
-  if ((e = hipMalloc(&d_bases, nbytes + 16)) != hipSuccess || (e = hipMalloc(&d_off, (n + 1) * sizeof(uint64_t))) != hipSuccess ||
-      (e = hipMalloc(&d_out, (size_t)n * sizeof(walt_best_match))) != hipSuccess ||
-      (e = hipMalloc(&d_stats, sizeof(walt_batch_stats))) != hipSuccess ||
-      (e = hipMalloc(&d_ws, walt_se_workspace_bytes(n, max_len))) != hipSuccess) {
-    cleanup();
+  // offsets as the kernels want them: relative to the first read of the batch (a caller that shards a batch
+  // over several devices passes a slice of its offsets array)
+  const uint64_t* off_src = offsets;
+  std::vector<uint64_t> rel;
+  if (offsets[0] != 0) {
+    rel.resize((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
+    off_src = rel.data();
+  }
+  if ((e = host_api_buffer(idx, 0, nbytes + 16, &d_bases)) != hipSuccess ||
+      (e = host_api_buffer(idx, 1, ((size_t)n + 1) * sizeof(uint64_t), &d_off)) != hipSuccess ||
+      (e = host_api_buffer(idx, 2, (size_t)n * sizeof(walt_best_match), &d_out)) != hipSuccess ||
+      (e = host_api_buffer(idx, 3, sizeof(walt_batch_stats), &d_stats)) != hipSuccess ||
+      (e = host_api_buffer(idx, 4, walt_se_workspace_bytes(n, max_len), &d_ws)) != hipSuccess)
     return fail(WALT_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
-  }
-  if ((e = hipMemcpy(d_bases, bases + offsets[0], nbytes, hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(d_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemset(d_stats, 0, sizeof(walt_batch_stats))) != hipSuccess) {
-    cleanup();
+  if ((e = hipMemcpyAsync(d_bases, bases + offsets[0], nbytes, hipMemcpyHostToDevice, nullptr)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_off, off_src, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr)) != hipSuccess ||
+      (e = hipMemsetAsync(d_stats, 0, sizeof(walt_batch_stats), nullptr)) != hipSuccess)
     return fail(WALT_EHIP, std::string("upload failed: ") + hipGetErrorString(e));
-  }
   rc = map_se_device(idx, d_bases, d_off, n, max_len, ag_wildcard, max_mismatches, b, d_out, d_stats, d_ws, nullptr);
   if (!rc) rc = check_read_errors(d_ws, nullptr);
   if (!rc) {
@@ -1005,7 +1018,6 @@ int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offset
     walt_batch_stats st;
     if (!rc && hipMemcpy(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess && stats) *stats = st;
   }
-  cleanup();
   return rc;
 }
 
