@@ -137,13 +137,14 @@ def se_leg(cx, idx, d_bases, d_off, n, read_len, max_mm, b, ag, steps, warmup, t
     st = d_stats.cpu().numpy() // (warmup + steps)  # walt_batch_stats of ONE step
     ctl = d_ws[:64 * 4].view(torch.int32).cpu().numpy()
     n_def = int(ctl[32])
+    n_heavy = int(ctl[56])  # reads pass 1 handed to the heavy pass (map_se.hip: heavy_count = control word 24)
     # deferred list of the last step (workspace layout of map_se.hip: control words, statistic shards, list)
     deferred = None
     if n_def and cx.pattern == 3:
         off = 64 * 4 + 256 * 16 * 8
         deferred = (d_ws[off:off + 4 * n_def].view(torch.int32) & 0x0FFFFFFF).long()
     return {"elapsed": elapsed, "pack_ms": pack_ms, "map_ms": map_ms, "d_out": d_out, "stats": st, "deferred": deferred,
-            "n_deferred": n_def, "d_ws": d_ws}
+            "n_deferred": n_def, "n_heavy": n_heavy, "d_ws": d_ws}
 
 
 def se_sample(cx, leg, n, n_uniform, n_hard):
@@ -635,8 +636,8 @@ def worker(args):
                 if int(os.environ.get("WALT_AMD_ABLATE", "0")) & 8:
                     log("danger-filter self-check: %d probe pairs checked, %d dangerous probes NOT flagged by the filter "
                         "(must be 0)" % (buf[14], buf[15]))
-        log("deferred to the literal pass: %d reads; kernel ms/step: pack %.2f map %.2f (median)" % (
-            leg["n_deferred"], float(np.median(leg["pack_ms"])), float(np.median(leg["map_ms"]))))
+        log("heavy pass: %d reads, literal pass: %d reads; kernel ms/step: pack %.2f map %.2f (median)" % (
+            leg["n_heavy"], leg["n_deferred"], float(np.median(leg["pack_ms"])), float(np.median(leg["map_ms"]))))
         log("device counters per step: probes %.2f, candidates %.2f per read, %d wave-cooperative regions" % (
             leg["stats"][1] / n, leg["stats"][2] / n, leg["stats"][3]))
         if rank == 0:
@@ -663,6 +664,7 @@ def worker(args):
                               "map_se_min": float(np.min(leg["map_ms"])), "map_se_max": float(np.max(leg["map_ms"]))},
                 "device_counters_per_read": {"probes": float(leg["stats"][1]) / n, "candidates": float(leg["stats"][2]) / n,
                                              "wave_cooperative_regions_per_step": int(leg["stats"][3]),
+                                             "heavy_pass_reads": int(leg["n_heavy"]),
                                              "deferred_to_literal_pass": int(leg["n_deferred"])},
             }
             if c_abi:

@@ -568,6 +568,77 @@ WALT_HD bool slot_kary_search(const StrandView& sv, uint32_t lo, uint32_t hi, ui
   return true;
 }
 
+// The same two searches as a round-by-round state machine, so that a caller can advance SEVERAL slots' searches
+// (both strands of a probe) in one loop: every round is eight independent, unconditional key loads per slot.
+// While the two ranges coincide the eight pivots serve both searches (ranges shrink 9-fold per round); once they
+// have parted each search gets four.  A finished search reads `safe`, any valid entry index.
+struct KaryState {
+  uint32_t x1, y1;  // first index whose masked key is >= T lies in [x1, y1]
+  uint32_t x2, y2;  // first index whose masked key is >  T lies in [x2, y2]
+};
+WALT_HD void kary_init(KaryState& s, uint32_t lo, uint32_t hi) { s.x1 = s.x2 = lo; s.y1 = s.y2 = hi; }
+WALT_HD bool kary_busy(const KaryState& s) { return s.y1 > s.x1 || s.y2 > s.x2; }
+WALT_HD void kary_round(const StrandView& sv, KaryState& s, uint64_t T, uint64_t M, uint32_t safe) {
+  const uint32_t n1 = s.y1 > s.x1 ? s.y1 - s.x1 : 0u, n2 = s.y2 > s.x2 ? s.y2 - s.x2 : 0u;
+  const bool same = s.x1 == s.x2 && s.y1 == s.y2;
+  uint32_t q[8];
+  uint64_t k[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (uint32_t i = 0; i < 8; ++i) {
+    const uint32_t both = s.x1 + (uint32_t)(((uint64_t)(2 * i + 1) * n1) / 16);
+    const uint32_t own = i < 4 ? s.x1 + (uint32_t)(((uint64_t)(2 * i + 1) * n1) / 8)
+                               : s.x2 + (uint32_t)(((uint64_t)(2 * (i - 4) + 1) * n2) / 8);
+    const bool live = same ? n1 != 0 : (i < 4 ? n1 != 0 : n2 != 0);
+    q[i] = live ? (same ? both : own) : safe;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (uint32_t i = 0; i < 8; ++i) k[i] = ent_key(sv.ent[q[i]]) & M;
+  // search 1 looks at pivots [0, m1), search 2 at [b2, b2 + m2)
+  const uint32_t m1 = same ? 8u : 4u, b2 = same ? 0u : 4u, m2 = same ? 8u : 4u;
+  if (n1) {
+    uint32_t c = 0;  // pivots below T: a prefix of them (sorted slot)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < 8; ++i) c += (i < m1 && k[i] < T) ? 1u : 0u;
+    uint32_t nx = s.x1, ny = s.y1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < 8; ++i) {
+      nx = (i < m1 && c == i + 1) ? q[i] + 1 : nx;
+      ny = (i < m1 && c == i) ? q[i] : ny;
+    }
+    s.x1 = nx; s.y1 = ny;
+  }
+  if (n2) {
+    uint32_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < 8; ++i) c += (i >= b2 && i < b2 + m2 && k[i] <= T) ? 1u : 0u;
+    uint32_t nx = s.x2, ny = s.y2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < 8; ++i) {
+      nx = (i >= b2 && i < b2 + m2 && c == i - b2 + 1) ? q[i] + 1 : nx;
+      ny = (i >= b2 && i < b2 + m2 && c == i - b2) ? q[i] : ny;
+    }
+    s.x2 = nx; s.y2 = ny;
+  }
+}
+WALT_HD bool kary_result(const KaryState& s, uint32_t& a, uint32_t& u) {
+  if (s.x2 <= s.x1) return false;
+  a = s.x1;
+  u = s.x2 - 1;
+  return true;
+}
+
 // The same narrowing for care chars >= 44 on a key-equal range of at most kLookupPos slots whose
 // genome positions are already in registers (the usual case for reads longer than ~134 bp: one
 // candidate).  lit_region would fetch, per character, the slot and then the genome word -- ten

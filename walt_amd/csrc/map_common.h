@@ -405,6 +405,120 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
   out.reg.l = a; out.reg.u = u;
 }
 
+// The heavy kernels' form of probe_resolve for BOTH strands of a probe.  Nearly every wavefront of a heavy pass
+// holds lanes with long slots on either strand, and two searches one after the other cost the wavefront the
+// sum of their dependent rounds; here
+//   1. slots of more than kScan entries on either strand are searched TOGETHER (core.h kary_round: eight
+//      independent loads per strand and round; rounds = the longer of the two searches, not their sum),
+//   2. the positions of regions of up to kLookupPos slots found that way are fetched in one round for both strands
+//      (the small-region verification and lit_region_small want them in registers),
+//   3. each strand finishes as probe_resolve does (tail characters of long seeds).
+// Same regions as probe_resolve: the equal range of a key in a sorted slot does not depend on how it is searched.
+template <bool LONG_SEED>
+__device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const StrandView& svm, const SlotProbe& pp,
+                                                   const SlotProbe& pm, const uint32_t* care, uint32_t seed_len,
+                                                   Lookup& lp, Lookup& lm, bool& tail_p, bool& tail_m) {
+  const uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0u;
+  const uint32_t nk = n < kKeyChars ? n : kKeyChars;
+  const uint64_t M = key_mask(nk);
+  const uint64_t T = target_key(care) & M;
+  uint32_t a[2] = {0, 0}, u[2] = {0, 0};
+  bool found[2] = {false, false};
+  uint32_t npos[2] = {0, 0};
+  uint32_t pos[2][kLookupPos];
+  // ---- 1. [a, u] of both strands
+  KaryState ks[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const SlotProbe& p = f ? pm : pp;
+#pragma unroll
+    for (uint32_t i = 0; i < kLookupPos; ++i) pos[f][i] = 0;
+    kary_init(ks[f], p.lo, p.lo);  // idle
+    if (p.ne == 0) continue;
+    if (p.ne <= kScan) {
+      uint32_t n_lt = 0, n_eq = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < kScan; ++j) {
+        const uint64_t k = ent_key(p.e[j]) & M;
+        n_lt += (j < p.ne && k < T) ? 1u : 0u;
+        n_eq += (j < p.ne && k == T) ? 1u : 0u;
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < kLookupPos; ++i) {
+        uint32_t q = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kScan; ++j) q = (n_lt + i == j) ? p.e[j].pos : q;
+        pos[f][i] = q;
+      }
+      found[f] = n_eq != 0;
+      a[f] = p.lo + n_lt;
+      u[f] = a[f] + n_eq - 1;
+      npos[f] = n_eq < kLookupPos ? n_eq : kLookupPos;
+    } else {
+      kary_init(ks[f], p.lo, p.lo + p.ne);
+    }
+  }
+  while (kary_busy(ks[0]) || kary_busy(ks[1])) {
+    kary_round(svp, ks[0], T, M, pp.lo);
+    kary_round(svm, ks[1], T, M, pm.lo);
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const SlotProbe& p = f ? pm : pp;
+    if (p.ne > kScan) found[f] = kary_result(ks[f], a[f], u[f]);
+  }
+  // ---- 2. positions of short regions the search found (one round, both strands; idle lanes read their slot's first entry)
+  {
+    uint32_t v[2][kLookupPos];
+    bool want[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const SlotProbe& p = f ? pm : pp;
+      const StrandView& sv = f ? svm : svp;
+      const uint32_t size = found[f] ? u[f] - a[f] + 1 : 0u;
+      want[f] = p.ne > kScan && size != 0 && size <= kLookupPos;
+#pragma unroll
+      for (uint32_t i = 0; i < kLookupPos; ++i) v[f][i] = sv.ent[(want[f] && i < size) ? a[f] + i : p.lo].pos;
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      if (want[f]) {
+#pragma unroll
+        for (uint32_t i = 0; i < kLookupPos; ++i) pos[f][i] = v[f][i];
+        npos[f] = u[f] - a[f] + 1;
+      }
+    }
+  }
+  // ---- 3. per strand
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const StrandView& sv = f ? svm : svp;
+    Lookup& out = f ? lm : lp;
+    bool& tail_check = f ? tail_m : tail_p;
+    tail_check = false;
+    out.npos = 0;
+    out.reg = empty_region();
+#pragma unroll
+    for (uint32_t i = 0; i < kLookupPos; ++i) out.pos[i] = pos[f][i];
+    if (!found[f]) continue;
+    out.npos = npos[f];
+    if (n > kKeyChars) {
+      const uint32_t size = u[f] - a[f] + 1;
+      if (LONG_SEED && size == 1 && out.npos == 1) {
+        tail_check = true;  // IndexRegion on one slot (mapping.cpp:206-211)
+        out.reg.l = a[f]; out.reg.u = a[f];
+      } else if (LONG_SEED && size <= kLookupPos && out.npos == size) {
+        out.reg = lit_region_small(sv, care, seed_len, a[f], size, out.pos, out.npos);
+      } else {
+        out.npos = 0;
+        out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a[f], u[f]);
+      }
+      continue;
+    }
+    out.reg.l = a[f]; out.reg.u = u[f];
+  }
+}
+
 // care chars [44, seed_len) of the slot at slot_pos against the read's (ent_char semantics: a position at or
 // beyond the genome end matches nothing).  The two words read here lie inside the window that
 // verify_nobranch loads for the same candidate, so this costs no extra memory round trip.

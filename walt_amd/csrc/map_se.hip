@@ -306,13 +306,62 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 // SlotProbe / probe_issue / probe_entries / probe_resolve / verify_nobranch live in map_common.h (shared with map_pe.hip)
 
 constexpr uint32_t kMidRegion = 16;  // heavy pass: regions up to this size are verified by their own lane, in batches
-// HEAVY = false (pass 1, every read): a lane that meets heavy work -- a directory slot of more than kScanMax
-// entries (k-ary search) or a region of more than kSmallRegion candidates (wave-cooperative verification) --
-// stops and appends its read to the heavy list instead of making its 63 wave-mates wait: on an hg19-like
-// genome a tenth of the reads is like that, so nearly every wavefront held some, and the phase stamps showed
-// 37 % of the kernel in slot searches and 50 % in cooperative regions.  HEAVY = true (pass 1b, the heavy
-// list): the same code with those paths enabled; every lane of such a wave has heavy work.
-template <int NW, bool DIAG, bool HEAVY>
+
+// ---- staged heavy pass --------------------------------------------------------------------------------------
+// The heavy list is mapped in four stages per chunk of `hcap` reads: stage k = 0, 1, 2 does what the monolithic
+// heavy kernel does for seed shift k (both strands' lookups, the regions of up to kMidRegion candidates) but turns
+// every larger region into a work ITEM instead of borrowing the wavefront for it; k_se_verify streams the items
+// with one wavefront per region and writes their RegionSummary; stage k + 1 starts by reading the summaries of
+// the seeds before it (they decide which probes the reference makes next, mapping.cpp:250-257); stage 3 only
+// folds and writes the record.  State per read of the chunk: six summaries (seed x strand) and a flag.
+struct HeavyStage {
+  uint4* sums;       // [6][hcap]: RegionSummary of (seed, strand) = sums[(2 * seed + strand) * hcap + j]
+  uint32_t* flag;    // [hcap]: 1 = the read went to the literal list at an earlier stage
+  uint4* items;      // 2 * hcap items of item_quads<NW>() 16-byte words; dense items from the front, gather items from the back
+  uint32_t* ctl;     // this (chunk, stage)'s counters: [0] dense items, [1] gather items
+  uint32_t hcap;     // reads per chunk
+  uint32_t first;    // heavy-list index of the chunk's first read
+  uint32_t stage;    // 0..2: seed shift of the stage, 3: final fold
+};
+constexpr uint32_t kItemDenseNone = 0xFFFFFFFFu;
+// A work item carries everything k_se_verify needs, so that the verifier's only dependent loads are the
+// candidates' own (no read offsets, no packed read, no mask table):
+//   word 0..3  j | strand << 31, first slot l, size, first dense record (records stay below 2^32, build_windows)
+//   word 4..7  read length, 0, 0, 0
+//   then the converted read rd[NW] and its compare masks mk[NW] for this seed shift, padded to 16 bytes
+template <int NW>
+constexpr uint32_t item_quads() { return 2u + (2u * NW + 3u) / 4u; }
+template <int NW>
+__device__ __forceinline__ void wave_append_item(bool take, bool dense, uint32_t jfi, uint32_t l, uint32_t size,
+                                                 uint32_t rec, uint32_t len, const uint32_t* rd, const uint32_t* mk,
+                                                 const HeavyStage& hs) {
+  constexpr uint32_t Q = item_quads<NW>();
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const bool mine = take && (dense == (side == 0));
+    const unsigned long long m = __ballot(mine);
+    if (!m) continue;
+    const int leader = (int)__ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&hs.ctl[side], (uint32_t)__popcll(m));
+    base = bcast(base, leader);
+    if (mine) {
+      const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      const uint64_t at = side == 0 ? k : (uint64_t)2 * hs.hcap - 1 - k;
+      uint4* it = hs.items + Q * at;
+      it[0] = make_uint4(jfi, l, size, rec);
+      it[1] = make_uint4(len, 0u, 0u, 0u);
+      uint32_t w[4 * (Q - 2)];
+#pragma unroll
+      for (uint32_t t = 0; t < 4 * (Q - 2); ++t) w[t] = t < (uint32_t)NW ? rd[t] : (t < 2u * NW ? mk[t - NW] : 0u);
+#pragma unroll
+      for (uint32_t q = 0; q + 2 < Q; ++q) it[2 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+  }
+}
+
+template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
                                                 const uint32_t* __restrict__ codes2, uint64_t o_first,
                                                 uint64_t o_read, uint64_t oe_read, uint32_t* __restrict__ err,
@@ -321,7 +370,10 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
                                                 BestMatch* __restrict__ out, uint32_t* __restrict__ defer_count,
                                                 uint32_t* __restrict__ defer_list, uint32_t* __restrict__ heavy_count,
                                                 uint32_t* __restrict__ heavy_list, MapCounters& ctr_out,
-                                                uint32_t& len_out, uint32_t ablate_rt, StampsT<DIAG>& st) {
+                                                uint32_t& len_out, uint32_t ablate_rt, StampsT<DIAG>& st,
+                                                const HeavyStage& hs = HeavyStage(), uint32_t j = 0) {
+  static_assert(!STAGED || HEAVY, "the staged kernels are heavy-pass kernels");
+  if constexpr (STAGED) valid = valid && !(hs.stage && hs.flag[j]);  // gone to the literal list at an earlier stage
   const uint32_t ablate = DIAG ? ablate_rt : 0u;
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t top_step = top_step_of(n_chrom);
@@ -346,6 +398,20 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
 
 #pragma unroll 1
   for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+    RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
+    bool replay = false;
+    if constexpr (STAGED) {
+      if (seed_i > hs.stage) break;
+      replay = seed_i < hs.stage;  // a seed of an earlier stage: its summaries are in the state arrays
+    }
+    if (replay) {
+      if (mappable) {
+        const uint4 a = hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j], c = hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j];
+        sum_p.min_mm = a.x; sum_p.count = a.y; sum_p.first = a.z; sum_p.last = a.w;
+        sum_m.min_mm = c.x; sum_m.count = c.y; sum_m.first = c.z; sum_m.last = c.w;
+      }
+    } else {
+    bool pend_p = false, pend_m = false;  // staged: the summary comes from k_se_verify
     // '+': exact (mapping.cpp:250-257 with the state after the '+' folds so far)
     bool need_p = mappable && (seed_i == 0 || (seed_i == 1 ? best.mismatch != 0 : best.mismatch > 1));
     // '-': superset of the reference's decision (see header comment)
@@ -407,8 +473,12 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     probe_entries(svm, pm);
     Lookup lp, lm;
     bool tail_p, tail_m;
-    probe_resolve<(NW > 8)>(svp, pp, care, lr.repeats, lp, tail_p);
-    probe_resolve<(NW > 8)>(svm, pm, care, lr.repeats, lm, tail_m);
+    if constexpr (HEAVY) {
+      probe_resolve_dual<(NW > 8)>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m);
+    } else {
+      probe_resolve<(NW > 8)>(svp, pp, care, lr.repeats, lp, tail_p);
+      probe_resolve<(NW > 8)>(svm, pm, care, lr.repeats, lm, tail_m);
+    }
     stamp(st, 3);
 
     uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
@@ -427,7 +497,6 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     stamp(st, 4);
 
     // small regions: candidate k of both strands checked side by side
-    RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
     const bool small_p = size_p && size_p <= kSmallRegion, small_m = size_m && size_m <= kSmallRegion;
     if (small_p || small_m) {
       const uint32_t kmax = (small_p ? size_p : 0u) > (small_m ? size_m : 0u) ? size_p : (small_m ? size_m : size_p);
@@ -525,7 +594,14 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         }
         if (nmid) { if (fi) sum_m = acc; else sum_p = acc; }
       }
-      unsigned long long big = __ballot(my_size > kMidRegion);
+      if constexpr (STAGED) {
+        const bool bigr = my_size > kMidRegion;
+        const DenseRange& dr = fi ? dr_m : dr_p;
+        const bool dense = bigr && dr.hi > dr.lo;
+        wave_append_item<NW>(bigr, dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone, lr.len, lr.rd, mk, hs);
+        if (bigr) { ++ctr.big; if (fi) pend_m = true; else pend_p = true; }
+      }
+      unsigned long long big = STAGED ? 0ull : __ballot(my_size > kMidRegion);
       while (big) {
         const int owner = (int)__ffsll((long long)big) - 1;
         big &= big - 1;
@@ -551,6 +627,13 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     }
     }
     stamp(st, 6);
+    if constexpr (STAGED) {
+      // this stage's summaries: what the lane worked out itself now, the items' when k_se_verify has run
+      if (valid && !pend_p) hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j] = make_uint4(sum_p.min_mm, sum_p.count, sum_p.first, sum_p.last);
+      if (valid && !pend_m) hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j] = make_uint4(sum_m.min_mm, sum_m.count, sum_m.first, sum_m.last);
+      break;
+    }
+    }  // !replay
     fold_region(best, sum_p, '+');  // empty when the '+' probe was not needed
     if (seed_i == 0) m0 = sum_m; else if (seed_i == 1) m1 = sum_m; else m2 = sum_m;
     if (sum_m.count && sum_m.min_mm < minus_lb) minus_lb = sum_m.min_mm;
@@ -563,8 +646,15 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
   }
   wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, defer_count, defer_list);
   if constexpr (!HEAVY) wave_append(heavy && !deferred, r, heavy_count, heavy_list);
-  if (!deferred && !heavy && valid) out[r] = best;
-  if (!deferred && !heavy) { ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big; }
+  if constexpr (STAGED) {
+    if (hs.stage == 0 ? valid || deferred : deferred) hs.flag[j] = deferred ? 1u : 0u;
+    if (hs.stage == 3 && valid) out[r] = best;
+    // the stage's own work (the literal pass counts a deferred read's again: these counters are diagnostic)
+    ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big;
+  } else {
+    if (!deferred && !heavy && valid) out[r] = best;
+    if (!deferred && !heavy) { ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big; }
+  }
   stamp(st, 7);
 }
 
@@ -669,7 +759,7 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 
 #if WALT_SEEDPATTERN == 3
 // pass 1: every read of the batch, one per lane (HEAVY = false); pass 1b: the reads of the heavy list (HEAVY = true)
-template <int NW, bool DIAG, bool HEAVY>
+template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
 __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
                                                     const uint64_t* __restrict__ offsets,
                                                     uint32_t* __restrict__ err,
@@ -682,8 +772,13 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
                                                     uint32_t* __restrict__ defer_list,
                                                     uint32_t* __restrict__ heavy_count,
                                                     uint32_t* __restrict__ heavy_list, uint32_t ablate,
-                                                    unsigned long long* __restrict__ stamps) {
-  const uint32_t n = HEAVY ? *heavy_count : n_all;
+                                                    unsigned long long* __restrict__ stamps,
+                                                    HeavyStage hs = HeavyStage()) {
+  uint32_t n = HEAVY ? *heavy_count : n_all;
+  if constexpr (STAGED) {  // this chunk of the heavy list
+    n = n > hs.first ? n - hs.first : 0u;
+    n = n < hs.hcap ? n : hs.hcap;
+  }
   if (HEAVY && n == 0) return;
   __shared__ BlockShared sh;
   __shared__ PreFilter pf;
@@ -706,7 +801,7 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
   uint64_t o_nx = 0, oe_nx = 0;
   uint32_t r_nx = 0;
   auto fetch = [&](uint64_t i) {
-    r_nx = HEAVY ? heavy_list[i] : (uint32_t)i;
+    r_nx = HEAVY ? heavy_list[(STAGED ? hs.first : 0u) + i] : (uint32_t)i;
     o_nx = offsets[r_nx];
     oe_nx = offsets[(uint64_t)r_nx + 1];
   };
@@ -718,13 +813,177 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
     const uint64_t o_cur = o_nx, oe_cur = oe_nx;
     if (c + 1 < c_hi && i64 + blockDim.x < n) fetch(i64 + blockDim.x);
     uint32_t len;
-    se_process_dual<NW, DIAG, HEAVY>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
-                                     out, defer_count, defer_list, heavy_count, heavy_list, ctr, len, ablate, st);
+    se_process_dual<NW, DIAG, HEAVY, STAGED>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
+                                             out, defer_count, defer_list, heavy_count, heavy_list, ctr, len, ablate, st, hs,
+                                             (uint32_t)i64);
     // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 sees every read
     if (!HEAVY) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
   stamp_end(st);
   flush_counters(ctr, shortv, stats);
+}
+
+// ---------------------------------------------------------------------------
+// k_se_verify: the work items of one heavy stage (HeavyStage), one region per wavefront.  An item brings the
+// read, its masks and the region (wave_append_item), all wave-uniform, so a lane carries little besides the
+// records it has in flight and the kernel runs at high occupancy; wavefronts take items in batches of
+// kVerifyBatch from a device counter (regions run from 17 to `-b` candidates: a static deal leaves a long tail).
+//   DENSE = true:  every candidate has a dense record (core.h dense_range): 32 (48) sequential bytes each, 64
+//                  candidates per step, and the NEXT step's records -- of this item or of the next one -- are
+//                  requested before the current step is evaluated (every path issues the same loads, so the wait
+//                  for the current step leaves them in flight);
+//   DENSE = false: index entry, then the genome window (coop_verify_groups' gather route).
+// The RegionSummary of a region is order-free once the slot order is kept in the lanes: minimum, number of
+// candidates holding it, the first and the last of them in slot order (core.h summary_merge) -- accumulated per
+// lane over its slots (ascending) and reduced once per item.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kVerifyBatch = 8;
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+struct LaneBest {  // this lane's slots of one region, ascending
+  uint32_t mm, cnt, f_k, f_gp, l_k, l_gp;
+};
+__device__ __forceinline__ void lane_best_add(LaneBest& a, uint32_t k, uint32_t gp, uint32_t mm) {
+  const bool has = mm != 0xFFFFFFFFu;
+  const bool better = has && mm < a.mm, same = has && mm == a.mm;
+  a.cnt = better ? 1u : a.cnt + (same ? 1u : 0u);
+  a.f_k = better ? k : a.f_k;
+  a.f_gp = better ? gp : a.f_gp;
+  a.l_k = (better || same) ? k : a.l_k;
+  a.l_gp = (better || same) ? gp : a.l_gp;
+  a.mm = better ? mm : a.mm;
+}
+__device__ __forceinline__ uint4 lane_best_reduce(const LaneBest& a) {
+  const uint32_t mn = wave_min_u32(a.mm);
+  if (mn == 0xFFFFFFFFu) return make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+  const bool eq = a.mm == mn;
+  const uint32_t cnt = wave_sum_u32(eq ? a.cnt : 0u);
+  const uint32_t fk = wave_min_u32(eq ? a.f_k : 0xFFFFFFFFu), lk = wave_max_u32(eq ? a.l_k : 0u);
+  const unsigned long long fm = __ballot(eq && a.f_k == fk), lm = __ballot(eq && a.l_k == lk);
+  return make_uint4(mn, cnt, bcast(a.f_gp, (int)__ffsll((long long)fm) - 1), bcast(a.l_gp, (int)__ffsll((long long)lm) - 1));
+}
+
+template <int NW, bool DENSE>
+__global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
+    IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs) {
+  constexpr uint32_t Q = item_quads<NW>();
+  static_assert(Q <= 64, "an item header is fetched by one wavefront load");
+  const uint32_t n_items = hs.ctl[DENSE ? 0 : 1];
+  if (n_items == 0) return;
+  __shared__ uint32_t s_start[kLdsChroms + 1];
+  const uint32_t n_chrom = iv.n_chrom, top_step = top_step_of(n_chrom);
+  const bool fits = n_chrom <= kLdsChroms;
+  if (fits)
+    for (uint32_t i = threadIdx.x; i <= n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  __syncthreads();
+  const uint32_t* si = fits ? s_start : iv.start_index;
+  uint32_t* const cursor = &hs.ctl[DENSE ? 2 : 3];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t seed_i = hs.stage;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  uint32_t n_verified = 0;
+  auto header = [&](uint32_t i, bool on) {  // lane q < Q: quad q of item i
+    const uint64_t at = DENSE ? (uint64_t)i : (uint64_t)2 * hs.hcap - 1 - i;
+    return (on && lane < Q) ? hs.items[Q * at + lane] : zero;
+  };
+  auto grab = [&]() {  // lane 0 holds the batch start once the atomic has returned
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(cursor, kVerifyBatch);
+    return v;
+  };
+  uint32_t nb_v = grab();
+  uint32_t b0 = bcast(nb_v, 0), t = 0;
+  nb_v = grab();
+  bool have = b0 < n_items;
+  uint4 hd = header(b0, have);
+  uint4 ra = zero, rc = zero, re = zero;  // the records of the step about to be evaluated (DENSE)
+  auto issue = [&](const StrandView& sv, uint32_t rec0, uint32_t size, uint32_t base, uint4& a, uint4& c, uint4& e) {
+    const uint32_t k = base + lane;
+    const uint64_t rec = (uint64_t)rec0 + (k < size ? k : size - 1);
+    const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * rec;
+    a = rp[0];
+    c = rp[1];
+    if constexpr (NW > 7) e = reinterpret_cast<const uint4*>(sv.win2)[rec];
+  };
+  if constexpr (DENSE) {
+    if (have) issue(iv.s[strand_base + (bcast(hd.x, 0) >> 31)], bcast(hd.w, 0), bcast(hd.z, 0), 0u, ra, rc, re);
+  }
+  while (have) {
+    const uint32_t jfi = bcast(hd.x, 0), l = bcast(hd.y, 0), size = bcast(hd.z, 0), rec0 = bcast(hd.w, 0);
+    const uint32_t len = bcast(hd.x, 1);
+    uint32_t rd[NW], mk[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int a = 8 + w, c = 8 + NW + w;
+      const uint32_t va = (a & 3) == 0 ? hd.x : (a & 3) == 1 ? hd.y : (a & 3) == 2 ? hd.z : hd.w;
+      const uint32_t vc = (c & 3) == 0 ? hd.x : (c & 3) == 1 ? hd.y : (c & 3) == 2 ? hd.z : hd.w;
+      rd[w] = bcast(va, a >> 2);
+      mk[w] = bcast(vc, c >> 2);
+    }
+    const uint32_t j = jfi & 0x7FFFFFFFu, fi = jfi >> 31;
+    const StrandView& sv = iv.s[strand_base + fi];
+    // the next item: the batch's next, or the first of the batch grabbed while this one was worked on
+    uint32_t ni;
+    if (t + 1 < kVerifyBatch) {
+      ++t;
+      ni = b0 + t;
+    } else {
+      b0 = bcast(nb_v, 0);
+      nb_v = grab();
+      t = 0;
+      ni = b0;
+    }
+    const bool hn = ni < n_items;
+    const uint4 hdn = header(ni, hn);
+    LaneBest acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    if constexpr (DENSE) {
+      auto consume = [&](uint32_t base) {
+        const uint32_t k = base + lane;
+        const uint32_t pos = ra.x;
+        const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos);
+        const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+        const uint32_t g = pos - seed_i;
+        const bool ok = k < size && (pos - c_lo >= seed_i) && (g + len < c_hi);  // mapping.cpp:280-286
+        uint32_t wv[NW + 1];
+        const uint32_t first[11] = {ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w,
+                                    NW > 7 ? re.x : 0u, NW > 7 ? re.y : 0u, NW > 7 ? re.z : 0u, NW > 7 ? re.w : 0u};
+#pragma unroll
+        for (int w = 0; w <= NW; ++w) wv[w] = w < 11 ? first[w] : 0u;
+        const uint32_t m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
+        n_verified += ok ? 1u : 0u;
+        lane_best_add(acc, k, ok ? g : 0u, ok ? m : 0xFFFFFFFFu);
+      };
+      uint32_t base = 0;
+      for (; base + 64 < size; base += 64) {
+        uint4 na, nc, ne = zero;
+        issue(sv, rec0, size, base + 64, na, nc, ne);
+        consume(base);
+        ra = na; rc = nc; re = ne;
+      }
+      {  // last step of the item: the first records of the next item are requested before it is evaluated
+        const uint32_t n_fi = bcast(hdn.x, 0) >> 31, n_size = bcast(hdn.z, 0), n_rec0 = bcast(hdn.w, 0);
+        uint4 na, nc, ne = zero;
+        issue(iv.s[strand_base + (hn ? n_fi : fi)], hn ? n_rec0 : rec0, hn ? n_size : size, 0u, na, nc, ne);
+        consume(base);
+        ra = na; rc = nc; re = ne;
+      }
+    } else {
+      DenseRange none;
+      none.lo = none.hi = l;
+      none.rec = 0;
+      for (uint32_t base = 0; base < size; base += 64) {
+        uint32_t gp[1], mm[1];
+        coop_verify_groups<NW, 1>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, none, gp, mm);
+        n_verified += mm[0] != 0xFFFFFFFFu ? 1u : 0u;
+        lane_best_add(acc, base + lane, gp[0], mm[0]);
+      }
+    }
+    const uint4 res = lane_best_reduce(acc);
+    if (lane == 0) hs.sums[(uint64_t)(2 * seed_i + fi) * hs.hcap + j] = res;
+    hd = hdn;
+    have = hn;
+  }
+  flush_counters({0u, n_verified, 0u}, 0u, stats);
 }
 
 #endif  // WALT_SEEDPATTERN == 3
@@ -769,6 +1028,18 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
+// staged heavy pass: reads per chunk of the heavy list (an eighth of the batch, the whole batch when it is small)
+// and the bytes of its state behind the dense read array: [128 control words][flag][6 summaries][2 x 2 item words]
+constexpr uint32_t kHeavyCtlWords = 128;  // 4 words per (chunk, stage): up to 8 chunks x 3 stages
+static uint32_t se_heavy_chunk(uint32_t n) {
+  const uint64_t eighth = ((uint64_t)n + 7) / 8;
+  return (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (eighth > 65536 ? eighth : 65536), 64);
+}
+static uint64_t se_heavy_bytes(uint32_t n, int nw) {
+  const uint64_t hcap = se_heavy_chunk(n);
+  const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
+  return 16 + kHeavyCtlWords * 4 + hcap * 4 + hcap * 6 * 16 + 2 * hcap * quads * 16;
+}
 
 // WALT_AMD_ABLATE (diagnostic builds of the measurement only; results are WRONG when
 // it is set): bit 0 skips verification, bit 1 stops after the directory lookup,
@@ -789,9 +1060,10 @@ template <int NW>
 static int launch_map_se(const walt_index* idx, const IndexView& view, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
                          uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
-                         hipStream_t stream) {
+                         uint32_t* heavy_area, hipStream_t stream) {
 #if WALT_SEEDPATTERN != 3
   (void)stride;
+  (void)heavy_area;
   // patterns 5 / 7: strand-major kernel over every read with the directory/key search, Bloom hits deferred
   // (untagged order) to the literal pass
   const unsigned g1 = grid_for(n) < 4 * kLiteralGrid ? grid_for(n) : 4 * kLiteralGrid;
@@ -821,14 +1093,58 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, 0u, nullptr);
   debug_sync("pass 1", stream);
-  if (diag2)
+  // WALT_AMD_HEAVY=mono: the one-kernel heavy pass (large regions verified by the whole wavefront of their read's
+  // lane) instead of the staged one (large regions streamed by k_se_verify); same results, kept for comparison
+  static const bool mono = [] { const char* e = getenv("WALT_AMD_HEAVY"); return e && !strcmp(e, "mono"); }();
+  if (diag2 && mono)
     hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, g_ablate, g_stamps);
-  else
+  else if (mono)
     hipLaunchKernelGGL((k_map_se<NW, false, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, 0u, nullptr);
+  else {
+    const uint32_t hcap = se_heavy_chunk(n);
+    const uint32_t chunks = (uint32_t)(((uint64_t)n + hcap - 1) / hcap);  // <= 8
+    HeavyStage hs;
+    hs.ctl = heavy_area;
+    hs.flag = heavy_area + kHeavyCtlWords;
+    hs.sums = reinterpret_cast<uint4*>(hs.flag + hcap);
+    hs.items = hs.sums + (uint64_t)6 * hcap;  // 2 * hcap items of item_quads<NW>() quads
+    hs.hcap = hcap;
+    uint32_t* const ctl0 = heavy_area;
+    static const unsigned vg_dense = [] {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, NW <= 10>, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+      return (unsigned)nb * 256u;
+    }();
+    static const unsigned vg_gather = [] {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, false>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
+      return (unsigned)nb * 256u;
+    }();
+    for (uint32_t c = 0; c < chunks; ++c) {
+      hs.first = c * hcap;
+      const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
+      for (uint32_t stage = 0; stage < 4; ++stage) {
+        hs.stage = stage;
+        hs.ctl = ctl0 + 4 * (3 * c + (stage < 3 ? stage : 0));
+        if (diag2)
+          hipLaunchKernelGGL((k_map_se<NW, true, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+                             n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                             heavy_list, g_ablate, g_stamps, hs);
+        else
+          hipLaunchKernelGGL((k_map_se<NW, false, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+                             n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                             heavy_list, 0u, nullptr, hs);
+        if (stage == 3) break;
+        if constexpr (NW <= 10)
+          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
+        hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
+      }
+    }
+  }
   debug_sync("heavy pass", stream);
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
@@ -874,7 +1190,11 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   uint32_t* defer_count = err + 32;  // control block: [0] count, [8..15] bin counts, [16..23] bin cursors
   uint32_t* defer_list = err + 64 + kStatShardBytes / 4;
   uint32_t* codes2 = defer_list + 3 * stride;  // deferred list, its sorted copy, heavy list
+  // state of the staged heavy pass behind the dense reads, 16-byte aligned
+  uint32_t* heavy_area = reinterpret_cast<uint32_t*>(
+      align_up(reinterpret_cast<uint64_t>(codes2 + codes2_words((uint64_t)n * max_read_len)), 16));
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
+  WALT_HIP(hipMemsetAsync(heavy_area, 0, kHeavyCtlWords * sizeof(uint32_t), stream));
   const uint8_t* bases = reinterpret_cast<const uint8_t*>(d_bases);
   const uint64_t* offsets = reinterpret_cast<const uint64_t*>(d_offsets);
   if (idx->profile) WALT_HIP(hipEventRecord(idx->ev[0], stream));
@@ -887,15 +1207,15 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   const uint32_t sb = ag ? 2u : 0u;
   int rc;
   switch (nw) {
-    case 7: rc = launch_map_se<7>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 8: rc = launch_map_se<8>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 7: rc = launch_map_se<7>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
+    case 8: rc = launch_map_se<8>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
 #if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
-    case 10: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 16: rc = launch_map_se<16>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    case 32: rc = launch_map_se<32>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
-    default: rc = launch_map_se<64>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    case 10: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
+    case 16: rc = launch_map_se<16>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
+    case 32: rc = launch_map_se<32>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
+    default: rc = launch_map_se<64>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
 #else
-    default: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, stream); break;
+    default: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
 #endif
   }
   if (rc) return rc;
@@ -962,9 +1282,8 @@ int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms) {
 size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
-  (void)nw;
   return 64 * sizeof(uint32_t) + kStatShardBytes + 3 * se_stride(n) * sizeof(uint32_t) +
-         codes2_words((uint64_t)n * max_read_len) * sizeof(uint32_t);
+         codes2_words((uint64_t)n * max_read_len) * sizeof(uint32_t) + se_heavy_bytes(n, nw);
 }
 
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
