@@ -116,8 +116,8 @@ struct StrandView {
   // consecutive index slots, but the genome windows behind them are scattered: one random 128-byte line per
   // candidate for 25 useful bytes, and the device serves ~48 G such lines per second whatever their size.
   // For every run of the index that lies inside ONE region of a 100-base read (same bucket, same first
-  // kWinKeyChars key characters) and holds at least one aligned 16-slot block -- i.e. every run of 31 slots or
-  // more, and some shorter ones -- the windows of ALL its slots are therefore stored once more, in slot order:
+  // kWinKeyChars key characters) and has at least kWinMinRun slots -- the regions the mapping kernels do not leave
+  // to a single lane -- the windows of ALL its slots are therefore stored once more, in slot order:
   //   wbits[slot >> 6]  bit (slot & 63): the slot has a dense record
   //   wrank[slot >> 6]  number of dense records in front of this 64-slot word (record of a slot = rank + popcount)
   //   win               record r: 8 words {pos, the 112 bases from genome position pos - kWinLead}
@@ -134,7 +134,7 @@ struct StrandView {
   uint32_t wcap;
   uint32_t wpad_;
 };
-constexpr uint32_t kWinShift = 4, kWinBlock = 1u << kWinShift;  // index slots per dense block
+constexpr uint32_t kWinMinRun = 17;  // runs of at least this many index slots get dense records (map_se.hip kMidRegion + 1)
 constexpr uint32_t kWinLead = kPat - 1;   // bases in front of pos: the largest seed shift (genome_pos = pos - seed_i)
 constexpr uint32_t kWinWords = 7, kWinWords2 = 4;
 constexpr uint32_t kWinKeyChars = kPat == 3 ? 20 : (kPat == 5 ? 26 : 32);  // key characters of a 100-base read's seed

@@ -465,49 +465,39 @@ int build_strand_device(walt_index* idx, int strand, const uint8_t* d_bytes, con
 }
 
 // ---------------------------------------------------------------------------
-// Dense candidate windows (core.h StrandView::wblk / win / win2)
+// Dense candidate windows (core.h StrandView::wbits / wrank / win / win2)
 // ---------------------------------------------------------------------------
-// flag[b] = 1 when the kWinBlock slots of block b lie inside one region of a 100-base read: same bucket and same first
-// kWinKeyChars key characters at both ends (entries between two equal ends of a sorted bucket are equal too; a
-// chromosome-end entry out of order only changes which blocks are chosen, never what a record holds)
-__global__ void k_win_mark(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t index_size,
-                           uint32_t nblk, uint32_t* __restrict__ flag) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nblk) return;
-  const uint64_t first = (uint64_t)kWinBlock * b, last = first + kWinBlock - 1;
-  uint32_t f = 0;
-  if (last < index_size) {
-    const Ent a = ent[first], z = ent[last];
-    if (((ent_key(a) ^ ent_key(z)) >> (64 - 2 * kWinKeyChars)) == 0 && hash_at_dev(g2, a.pos) == hash_at_dev(g2, z.pos)) f = 1;
+// eq bit j = slots j and j + 1 belong to the same run: same bucket and same first kWinKeyChars key characters, i.e. a
+// 100-base read whose region holds one holds the other (a chromosome-end entry out of order only changes which
+// slots are chosen, never what a record holds).  One wavefront per 64-slot word.
+__global__ void k_win_eq(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t index_size,
+                         unsigned long long* __restrict__ eq) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool same = false;
+  if (t + 1 < index_size) {
+    const Ent a = ent[t], z = ent[t + 1];
+    if (((ent_key(a) ^ ent_key(z)) >> (64 - 2 * kWinKeyChars)) == 0) same = hash_at_dev(g2, a.pos) == hash_at_dev(g2, z.pos);
   }
-  flag[b] = f;
+  const unsigned long long m = __ballot(same);
+  if ((threadIdx.x & 63) == 0 && t < index_size) eq[t >> 6] = m;
 }
-// bitmap of the slots with dense records: the 16 slots of every flagged block, and from a flagged block whose
-// neighbour is not flagged up to 15 slots further while they belong to the same run (same bucket, same first
-// kWinKeyChars key characters): the rest of a run that starts or ends inside a block
-__global__ void k_win_bits(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t index_size,
-                           const uint32_t* __restrict__ flag, uint32_t nblk, unsigned long long* __restrict__ bits) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nblk || !flag[b]) return;
-  const uint64_t first = (uint64_t)kWinBlock * b;
-  atomicOr(&bits[first >> 6], (unsigned long long)((1u << kWinBlock) - 1u) << (first & 63u));
-  const Ent ref = ent[first];
-  const uint32_t h_ref = hash_at_dev(g2, ref.pos);
-  const uint64_t kref = ent_key(ref) >> (64 - 2 * kWinKeyChars);
-  if (b > 0 && !flag[b - 1]) {
-    for (uint64_t j = first; j-- > first - (kWinBlock - 1);) {
-      const Ent e = ent[j];
-      if ((ent_key(e) >> (64 - 2 * kWinKeyChars)) != kref || hash_at_dev(g2, e.pos) != h_ref) break;
-      atomicOr(&bits[j >> 6], 1ull << (j & 63u));
-    }
+// bitmap of the slots with dense records: every slot of a run of at least kWinMinRun slots.  The run of slot j
+// reaches L slots down and R slots up, each counted to 16 on the eq bits around j: one thread per 64-slot word.
+__global__ void k_win_bits(const unsigned long long* __restrict__ eq, uint32_t nw, unsigned long long* __restrict__ bits) {
+  static_assert(kWinMinRun >= 2 && kWinMinRun <= 33, "run lengths are counted on 16 bits either side");
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nw) return;
+  const unsigned long long prev = w ? eq[w - 1] : 0ull, cur = eq[w], next = w + 1 < nw ? eq[w + 1] : 0ull;
+  unsigned long long out = 0;
+  for (uint32_t b = 0; b < 64; ++b) {
+    const unsigned long long up = b ? (cur >> b) | (next << (64 - b)) : cur;        // bit 0: eq of slot j
+    const unsigned long long dn = b >= 16 ? cur >> (b - 16) : (cur << (16 - b)) | (prev >> (48 + b));  // bit 15: eq of slot j - 1
+    const uint32_t nu = (uint32_t)(~up) & 0xFFFFu, nd = (uint32_t)(~dn) & 0xFFFFu;
+    const uint32_t R = nu ? (uint32_t)__ffs((int)nu) - 1u : 16u;
+    const uint32_t L = nd ? (uint32_t)__clz((int)(nd << 16)) : 16u;
+    if (L + R + 1 >= kWinMinRun) out |= 1ull << b;
   }
-  if (b + 1 >= nblk || !flag[b + 1]) {
-    for (uint64_t j = first + kWinBlock; j < first + 2 * kWinBlock - 1 && j < index_size; ++j) {
-      const Ent e = ent[j];
-      if ((ent_key(e) >> (64 - 2 * kWinKeyChars)) != kref || hash_at_dev(g2, e.pos) != h_ref) break;
-      atomicOr(&bits[j >> 6], 1ull << (j & 63u));
-    }
-  }
+  bits[w] = out;
 }
 __global__ void k_win_popc(const unsigned long long* __restrict__ bits, uint32_t nw, uint32_t* __restrict__ cnt) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -564,29 +554,28 @@ static int build_windows(walt_index* idx) {
   for (int s = 0; s < 4; ++s) {
     if (!((idx->strand_mask >> s) & 1u)) continue;
     StrandView& sv = idx->view.s[s];
-    const uint32_t nblk = (uint32_t)(((uint64_t)sv.index_size + kWinBlock - 1) >> kWinShift);
     const uint32_t nw = (uint32_t)(((uint64_t)sv.index_size + 63) >> 6);
-    if (nblk == 0) { --n_strands; continue; }
+    if (nw == 0) { --n_strands; continue; }
     size_t free_b = 0, total_b = 0;
     WALT_HIP(hipMemGetInfo(&free_b, &total_b));
     // a small index (tests, bacterial genomes) needs no reserve: its batches are small too
     const double reserve = std::min(reserve_gb * 1e9, 0.25 * (double)total_b);
-    double budget = ((double)free_b - reserve - 16.0 * nw - 4.0 * nblk) / n_strands;  // bitmap, ranks and the builder's temporaries
+    double budget = ((double)free_b - reserve - 24.0 * nw) / n_strands;  // bitmap, ranks and the builder's temporaries
     budget = std::min(budget, cap_gb * 1e9);
     --n_strands;
     const uint64_t rec_bytes = 4ull * (kWinWords + 1 + kWinWords2);
     if (budget < 1024.0 * rec_bytes) continue;
     // record numbers must fit 32 bits: the mapping kernels pass them between lanes as one word
     const uint32_t cap_recs = (uint32_t)std::min<double>(budget / (double)rec_bytes, 4.0e9);
-    uint32_t *flag = nullptr, *rank = nullptr;
-    unsigned long long* bits = nullptr;
+    uint32_t* rank = nullptr;
+    unsigned long long *bits = nullptr, *flag = nullptr;
     int rc;
     if ((rc = dev_alloc(idx, &bits, (uint64_t)nw + 1))) return rc;
     if ((rc = dev_alloc(idx, &rank, (uint64_t)nw + 1))) return rc;
-    WALT_HIP(hipMalloc(reinterpret_cast<void**>(&flag), ((uint64_t)nblk + 1) * 4));
-    WALT_HIP(hipMemsetAsync(bits, 0, ((uint64_t)nw + 1) * 8, stream));
-    hipLaunchKernelGGL(k_win_mark, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, sv.g2, sv.ent, sv.index_size, nblk, flag);
-    hipLaunchKernelGGL(k_win_bits, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, sv.g2, sv.ent, sv.index_size, flag, nblk, bits);
+    WALT_HIP(hipMalloc(reinterpret_cast<void**>(&flag), ((uint64_t)nw + 1) * 8));  // the eq bitmap (temporary)
+    hipLaunchKernelGGL(k_win_eq, dim3((unsigned)(((uint64_t)nw * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sv.g2, sv.ent,
+                       sv.index_size, flag);
+    hipLaunchKernelGGL(k_win_bits, dim3(grid_for(nw)), dim3(kBlock), 0, stream, flag, nw, bits);
     hipError_t se = hipStreamSynchronize(stream);
     hipFree(flag);
     WALT_HIP(se);

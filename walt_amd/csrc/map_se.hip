@@ -318,7 +318,11 @@ struct HeavyStage {
   uint4* sums;       // [6][hcap]: RegionSummary of (seed, strand) = sums[(2 * seed + strand) * hcap + j]
   uint32_t* flag;    // [hcap]: 1 = the read went to the literal list at an earlier stage
   uint4* items;      // 2 * hcap items of item_quads<NW>() 16-byte words; dense items from the front, gather items from the back
-  uint32_t* ctl;     // this (chunk, stage)'s counters: [0] dense items, [1] gather items
+  uint32_t* ctl;     // this (chunk, stage)'s counters: [0] dense items, [1] gather items, [2] [3] the verifiers' cursors,
+                     // [4] reads that go on to the next stage
+  const uint32_t* list_in;  // stages 1, 2: the chunk positions j this stage visits (count in count_in[4]); else every j
+  const uint32_t* count_in;
+  uint32_t* list_out;       // stages 0, 1: positions that may need the next seed
   uint32_t hcap;     // reads per chunk
   uint32_t first;    // heavy-list index of the chunk's first read
   uint32_t stage;    // 0..2: seed shift of the stage, 3: final fold
@@ -404,19 +408,24 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       if (seed_i > hs.stage) break;
       replay = seed_i < hs.stage;  // a seed of an earlier stage: its summaries are in the state arrays
     }
-    if (replay) {
-      if (mappable) {
-        const uint4 a = hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j], c = hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j];
-        sum_p.min_mm = a.x; sum_p.count = a.y; sum_p.first = a.z; sum_p.last = a.w;
-        sum_m.min_mm = c.x; sum_m.count = c.y; sum_m.first = c.z; sum_m.last = c.w;
-      }
-    } else {
-    bool pend_p = false, pend_m = false;  // staged: the summary comes from k_se_verify
     // '+': exact (mapping.cpp:250-257 with the state after the '+' folds so far)
     bool need_p = mappable && (seed_i == 0 || (seed_i == 1 ? best.mismatch != 0 : best.mismatch > 1));
     // '-': superset of the reference's decision (see header comment)
     const uint32_t lb = best.mismatch < minus_lb ? best.mismatch : minus_lb;
     bool need_m = mappable && (seed_i == 0 || (seed_i == 1 ? lb != 0 : lb > 1));
+    if (replay) {
+      // only what the stage of this seed computed: a read that left the stage lists early (its need was already
+      // decided by part of the summaries; more of them only lower the best) has nothing valid stored for later seeds
+      if (need_p) {
+        const uint4 a = hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j];
+        sum_p.min_mm = a.x; sum_p.count = a.y; sum_p.first = a.z; sum_p.last = a.w;
+      }
+      if (need_m) {
+        const uint4 c = hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j];
+        sum_m.min_mm = c.x; sum_m.count = c.y; sum_m.first = c.z; sum_m.last = c.w;
+      }
+    } else {
+    bool pend_p = false, pend_m = false;  // staged: the summary comes from k_se_verify
     if (ablate & 4u) need_p = need_m = false;
 
     uint32_t care[kCareWords] = {0, 0, 0, 0};
@@ -631,6 +640,12 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       // this stage's summaries: what the lane worked out itself now, the items' when k_se_verify has run
       if (valid && !pend_p) hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j] = make_uint4(sum_p.min_mm, sum_p.count, sum_p.first, sum_p.last);
       if (valid && !pend_m) hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j] = make_uint4(sum_m.min_mm, sum_m.count, sum_m.first, sum_m.last);
+      if (seed_i < 2) {
+        // the next seed is probed on '+' while the best of the '+' strand is above seed_i (mapping.cpp:250-257), and
+        // never on '-' otherwise (the '-' bound is at most the '+' best); pending summaries can only lower it
+        const uint32_t known = (!pend_p && sum_p.count && sum_p.min_mm < best.mismatch) ? sum_p.min_mm : best.mismatch;
+        wave_append(mappable && known > seed_i, j, &hs.ctl[4], hs.list_out);
+      }
       break;
     }
     }  // !replay
@@ -775,9 +790,10 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
                                                     unsigned long long* __restrict__ stamps,
                                                     HeavyStage hs = HeavyStage()) {
   uint32_t n = HEAVY ? *heavy_count : n_all;
-  if constexpr (STAGED) {  // this chunk of the heavy list
+  if constexpr (STAGED) {  // this chunk of the heavy list, or what the previous stage left of it
     n = n > hs.first ? n - hs.first : 0u;
     n = n < hs.hcap ? n : hs.hcap;
+    if (hs.list_in) n = hs.count_in[4];
   }
   if (HEAVY && n == 0) return;
   __shared__ BlockShared sh;
@@ -799,9 +815,14 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
   const uint64_t o_first = offsets[0];
   // this lane's read offsets are fetched one chunk ahead
   uint64_t o_nx = 0, oe_nx = 0;
-  uint32_t r_nx = 0;
+  uint32_t r_nx = 0, j_nx = 0;
   auto fetch = [&](uint64_t i) {
-    r_nx = HEAVY ? heavy_list[(STAGED ? hs.first : 0u) + i] : (uint32_t)i;
+    if constexpr (STAGED) {
+      j_nx = hs.list_in ? hs.list_in[i] : (uint32_t)i;
+      r_nx = heavy_list[hs.first + j_nx];
+    } else {
+      r_nx = HEAVY ? heavy_list[i] : (uint32_t)i;
+    }
     o_nx = offsets[r_nx];
     oe_nx = offsets[(uint64_t)r_nx + 1];
   };
@@ -809,13 +830,13 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
   for (uint64_t c = c_lo; c < c_hi; ++c) {
     const uint64_t i64 = c * blockDim.x + threadIdx.x;
     const bool valid = i64 < n;
-    const uint32_t r = valid ? r_nx : 0;
+    const uint32_t r = valid ? r_nx : 0, j_cur = j_nx;
     const uint64_t o_cur = o_nx, oe_cur = oe_nx;
     if (c + 1 < c_hi && i64 + blockDim.x < n) fetch(i64 + blockDim.x);
     uint32_t len;
     se_process_dual<NW, DIAG, HEAVY, STAGED>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
                                              out, defer_count, defer_list, heavy_count, heavy_list, ctr, len, ablate, st, hs,
-                                             (uint32_t)i64);
+                                             j_cur);
     // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 sees every read
     if (!HEAVY) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
@@ -1030,7 +1051,7 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 // staged heavy pass: reads per chunk of the heavy list (an eighth of the batch, the whole batch when it is small)
 // and the bytes of its state behind the dense read array: [128 control words][flag][6 summaries][2 x 2 item words]
-constexpr uint32_t kHeavyCtlWords = 128;  // 4 words per (chunk, stage): up to 8 chunks x 3 stages
+constexpr uint32_t kHeavyCtlWords = 256;  // 8 words per (chunk, stage): up to 8 chunks x 3 stages
 static uint32_t se_heavy_chunk(uint32_t n) {
   const uint64_t eighth = ((uint64_t)n + 7) / 8;
   return (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (eighth > 65536 ? eighth : 65536), 64);
@@ -1038,7 +1059,7 @@ static uint32_t se_heavy_chunk(uint32_t n) {
 static uint64_t se_heavy_bytes(uint32_t n, int nw) {
   const uint64_t hcap = se_heavy_chunk(n);
   const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
-  return 16 + kHeavyCtlWords * 4 + hcap * 4 + hcap * 6 * 16 + 2 * hcap * quads * 16;
+  return 16 + kHeavyCtlWords * 4 + 3 * hcap * 4 + hcap * 6 * 16 + 2 * hcap * quads * 16;  // flag + two stage lists
 }
 
 // WALT_AMD_ABLATE (diagnostic builds of the measurement only; results are WRONG when
@@ -1110,7 +1131,8 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
     HeavyStage hs;
     hs.ctl = heavy_area;
     hs.flag = heavy_area + kHeavyCtlWords;
-    hs.sums = reinterpret_cast<uint4*>(hs.flag + hcap);
+    uint32_t* const lists = hs.flag + hcap;  // [2][hcap]: what stage 0 hands to stage 1, stage 1 to stage 2
+    hs.sums = reinterpret_cast<uint4*>(lists + 2 * (uint64_t)hcap);
     hs.items = hs.sums + (uint64_t)6 * hcap;  // 2 * hcap items of item_quads<NW>() quads
     hs.hcap = hcap;
     uint32_t* const ctl0 = heavy_area;
@@ -1129,7 +1151,11 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
       for (uint32_t stage = 0; stage < 4; ++stage) {
         hs.stage = stage;
-        hs.ctl = ctl0 + 4 * (3 * c + (stage < 3 ? stage : 0));
+        hs.ctl = ctl0 + 8 * (3 * c + (stage < 3 ? stage : 0));
+        const bool listed = stage == 1 || stage == 2;
+        hs.list_in = listed ? lists + (uint64_t)(stage - 1) * hcap : nullptr;
+        hs.count_in = listed ? ctl0 + 8 * (3 * c + stage - 1) : nullptr;
+        hs.list_out = stage < 2 ? lists + (uint64_t)stage * hcap : nullptr;
         if (diag2)
           hipLaunchKernelGGL((k_map_se<NW, true, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
