@@ -884,66 +884,76 @@ __device__ __forceinline__ uint4 lane_best_reduce(const LaneBest& a) {
   return make_uint4(mn, cnt, bcast(a.f_gp, (int)__ffsll((long long)fm) - 1), bcast(a.l_gp, (int)__ffsll((long long)lm) - 1));
 }
 
-template <int NW, bool DENSE>
-__global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
-    IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs) {
+// A pointer the kernel got inside a by-value struct is a generic pointer to the compiler, and a load through it a
+// FLAT load: it counts as vector-memory AND as LDS traffic, so that waiting for one -- or for any LDS read
+// while one is pending -- waits for every record in flight.  These loads are global by construction.
+template <class T>
+__device__ __forceinline__ T load_global(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t __attribute__((address_space(1))) gword;
+  const gword* q = reinterpret_cast<const gword*>(reinterpret_cast<uintptr_t>(p));
+  T v;
+  uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = q[i];
+  return v;
+#else
+  return *p;
+#endif
+}
+
+// the item loop of k_se_verify; FITS: the chromosome starts are in LDS (s_start), else in HBM
+template <int NW, bool DENSE, bool FITS>
+__device__ __forceinline__ void verify_items(const IndexView& iv, uint32_t strand_base, const HeavyStage& hs, uint32_t n_items,
+                                             const uint32_t* s_start, uint32_t& n_verified) {
   constexpr uint32_t Q = item_quads<NW>();
-  static_assert(Q <= 64, "an item header is fetched by one wavefront load");
-  const uint32_t n_items = hs.ctl[DENSE ? 0 : 1];
-  if (n_items == 0) return;
-  __shared__ uint32_t s_start[kLdsChroms + 1];
   const uint32_t n_chrom = iv.n_chrom, top_step = top_step_of(n_chrom);
-  const bool fits = n_chrom <= kLdsChroms;
-  if (fits)
-    for (uint32_t i = threadIdx.x; i <= n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
-  __syncthreads();
-  const uint32_t* si = fits ? s_start : iv.start_index;
   uint32_t* const cursor = &hs.ctl[DENSE ? 2 : 3];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t seed_i = hs.stage;
   const uint4 zero = make_uint4(0, 0, 0, 0);
-  uint32_t n_verified = 0;
   auto header = [&](uint32_t i, bool on) {  // lane q < Q: quad q of item i
     const uint64_t at = DENSE ? (uint64_t)i : (uint64_t)2 * hs.hcap - 1 - i;
-    return (on && lane < Q) ? hs.items[Q * at + lane] : zero;
+    // branch-free (a value loaded under a branch is waited for where the branch ends): idle lanes read quad 0
+    return load_global(hs.items + ((on && lane < Q) ? Q * at + lane : 0ull));
   };
   auto grab = [&]() {  // lane 0 holds the batch start once the atomic has returned
     uint32_t v = 0;
     if (lane == 0) v = atomicAdd(cursor, kVerifyBatch);
     return v;
   };
+  auto chrom_bounds = [&](uint32_t pos, uint32_t& c_lo, uint32_t& c_hi) {
+    if constexpr (FITS) {
+      const uint32_t chr = chrom_id_steps(s_start, n_chrom, top_step, pos);
+      c_lo = s_start[chr]; c_hi = s_start[chr + 1];
+    } else {
+      const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
+      c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
+    }
+  };
   uint32_t nb_v = grab();
   uint32_t b0 = bcast(nb_v, 0), t = 0;
   nb_v = grab();
   bool have = b0 < n_items;
   uint4 hd = header(b0, have);
-  uint4 ra = zero, rc = zero, re = zero;  // the records of the step about to be evaluated (DENSE)
-  auto issue = [&](const StrandView& sv, uint32_t rec0, uint32_t size, uint32_t base, uint4& a, uint4& c, uint4& e) {
-    const uint32_t k = base + lane;
-    const uint64_t rec = (uint64_t)rec0 + (k < size ? k : size - 1);
-    const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * rec;
-    a = rp[0];
-    c = rp[1];
-    if constexpr (NW > 7) e = reinterpret_cast<const uint4*>(sv.win2)[rec];
-  };
-  if constexpr (DENSE) {
-    if (have) issue(iv.s[strand_base + (bcast(hd.x, 0) >> 31)], bcast(hd.w, 0), bcast(hd.z, 0), 0u, ra, rc, re);
-  }
-  while (have) {
-    const uint32_t jfi = bcast(hd.x, 0), l = bcast(hd.y, 0), size = bcast(hd.z, 0), rec0 = bcast(hd.w, 0);
-    const uint32_t len = bcast(hd.x, 1);
-    uint32_t rd[NW], mk[NW];
+  // the current item, wave-uniform
+  uint32_t jfi = 0, l = 0, size = 1, rec0 = 0, len = 0, rd[NW], mk[NW];
+  auto decode = [&](const uint4& h) {
+    jfi = bcast(h.x, 0); l = bcast(h.y, 0); size = bcast(h.z, 0); rec0 = bcast(h.w, 0);
+    len = bcast(h.x, 1);
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const int a = 8 + w, c = 8 + NW + w;
-      const uint32_t va = (a & 3) == 0 ? hd.x : (a & 3) == 1 ? hd.y : (a & 3) == 2 ? hd.z : hd.w;
-      const uint32_t vc = (c & 3) == 0 ? hd.x : (c & 3) == 1 ? hd.y : (c & 3) == 2 ? hd.z : hd.w;
+      const uint32_t va = (a & 3) == 0 ? h.x : (a & 3) == 1 ? h.y : (a & 3) == 2 ? h.z : h.w;
+      const uint32_t vc = (c & 3) == 0 ? h.x : (c & 3) == 1 ? h.y : (c & 3) == 2 ? h.z : h.w;
       rd[w] = bcast(va, a >> 2);
       mk[w] = bcast(vc, c >> 2);
     }
-    const uint32_t j = jfi & 0x7FFFFFFFu, fi = jfi >> 31;
-    const StrandView& sv = iv.s[strand_base + fi];
-    // the next item: the batch's next, or the first of the batch grabbed while this one was worked on
+  };
+  // the item after it: index (the batch's next, or the first of the batch grabbed meanwhile) and header load
+  uint4 hdn = zero;
+  bool hn = false;
+  auto fetch_next = [&]() {
     uint32_t ni;
     if (t + 1 < kVerifyBatch) {
       ++t;
@@ -954,41 +964,79 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
       t = 0;
       ni = b0;
     }
-    const bool hn = ni < n_items;
-    const uint4 hdn = header(ni, hn);
-    LaneBest acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-    if constexpr (DENSE) {
-      auto consume = [&](uint32_t base) {
+    hn = ni < n_items;
+    hdn = header(ni, hn);
+  };
+  if (!have) return;
+  decode(hd);
+  fetch_next();
+  LaneBest acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+  if constexpr (DENSE) {
+    // Two record buffers used in turn (a register COPY of a loaded value waits for the load, so the buffers swap
+    // roles instead): while step s is evaluated from one, step s + 1 -- of this item, or the first of the next --
+    // is on its way into the other.  Every step issues the same loads whatever it is (uniform selects on the
+    // addresses, no branch around a load), so the wait before the evaluation leaves exactly them in flight.
+    uint4 ra0 = zero, rc0 = zero, re0 = zero, ra1 = zero, rc1 = zero, re1 = zero;
+    auto issue = [&](uint32_t fi, uint32_t r0, uint32_t sz, uint32_t base, uint4& a, uint4& c, uint4& e) {
+      const StrandView& sv = iv.s[strand_base + fi];
+      const uint32_t k = base + lane;
+      const uint64_t rec = (uint64_t)r0 + (k < sz ? k : sz - 1);
+      const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * rec;
+      a = load_global(rp);
+      c = load_global(rp + 1);
+      if constexpr (NW > 7) e = load_global(reinterpret_cast<const uint4*>(sv.win2) + rec);
+    };
+    uint32_t base = 0;
+    bool done = false;
+    auto step = [&](uint4& xa, uint4& xc, uint4& xe, uint4& ya, uint4& yc, uint4& ye) {
+      const bool last = base + 64 >= size;
+      // what the other buffer gets: this item's next step, the next item's first, or (nothing left) a repeat
+      uint32_t n_fi = jfi >> 31, n_rec0 = rec0, n_size = size, n_base = last ? 0u : base + 64;
+      if (last && hn) { n_fi = bcast(hdn.x, 0) >> 31; n_size = bcast(hdn.z, 0); n_rec0 = bcast(hdn.w, 0); }
+      issue(n_fi, n_rec0, n_size, n_base, ya, yc, ye);
+      {
         const uint32_t k = base + lane;
-        const uint32_t pos = ra.x;
-        const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos);
-        const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+        const uint32_t pos = xa.x;
+        uint32_t c_lo, c_hi;
+        chrom_bounds(pos, c_lo, c_hi);
         const uint32_t g = pos - seed_i;
         const bool ok = k < size && (pos - c_lo >= seed_i) && (g + len < c_hi);  // mapping.cpp:280-286
         uint32_t wv[NW + 1];
-        const uint32_t first[11] = {ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w,
-                                    NW > 7 ? re.x : 0u, NW > 7 ? re.y : 0u, NW > 7 ? re.z : 0u, NW > 7 ? re.w : 0u};
+        const uint32_t first[11] = {xa.y, xa.z, xa.w, xc.x, xc.y, xc.z, xc.w,
+                                    NW > 7 ? xe.x : 0u, NW > 7 ? xe.y : 0u, NW > 7 ? xe.z : 0u, NW > 7 ? xe.w : 0u};
 #pragma unroll
         for (int w = 0; w <= NW; ++w) wv[w] = w < 11 ? first[w] : 0u;
         const uint32_t m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
         n_verified += ok ? 1u : 0u;
         lane_best_add(acc, k, ok ? g : 0u, ok ? m : 0xFFFFFFFFu);
-      };
-      uint32_t base = 0;
-      for (; base + 64 < size; base += 64) {
-        uint4 na, nc, ne = zero;
-        issue(sv, rec0, size, base + 64, na, nc, ne);
-        consume(base);
-        ra = na; rc = nc; re = ne;
       }
-      {  // last step of the item: the first records of the next item are requested before it is evaluated
-        const uint32_t n_fi = bcast(hdn.x, 0) >> 31, n_size = bcast(hdn.z, 0), n_rec0 = bcast(hdn.w, 0);
-        uint4 na, nc, ne = zero;
-        issue(iv.s[strand_base + (hn ? n_fi : fi)], hn ? n_rec0 : rec0, hn ? n_size : size, 0u, na, nc, ne);
-        consume(base);
-        ra = na; rc = nc; re = ne;
+      if (last) {
+        const uint4 res = lane_best_reduce(acc);
+        if (lane == 0) hs.sums[(uint64_t)(2 * seed_i + (jfi >> 31)) * hs.hcap + (jfi & 0x7FFFFFFFu)] = res;
+        acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+        if (hn) {
+          decode(hdn);
+          fetch_next();
+          base = 0;
+        } else {
+          done = true;
+        }
+      } else {
+        base += 64;
       }
-    } else {
+    };
+    issue(jfi >> 31, rec0, size, 0u, ra0, rc0, re0);
+    for (;;) {
+      step(ra0, rc0, re0, ra1, rc1, re1);
+      if (done) break;
+      step(ra1, rc1, re1, ra0, rc0, re0);
+      if (done) break;
+    }
+  } else {
+    const uint32_t* si = FITS ? s_start : iv.start_index;
+    for (;;) {
+      const uint32_t fi = jfi >> 31;
+      const StrandView& sv = iv.s[strand_base + fi];
       DenseRange none;
       none.lo = none.hi = l;
       none.rec = 0;
@@ -998,12 +1046,30 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
         n_verified += mm[0] != 0xFFFFFFFFu ? 1u : 0u;
         lane_best_add(acc, base + lane, gp[0], mm[0]);
       }
+      const uint4 res = lane_best_reduce(acc);
+      if (lane == 0) hs.sums[(uint64_t)(2 * seed_i + fi) * hs.hcap + (jfi & 0x7FFFFFFFu)] = res;
+      acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+      if (!hn) break;
+      decode(hdn);
+      fetch_next();
     }
-    const uint4 res = lane_best_reduce(acc);
-    if (lane == 0) hs.sums[(uint64_t)(2 * seed_i + fi) * hs.hcap + j] = res;
-    hd = hdn;
-    have = hn;
   }
+}
+
+template <int NW, bool DENSE>
+__global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
+    IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs) {
+  static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
+  const uint32_t n_items = hs.ctl[DENSE ? 0 : 1];
+  if (n_items == 0) return;
+  __shared__ uint32_t s_start[kLdsChroms + 1];
+  const bool fits = iv.n_chrom <= kLdsChroms;
+  if (fits)
+    for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  __syncthreads();
+  uint32_t n_verified = 0;
+  if (fits) verify_items<NW, DENSE, true>(iv, strand_base, hs, n_items, s_start, n_verified);
+  else verify_items<NW, DENSE, false>(iv, strand_base, hs, n_items, s_start, n_verified);
   flush_counters({0u, n_verified, 0u}, 0u, stats);
 }
 
