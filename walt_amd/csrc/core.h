@@ -158,6 +158,20 @@ WALT_HD DenseRange dense_range(const StrandView& sv, uint32_t l, uint32_t size, 
   DenseRange d;
   d.lo = d.hi = l;
   d.rec = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // branch-free: the four loads are issued by every lane (a lane without a region reads word 0), so that two calls
+  // -- the two strands of a probe -- share one memory round trip instead of waiting for each other's branch
+  if (sv.wbits == nullptr) return d;  // uniform
+  const bool on = usable && size;
+  const uint32_t first = on ? l : 0u, last = on ? l + size - 1 : 0u;
+  const unsigned long long b0 = sv.wbits[first >> 6], b1 = sv.wbits[last >> 6];
+  const uint32_t k0 = sv.wrank[first >> 6], k1 = sv.wrank[last >> 6];
+  const uint32_t r0 = k0 + popc64(b0 & ((1ull << (first & 63u)) - 1ull)), r1 = k1 + popc64(b1 & ((1ull << (last & 63u)) - 1ull));
+  if (on && ((b0 >> (first & 63u)) & 1ull) && ((b1 >> (last & 63u)) & 1ull) && r1 - r0 == size - 1 && r1 < sv.wcap) {
+    d.hi = l + size;
+    d.rec = r0;
+  }
+#else
   if (usable && size) {
     const uint32_t last = l + size - 1;
     const unsigned long long b0 = sv.wbits[l >> 6], b1 = sv.wbits[last >> 6];
@@ -168,6 +182,7 @@ WALT_HD DenseRange dense_range(const StrandView& sv, uint32_t l, uint32_t size, 
       d.rec = r0;
     }
   }
+#endif
   return d;
 }
 

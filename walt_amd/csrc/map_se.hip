@@ -541,19 +541,26 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     //  * only the larger ones take the whole wavefront.
     DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, size_p > kMidRegion && win_usable<NW>(svp, lr.len));
     DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, size_m > kMidRegion && win_usable<NW>(svm, lr.len));
+    // mid regions: a lane usually has one, on either strand, so the strands are not taken in turn: in the first
+    // pass every lane works on its '+' mid region, or on its '-' one if it has no '+'; the second pass (skipped
+    // unless some lane has both) takes the remaining '-' ones.  All loads of a round are unconditional (idle
+    // candidates read the first words of the genome): a load under `if (candidate ok)` is waited for at the end of
+    // its branch, which made the four candidates of a round four round trips.
+    {
+      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kMidRegion) ? size_p : 0u;
+      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kMidRegion) ? size_m : 0u;
 #pragma unroll 1
-    for (uint32_t fi = 0; fi < 2; ++fi) {
-      const StrandView& sv = fi ? svm : svp;
-      const uint32_t my_size = fi ? size_m : size_p;
-      const uint32_t my_l = fi ? lm.reg.l : lp.reg.l;
-      const uint32_t nmid = (my_size > kSmallRegion && my_size <= kMidRegion) ? my_size : 0u;
-      if (__ballot(nmid != 0)) {
+      for (uint32_t pass = 0; pass < 2; ++pass) {
+        const bool on_m = pass == 0 ? (nmid_p == 0 && nmid_m != 0) : (nmid_p != 0 && nmid_m != 0);
+        const bool on_p = pass == 0 && nmid_p != 0;
+        const uint32_t nmid = on_p ? nmid_p : (on_m ? nmid_m : 0u);
+        if (!__ballot(nmid != 0)) continue;
+        const Ent* const ent = on_m ? svm.ent : svp.ent;
+        const uint32_t* const g2 = on_m ? svm.g2 : svp.g2;
+        const uint32_t my_l = nmid ? (on_m ? lm.reg.l : lp.reg.l) : 0u;
         uint32_t posb[kMidRegion];
 #pragma unroll
-        for (uint32_t k = 0; k < kMidRegion; ++k) {
-          posb[k] = 0;
-          if (k < nmid) posb[k] = sv.ent[my_l + k].pos;
-        }
+        for (uint32_t k = 0; k < kMidRegion; ++k) posb[k] = ent[my_l + (k < nmid ? k : 0u)].pos;
         RegionSummary acc = summary_empty();
 #pragma unroll 1
         for (uint32_t k0 = 0; k0 < kMidRegion; k0 += 4) {
@@ -561,48 +568,51 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
           bool ok[4];
           uint32_t gpv[4], win[4][NW + 1];
 #pragma unroll
-          for (uint32_t j = 0; j < 4; ++j) {
-            // posb[k0 + j] by selects (k0 is not a compile-time constant: indexing would go to scratch)
+          for (uint32_t jj = 0; jj < 4; ++jj) {
+            // posb[k0 + jj] by selects (k0 is not a compile-time constant: indexing would go to scratch)
             uint32_t pos = 0;
 #pragma unroll
-            for (uint32_t k = j; k < kMidRegion; k += 4) pos = (k == k0 + j) ? posb[k] : pos;
+            for (uint32_t k = jj; k < kMidRegion; k += 4) pos = (k == k0 + jj) ? posb[k] : pos;
             uint32_t c_lo, c_hi;
             if (n_chrom <= kLdsChroms) {
               const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, pos);
               c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
             } else {
-              const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos);
-              c_lo = si[chr]; c_hi = si[chr + 1];
+              const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
+              c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
             }
             const uint32_t g = pos - seed_i;
-            ok[j] = k0 + j < nmid && (pos - c_lo >= seed_i) && (g + lr.len < c_hi);  // mapping.cpp:280-286
-            gpv[j] = ok[j] ? g : 0u;
+            ok[jj] = k0 + jj < nmid && (pos - c_lo >= seed_i) && (g + lr.len < c_hi);  // mapping.cpp:280-286
+            gpv[jj] = ok[jj] ? g : 0u;
+            const uint32_t* gw = g2 + (gpv[jj] >> 4);
 #pragma unroll
-            for (int w = 0; w <= NW; ++w) win[j][w] = 0;
-            if (ok[j]) {
-              const uint32_t* gw = sv.g2 + (g >> 4);
+            for (int w = 0; w <= NW; w += 4) {
+              constexpr int kAll = NW + 1;
+              const int cnt = kAll - w < 4 ? kAll - w : 4;
+              uint32_t q[4] = {0, 0, 0, 0};
+              __builtin_memcpy(q, gw + w, 4 * cnt);
 #pragma unroll
-              for (int w = 0; w <= NW; w += 4) {
-                constexpr int kAll = NW + 1;
-                const int cnt = kAll - w < 4 ? kAll - w : 4;
-                uint32_t q[4] = {0, 0, 0, 0};
-                __builtin_memcpy(q, gw + w, 4 * cnt);
-#pragma unroll
-                for (int t = 0; t < cnt; ++t) win[j][w + t] = q[t];
-              }
+              for (int t = 0; t < cnt; ++t) win[jj][w + t] = q[t];
             }
           }
 #pragma unroll
-          for (uint32_t j = 0; j < 4; ++j) {
-            if (ok[j]) {
-              const uint32_t mm = count_mismatch_regs<NW>(win[j], 2 * (gpv[j] & 15u), lr.rd, mk);
-              acc = summary_merge(acc, summary_one(mm, gpv[j]));
+          for (uint32_t jj = 0; jj < 4; ++jj) {
+            const uint32_t mm = count_mismatch_regs<NW>(win[jj], 2 * (gpv[jj] & 15u), lr.rd, mk);
+            if (ok[jj]) {
+              acc = summary_merge(acc, summary_one(mm, gpv[jj]));
               ++ctr.verified;
             }
           }
         }
-        if (nmid) { if (fi) sum_m = acc; else sum_p = acc; }
+        if (on_p) sum_p = acc;
+        if (on_m) sum_m = acc;
       }
+    }
+#pragma unroll 1
+    for (uint32_t fi = 0; fi < 2; ++fi) {
+      const StrandView& sv = fi ? svm : svp;
+      const uint32_t my_size = fi ? size_m : size_p;
+      const uint32_t my_l = fi ? lm.reg.l : lp.reg.l;
       if constexpr (STAGED) {
         const bool bigr = my_size > kMidRegion;
         const DenseRange& dr = fi ? dr_m : dr_p;
