@@ -391,6 +391,8 @@ def pe_leg(cx, idx, d1, d2, d_off, n, read_len, max_mm, b, top_k, frag_range, st
     ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last pass (map_pe.hip carve_pe)
     return {"elapsed": elapsed, "per_step": per_step, "d_out": d_out, "stats": st,
             "lists": {"literal": [int(ctl[64]), int(ctl[96])], "overflowed_small_heaps": [int(ctl[89]), int(ctl[121])],
+                      "staged": [int(ctl[88]), int(ctl[120])], "staged_fallback": [int(ctl[90]), int(ctl[122])],
+                      "staged_items": [[int(ctl[92]), int(ctl[93])], [int(ctl[124]), int(ctl[125])]],
                       "heavy_pairs": int(ctl[128])}}
 
 
@@ -749,6 +751,9 @@ def worker(args):
                          timed_barrier=headline)
             elapsed = wdist.allreduce_max(leg["elapsed"], device=dev if not shared_gpu else "cpu") if headline else leg["elapsed"]
             log("%s paired-end 2 x %d bp: %.1f ms/step; lists %s" % (tag, rl, 1e3 * elapsed / steps, leg["lists"]))
+            log("  device counters per pair: probes %.2f, candidates verified %.1f, large regions %.3f" % (
+                (float(leg["stats"][1]) + float(leg["stats"][5])) / npairs, (float(leg["stats"][2]) + float(leg["stats"][6])) / npairs,
+                (float(leg["stats"][3]) + float(leg["stats"][7])) / npairs))
             words = leg["d_out"].view(torch.int32).view(npairs, 16)
             vec = wdist.pe_stats_vector(words, args.frag_range, int(leg["stats"][0]), int(leg["stats"][4]))
             vec_local = vec.cpu().numpy().astype(np.uint64)

@@ -1,0 +1,266 @@
+// map_items.h -- work items for large candidate regions and the loop that streams them (single-end heavy stages,
+// map_se.hip; paired-end complex reads, map_pe.hip).
+//
+// A region of more than a few candidates is not verified by the lane that found it (its 63 wave-mates would wait)
+// nor by borrowing that lane's wavefront (its registers hold 64 reads' state: three wavefronts per SIMD); the lane
+// writes an ITEM and a second kernel takes one item per wavefront.  An item carries everything the verification
+// needs, so the verifier's only dependent loads are the candidates' own:
+//   quad 0   id (the producer's: which read / probe), first slot l, size, first dense record or kItemDenseNone
+//            (record numbers stay below 2^32, device_index.hip build_windows)
+//   quad 1   read length, seed shift, 0, 0
+//   then     the converted read rd[NW] and its compare masks mk[NW] for that seed shift, padded to 16 bytes
+// Items whose candidates all have dense records (core.h dense_range) are queued from the front of the array,
+// the others from its back; each kind has its own verifier instance.
+#ifndef WALT_AMD_MAP_ITEMS_H_
+#define WALT_AMD_MAP_ITEMS_H_
+
+#include "map_common.h"
+
+namespace walt {
+
+constexpr uint32_t kItemDenseNone = 0xFFFFFFFFu;
+// Items a wavefront takes per visit to the queue's cursor: every visit is an atomic on ONE address, and the device
+// serves about a hundred million of those per second -- a million items taken eight at a time spent half the
+// verifier's time queueing for the cursor.  So: a quarter of a wavefront's fair share, at most kVerifyBatchMax.
+constexpr uint32_t kVerifyBatchMax = 32;
+
+struct ItemQueue {
+  uint4* items;   // cap items of item_quads<NW>() quads
+  uint32_t* ctl;  // [0] dense items, [1] gather items, [2] [3] the verifiers' cursors (zeroed by the host)
+  uint32_t cap;   // items the array has room for, both kinds together
+};
+
+template <int NW>
+constexpr uint32_t item_quads() { return 2u + (2u * NW + 3u) / 4u; }
+
+// All 64 lanes call this; lanes with `take` append one item each (one atomic per wavefront and kind).
+template <int NW>
+__device__ __forceinline__ void item_append(bool take, bool dense, uint32_t id, uint32_t l, uint32_t size, uint32_t rec,
+                                            uint32_t len, uint32_t seed_i, const uint32_t* rd, const uint32_t* mk,
+                                            const ItemQueue& q) {
+  constexpr uint32_t Q = item_quads<NW>();
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const bool mine = take && (dense == (side == 0));
+    const unsigned long long m = __ballot(mine);
+    if (!m) continue;
+    const int leader = (int)__ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&q.ctl[side], (uint32_t)__popcll(m));
+    base = bcast(base, leader);
+    if (mine) {
+      const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      const uint64_t at = side == 0 ? k : (uint64_t)q.cap - 1 - k;
+      uint4* it = q.items + Q * at;
+      it[0] = make_uint4(id, l, size, rec);
+      it[1] = make_uint4(len, seed_i, 0u, 0u);
+      uint32_t w[4 * (Q - 2)];
+#pragma unroll
+      for (uint32_t t = 0; t < 4 * (Q - 2); ++t) w[t] = t < (uint32_t)NW ? rd[t] : (t < 2u * NW ? mk[t - NW] : 0u);
+#pragma unroll
+      for (uint32_t qd = 0; qd + 2 < Q; ++qd) it[2 + qd] = make_uint4(w[4 * qd], w[4 * qd + 1], w[4 * qd + 2], w[4 * qd + 3]);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+// A pointer the kernel got inside a by-value struct is a generic pointer to the compiler, and a load through it a
+// FLAT load: it counts as vector-memory AND as LDS traffic, so that waiting for one -- or for any LDS read
+// while one is pending -- waits for every record in flight.  These loads are global by construction.
+template <class T>
+__device__ __forceinline__ T load_global(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t __attribute__((address_space(1))) gword;
+  const gword* q = reinterpret_cast<const gword*>(reinterpret_cast<uintptr_t>(p));
+  T v;
+  uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = q[i];
+  return v;
+#else
+  return *p;
+#endif
+}
+
+// The item loop of a verifier kernel: one region per wavefront, everything about the item wave-uniform, so a lane
+// carries little besides the records it has in flight and the kernel runs at high occupancy.  Wavefronts take
+// items in batches from the queue's cursor (regions run from 17 to `-b` candidates: a static deal
+// leaves a long tail).
+//   DENSE = true:  every candidate has a dense record: 32 (48) sequential bytes each, 64 candidates per step, two
+//                  record buffers used in turn (a register COPY of a loaded value waits for the load, so the buffers
+//                  swap roles instead): while step s is evaluated from one, step s + 1 -- of this item, or the
+//                  first of the next -- is on its way into the other.  Every step issues the same loads whatever
+//                  it is (uniform selects on the addresses, no branch around a load), so the wait before the
+//                  evaluation leaves exactly them in flight.
+//   DENSE = false: index entry, then the genome window (coop_verify_groups' gather route).
+//   FITS:          the chromosome starts are in LDS (s_start), else read from HBM.
+// Sink (all calls wave-uniform):  strand(id) -> 0 / 1;  begin(id, seed_i, position in the queue);  add(k, gp, mm) per lane and step
+// (k = slot offset in the region, mm = 0xFFFFFFFF when the slot is beyond the region or fails the edge filters of
+// mapping.cpp:280-286 / paired.cpp:166-171);  step() after every 64 candidates;  end().
+template <int NW, bool DENSE, bool FITS, class Sink>
+__device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand_base, const ItemQueue& q, uint32_t n_items,
+                                            const uint32_t* s_start, Sink& sink) {
+  constexpr uint32_t Q = item_quads<NW>();
+  const uint32_t n_chrom = iv.n_chrom, top_step = top_step_of(n_chrom);
+  uint32_t* const cursor = &q.ctl[DENSE ? 2 : 3];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  auto header = [&](uint32_t i, bool on) {  // lane t < Q: quad t of item i
+    const uint64_t at = DENSE ? (uint64_t)i : (uint64_t)q.cap - 1 - i;
+    // branch-free (a value loaded under a branch is waited for where the branch ends): idle lanes read quad 0
+    return load_global(q.items + ((on && lane < Q) ? Q * at + lane : 0ull));
+  };
+  // The first batch of every wavefront is dealt statically (wave w: items [w * batch, (w + 1) * batch)), the cursor
+  // hands out what lies behind those: a launch with few items -- the later stages -- makes no atomic at all
+  // (two per wavefront, as it was, cost a nearly empty launch 0.6 ms).
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t batch = n_items / (4 * n_waves);
+  batch = batch < 1 ? 1u : (batch > kVerifyBatchMax ? kVerifyBatchMax : batch);
+  const uint32_t dealt = n_waves * batch;
+  auto grab = [&]() {  // lane 0 holds the batch start once the atomic has returned
+    uint32_t v = 0;
+    if (lane == 0) v = dealt + atomicAdd(cursor, batch);
+    return v;
+  };
+  auto chrom_bounds = [&](uint32_t pos, uint32_t& c_lo, uint32_t& c_hi) {
+    if constexpr (FITS) {  // through the LDS array itself: through a pointer that may be either, the reads would be FLAT loads
+      const uint32_t chr = chrom_id_steps(s_start, n_chrom, top_step, pos);
+      c_lo = s_start[chr]; c_hi = s_start[chr + 1];
+    } else {
+      const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
+      c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
+    }
+  };
+  uint32_t b0 = wave * batch, t = 0;
+  if (b0 >= n_items) return;
+  uint32_t nb_v = 0;        // lane 0: start of the next batch, asked for when the current batch's last item begins
+  bool asked = false;
+  if (batch == 1 && dealt < n_items) {  // the first item is its batch's last
+    nb_v = grab();
+    asked = true;
+  }
+  uint4 hd = header(b0, true);
+  // the current item, wave-uniform
+  uint32_t id = 0, l = 0, size = 1, rec0 = 0, len = 0, seed_i = 0, rd[NW], mk[NW];
+  auto decode = [&](const uint4& h) {
+    id = bcast(h.x, 0); l = bcast(h.y, 0); size = bcast(h.z, 0); rec0 = bcast(h.w, 0);
+    len = bcast(h.x, 1); seed_i = bcast(h.y, 1);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int a = 8 + w, c = 8 + NW + w;
+      const uint32_t va = (a & 3) == 0 ? h.x : (a & 3) == 1 ? h.y : (a & 3) == 2 ? h.z : h.w;
+      const uint32_t vc = (c & 3) == 0 ? h.x : (c & 3) == 1 ? h.y : (c & 3) == 2 ? h.z : h.w;
+      rd[w] = bcast(va, a >> 2);
+      mk[w] = bcast(vc, c >> 2);
+    }
+  };
+  // the item after it: index (the batch's next, or the first of the batch grabbed meanwhile) and header load
+  uint4 hdn = zero;
+  bool hn = false;
+  uint32_t cur_i = b0, ni = 0;  // queue positions of the current and the next item
+  auto fetch_next = [&]() {
+    if (t + 1 < batch) {
+      ++t;
+      ni = b0 + t;
+    } else {
+      b0 = asked ? bcast(nb_v, 0) : 0xFFFFFFFFu;  // (asked: the atomic was issued one item ago)
+      asked = false;
+      t = 0;
+      ni = b0;
+    }
+    if (t + 1 == batch && ni < n_items && dealt < n_items) {  // ni is the batch's last item: ask for the batch after it
+      nb_v = grab();
+      asked = true;
+    }
+    hn = ni < n_items;
+    hdn = header(ni, hn);
+  };
+  decode(hd);
+  fetch_next();
+  sink.begin(id, seed_i, cur_i);
+  if constexpr (DENSE && NW <= 10) {
+    uint4 ra0 = zero, rc0 = zero, re0 = zero, ra1 = zero, rc1 = zero, re1 = zero;
+    auto issue = [&](uint32_t fi, uint32_t r0, uint32_t sz, uint32_t base, uint4& a, uint4& c, uint4& e) {
+      const StrandView& sv = iv.s[strand_base + fi];
+      const uint32_t k = base + lane;
+      const uint64_t rec = (uint64_t)r0 + (k < sz ? k : sz - 1);
+      const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * rec;
+      a = load_global(rp);
+      c = load_global(rp + 1);
+      if constexpr (NW > 7) e = load_global(reinterpret_cast<const uint4*>(sv.win2) + rec);
+    };
+    uint32_t base = 0;
+    bool done = false;
+    auto step = [&](uint4& xa, uint4& xc, uint4& xe, uint4& ya, uint4& yc, uint4& ye) {
+      const bool last = base + 64 >= size;
+      // what the other buffer gets: this item's next step, the next item's first, or (nothing left) a repeat
+      uint32_t n_fi = Sink::strand(id), n_rec0 = rec0, n_size = size;
+      const uint32_t n_base = last ? 0u : base + 64;
+      if (last && hn) { n_fi = Sink::strand(bcast(hdn.x, 0)); n_size = bcast(hdn.z, 0); n_rec0 = bcast(hdn.w, 0); }
+      issue(n_fi, n_rec0, n_size, n_base, ya, yc, ye);
+      {
+        const uint32_t k = base + lane;
+        const uint32_t pos = xa.x;
+        uint32_t c_lo, c_hi;
+        chrom_bounds(pos, c_lo, c_hi);
+        const uint32_t g = pos - seed_i;
+        const bool ok = k < size && (pos - c_lo >= seed_i) && (g + len < c_hi);
+        uint32_t wv[NW + 1];
+        const uint32_t first[11] = {xa.y, xa.z, xa.w, xc.x, xc.y, xc.z, xc.w,
+                                    NW > 7 ? xe.x : 0u, NW > 7 ? xe.y : 0u, NW > 7 ? xe.z : 0u, NW > 7 ? xe.w : 0u};
+#pragma unroll
+        for (int w = 0; w <= NW; ++w) wv[w] = w < 11 ? first[w] : 0u;
+        const uint32_t m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
+        sink.add(k, ok ? g : 0u, ok ? m : 0xFFFFFFFFu);
+        sink.step();
+      }
+      if (last) {
+        sink.end();
+        if (hn) {
+          decode(hdn);
+          cur_i = ni;
+          fetch_next();
+          sink.begin(id, seed_i, cur_i);
+          base = 0;
+        } else {
+          done = true;
+        }
+      } else {
+        base += 64;
+      }
+    };
+    issue(Sink::strand(id), rec0, size, 0u, ra0, rc0, re0);
+    for (;;) {
+      step(ra0, rc0, re0, ra1, rc1, re1);
+      if (done) break;
+      step(ra1, rc1, re1, ra0, rc0, re0);
+      if (done) break;
+    }
+  } else {
+    const uint32_t* si = FITS ? s_start : iv.start_index;
+    for (;;) {
+      const StrandView& sv = iv.s[strand_base + Sink::strand(id)];
+      DenseRange none;
+      none.lo = none.hi = l;
+      none.rec = 0;
+      for (uint32_t base = 0; base < size; base += 64) {
+        uint32_t gp[1], mm[1];
+        coop_verify_groups<NW, 1>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, none, gp, mm);
+        sink.add(base + lane, gp[0], mm[0]);
+        sink.step();
+      }
+      sink.end();
+      if (!hn) break;
+      decode(hdn);
+      cur_i = ni;
+      fetch_next();
+      sink.begin(id, seed_i, cur_i);
+    }
+  }
+}
+
+}  // namespace walt
+#endif  // WALT_AMD_MAP_ITEMS_H_

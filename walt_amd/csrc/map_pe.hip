@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include "map_common.h"
+#include "map_items.h"
 
 namespace walt {
 
@@ -388,6 +389,399 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   pe_flush(shortv, n_probe, n_verified, 0, stats);
 }
 
+// ---------------------------------------------------------------------------
+// Staged path for the complex reads (and the reads that met the chromosome-end filter): on a repeat-rich genome a
+// few per cent of the reads own nearly all candidates -- thousands each, because a heap that is not full takes no
+// early exit -- and the list kernel below, which verifies a region with the wavefront of the lane that owns it
+// and keeps that wavefront's heaps in LDS, runs them at a wavefront and a half per SIMD.  Here instead:
+//   k_pe_stage   one read per lane: all six probes (a superset of the reference's: its exits need a full heap),
+//                both strands of a seed shift looked up together; regions of up to kMidRegion candidates are
+//                verified in place and their SURVIVORS (mismatches <= -m, in slot order) stored per probe;
+//                larger regions become work items (map_items.h).  The exact chromosome-end test runs here;
+//                only truly dangerous reads go on to the literal list.
+//   k_pe_verify  one region per wavefront (item_stream): survivors appended in slot order to the probe's list.
+//                Filter: a candidate is dropped when top_k earlier survivors OF THE SAME REGION have no more
+//                mismatches than it has -- the heap is then full of candidates at least as good, and
+//                TopCandidates::Push (paired.hpp:63-70) would refuse it whatever else the heap holds.
+//   k_pe_push    one read per lane: the probes in the reference's order (+s0 +s1 +s2 -s0 -s1 -s2) under its exact
+//                exits (paired.cpp:133-149; a probe after an exit is simply not read), survivors pushed in slot
+//                order into the read's heap (LDS), heap popped into the ranked list.
+// A read whose probe keeps more survivors than kPeChunks chunks hold, or beyond the staged capacity of the pass, goes
+// to the list kernel as before.  The reads with a truly dangerous probe take the same three kernels in a second
+// round (LITERAL = true: the dangerous probes' regions come from the literal search, core.h seed_lookup_ex).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kPeMidRegion = 16;  // regions up to this size are verified by their own lane
+constexpr uint32_t kPeChunkEnts = 64;  // survivors per chunk of the pool
+constexpr uint32_t kPeChunks = 8;      // chunks a probe may take (512 survivors); more: the list kernel maps the read
+
+// Survivors {position, mismatches} of probe p of staged read j.  A region verified in place has at most
+// kPeMidRegion of them: inl[(p * kPeMidRegion + k) * ccap + j].  An item's survivors go to chunks of kPeChunkEnts
+// taken from a pool as they come (their number is not known beforehand and runs from none to hundreds):
+// chunk[(p * kPeChunks + c) * ccap + j] = number of the c-th chunk.  surv_n[p * ccap + j] = count, bit 31: chunked.
+struct PeStage {
+  uint2* inl;
+  uint32_t* surv_n;
+  uint32_t* cz;      // [p * ccap + j]: the probe's survivors with 0 mismatches | those with at most 1 << 16 (each capped at 65535)
+  uint32_t* chunk;
+  uint2* pool;
+  uint32_t* pool_next;   // chunks handed out from the dynamic part
+  uint32_t pool_chunks;  // chunks the pool holds
+  uint32_t static_n;     // the first chunk of dense item i of seed s is chunk s * static_n + i while i < static_n (no
+                         // atomic: same-address atomics run at ~10 ns each, and nearly every item takes one chunk);
+                         // the dynamic part starts at 3 * static_n
+  uint32_t* flag;    // [j]: 1 = gone to the literal list, 2 = a probe outgrew its chunks or the pool
+  ItemQueue q;       // 6 * ccap items; id = j | probe << 24, probe = 3 * strand + seed shift
+  uint32_t ccap;     // staged reads per pass and mate
+};
+
+template <int NW, bool LITERAL>
+__device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
+                                              const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets,
+                                              uint32_t* __restrict__ err, uint32_t r, bool valid, uint32_t j,
+                                              uint32_t strand_base, uint32_t max_mm, uint32_t b, const PeStage& ps,
+                                              uint32_t* __restrict__ lit_count, uint32_t* __restrict__ lit_list,
+                                              uint32_t stage_seed, uint32_t top_k, uint32_t& n_probe, uint32_t& n_verified,
+                                              uint32_t& n_big) {
+  const uint32_t n_chrom = iv.n_chrom;
+  const uint32_t top_step = top_step_of(n_chrom);
+  const StrandView& svp = iv.s[strand_base];
+  const StrandView& svm = iv.s[strand_base + 1];
+  const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
+  LaneRead<NW> lr;
+  {
+    uint64_t o = 0, oe = 0;
+    if (valid) { o = offsets[r]; oe = offsets[r + 1]; }
+    lane_load_read<NW>(lr, codes2, offsets[0], o, oe, valid, ga, err, iv);
+  }
+  bool mappable = valid && lr.len >= kMinReadLen;
+  bool dead = false;
+  uint32_t defer_iter = 0;
+  const uint64_t ccap = ps.ccap;
+  uint32_t z0_p = 0, z1_p = 0, z0_m = 0, z1_m = 0;  // this seed's in-place survivors with 0 / at most 1 mismatches
+  auto keep = [&](uint32_t probe, uint32_t& cnt, uint32_t& z0, uint32_t& z1, bool ok, uint32_t gp, uint32_t mm) {  // survivors of an in-place region
+    if (ok && mm <= max_mm) {  // paired.cpp:192-195
+      ps.inl[((uint64_t)probe * kPeMidRegion + cnt) * ccap + j] = make_uint2(gp, mm);
+      ++cnt;
+      z0 += mm == 0 ? 1u : 0u;
+      z1 += mm <= 1 ? 1u : 0u;
+    }
+  };
+  // Which of this seed's two probes the reference can still make (paired.cpp:133-149: it stops a strand once the heap
+  // is full of candidates with no mismatch, from seed 2 on with at most one).  The heap holds the top_k best of what
+  // was pushed, so that is: top_k pushed candidates that good.  Counted over the probes of the earlier seeds that
+  // were made (a '+' probe of THIS seed or a later one could only add to what the '-' strand sees): never a
+  // probe dropped that the reference makes; k_pe_push applies the exact exits.
+  bool need_p = mappable, need_m = mappable;
+  if (stage_seed > 0 && valid) {
+    if (ps.flag[j] & 1u) mappable = need_p = need_m = false;  // went to the literal list at an earlier seed
+    auto zeros = [&](uint32_t probe, bool made, uint32_t& a0, uint32_t& a1) {
+      const uint32_t v = made ? ps.cz[(uint64_t)probe * ccap + j] : 0u;
+      a0 += v & 0xFFFFu;
+      a1 += v >> 16;
+    };
+    uint32_t p0 = 0, p1 = 0, a0 = 0, a1 = 0;  // '+' strand so far; both strands so far
+    zeros(0, true, p0, p1);
+    const bool made_p1 = p0 < top_k;                       // +s1 is made unless +s0 filled the heap with exact matches
+    uint32_t m0 = 0, m1 = 0;
+    zeros(3, true, m0, m1);
+    const bool made_m1 = p0 + m0 < top_k;                  // (superset) -s1
+    if (stage_seed == 1) {
+      need_p = need_p && made_p1;
+      need_m = need_m && made_m1;
+    } else {
+      zeros(1, made_p1, p0, p1);
+      zeros(4, made_m1, m0, m1);
+      need_p = need_p && p1 < top_k;                       // +s2: unless top_k candidates with at most one mismatch on '+'
+      need_m = need_m && p1 + m1 < top_k;
+    }
+    (void)a0; (void)a1;
+  }
+
+#pragma unroll 1
+  for (uint32_t seed_i = stage_seed; seed_i <= stage_seed; ++seed_i) {
+    bool need = need_p || need_m;
+    uint32_t care[kCareWords] = {0, 0, 0, 0};
+    uint32_t slot = 0, span = 0;
+    if (need) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
+    const uint32_t bkey = bloom_key_of_care(care);
+    uint64_t bw_p = 0, bw_m = 0;
+    if (need_p && prefilter_hit(pf, 0, bkey)) bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
+    if (need_m && prefilter_hit(pf, 1, bkey)) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
+    SlotProbe pp, pm;
+    uint32_t hi_p, hi_m;
+    probe_issue(svp, need_p, slot, span, pp, hi_p);
+    probe_issue(svm, need_m, slot, span, pm, hi_m);
+    const bool bad_p = need_p && bw_p && danger_filter_hit(bw_p, care);
+    const bool bad_m = need_m && bw_m && danger_filter_hit(bw_m, care);
+    bool lit_p = false, lit_m = false;  // LITERAL: this strand's region comes from the literal search
+    if (bad_p || bad_m) {  // the filter is a superset: the exact test decides
+      const bool dng_p = bad_p && probe_is_dangerous(svp, care, seed_len_of(lr.repeats));
+      const bool dng_m = bad_m && probe_is_dangerous(svm, care, seed_len_of(lr.repeats));
+      if (LITERAL) {
+        lit_p = dng_p;
+        lit_m = dng_m;
+      } else if (dng_p || dng_m) {
+        dead = true;
+        mappable = false;
+        need = need_p = need_m = false;
+        defer_iter = seed_i + (dng_p ? 0u : 3u);
+      }
+    }
+    pp.ne = (need_p && !lit_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
+    pm.ne = (need_m && !lit_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
+    probe_entries(svp, pp);
+    probe_entries(svm, pm);
+    Lookup lp, lm;
+    bool tail_p, tail_m;
+    probe_resolve_dual<(NW > 8)>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m);
+    if constexpr (LITERAL) {  // LowerBound / UpperBound as the reference runs them (the lanes of a wave come sorted by iteration)
+      if (lit_p && need_p) { seed_lookup_ex(iv, svp, care, slot, span, seed_len_of(lr.repeats), lp, false); tail_p = false; }
+      if (lit_m && need_m) { seed_lookup_ex(iv, svm, care, slot, span, seed_len_of(lr.repeats), lm, false); tail_m = false; }
+    }
+    uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
+    uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
+    n_probe += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
+    if (size_p > b) size_p = 0;  // paired.cpp:161-163
+    if (size_m > b) size_m = 0;
+    uint32_t mk[NW];
+    make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
+    const uint32_t probe_p = seed_i, probe_m = 3 + seed_i;
+    uint32_t cnt_p = 0, cnt_m = 0;
+    // regions of up to kSmallRegion candidates: candidate k of both strands side by side (positions in registers)
+    const bool small_p = size_p && size_p <= kSmallRegion, small_m = size_m && size_m <= kSmallRegion;
+    if (small_p || small_m) {
+      const uint32_t kmax = (small_p ? size_p : 0u) > (small_m ? size_m : 0u) ? size_p : (small_m ? size_m : size_p);
+#pragma unroll 1
+      for (uint32_t k = 0; k < kmax; ++k) {
+        const bool act_p = small_p && k < size_p, act_m = small_m && k < size_m;
+        uint32_t pos_p = k == 0 ? lp.pos[0] : k == 1 ? lp.pos[1] : k == 2 ? lp.pos[2] : lp.pos[3];
+        uint32_t pos_m = k == 0 ? lm.pos[0] : k == 1 ? lm.pos[1] : k == 2 ? lm.pos[2] : lm.pos[3];
+        if (act_p && k >= lp.npos) pos_p = svp.ent[lp.reg.l + k].pos;
+        if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
+        bool ok_p, ok_m;
+        uint32_t gp_p, gp_m, mm_p, mm_m;
+        verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+        verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+        if (NW > 8) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
+          const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, lr.repeats), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, lr.repeats);
+          ok_p = ok_p && (!tail_p || t_p);
+          ok_m = ok_m && (!tail_m || t_m);
+        }
+        n_verified += (ok_p ? 1u : 0u) + (ok_m ? 1u : 0u);
+        keep(probe_p, cnt_p, z0_p, z1_p, ok_p, gp_p, mm_p);
+        keep(probe_m, cnt_m, z0_m, z1_m, ok_m, gp_m, mm_m);
+      }
+    }
+    // mid regions (map_se.hip heavy stages): one pass for the lanes' '+' (or only '-') region, a second for the rest
+    {
+      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kPeMidRegion) ? size_p : 0u;
+      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kPeMidRegion) ? size_m : 0u;
+#pragma unroll 1
+      for (uint32_t pass = 0; pass < 2; ++pass) {
+        const bool on_m = pass == 0 ? (nmid_p == 0 && nmid_m != 0) : (nmid_p != 0 && nmid_m != 0);
+        const bool on_p = pass == 0 && nmid_p != 0;
+        const uint32_t nmid = on_p ? nmid_p : (on_m ? nmid_m : 0u);
+        if (!__ballot(nmid != 0)) continue;
+        const Ent* const ent = on_m ? svm.ent : svp.ent;
+        const uint32_t* const g2 = on_m ? svm.g2 : svp.g2;
+        const uint32_t my_l = nmid ? (on_m ? lm.reg.l : lp.reg.l) : 0u;
+        const uint32_t probe = on_m ? probe_m : probe_p;
+        uint32_t posb[kPeMidRegion];
+#pragma unroll
+        for (uint32_t k = 0; k < kPeMidRegion; ++k) posb[k] = ent[my_l + (k < nmid ? k : 0u)].pos;
+        uint32_t cnt = 0, y0 = 0, y1 = 0;
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < kPeMidRegion; k0 += 4) {
+          if (!__ballot(k0 < nmid)) break;
+          bool ok[4];
+          uint32_t gpv[4], win[4][NW + 1];
+#pragma unroll
+          for (uint32_t jj = 0; jj < 4; ++jj) {
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t k = jj; k < kPeMidRegion; k += 4) pos = (k == k0 + jj) ? posb[k] : pos;
+            uint32_t c_lo, c_hi;
+            if (n_chrom <= kLdsChroms) {
+              const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, pos);
+              c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
+            } else {
+              const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
+              c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
+            }
+            const uint32_t g = pos - seed_i;
+            ok[jj] = k0 + jj < nmid && (pos - c_lo >= seed_i) && (g + lr.len < c_hi);  // paired.cpp:166-171
+            gpv[jj] = ok[jj] ? g : 0u;
+            const uint32_t* gw = g2 + (gpv[jj] >> 4);
+#pragma unroll
+            for (int w = 0; w <= NW; w += 4) {
+              constexpr int kAll = NW + 1;
+              const int cw = kAll - w < 4 ? kAll - w : 4;
+              uint32_t qq[4] = {0, 0, 0, 0};
+              __builtin_memcpy(qq, gw + w, 4 * cw);
+#pragma unroll
+              for (int t = 0; t < cw; ++t) win[jj][w + t] = qq[t];
+            }
+          }
+#pragma unroll
+          for (uint32_t jj = 0; jj < 4; ++jj) {
+            const uint32_t mm = count_mismatch_regs<NW>(win[jj], 2 * (gpv[jj] & 15u), lr.rd, mk);
+            n_verified += ok[jj] ? 1u : 0u;
+            keep(probe, cnt, y0, y1, ok[jj], gpv[jj], mm);
+          }
+        }
+        if (on_p) { cnt_p = cnt; z0_p = y0; z1_p = y1; }
+        if (on_m) { cnt_m = cnt; z0_m = y0; z1_m = y1; }
+      }
+    }
+    // larger regions: work items
+    const bool big_p = size_p > kPeMidRegion, big_m = size_m > kPeMidRegion;
+    const DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, big_p && win_usable<NW>(svp, lr.len));
+    const DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, big_m && win_usable<NW>(svm, lr.len));
+    {
+      const bool dn_p = big_p && dr_p.hi > dr_p.lo, dn_m = big_m && dr_m.hi > dr_m.lo;
+      item_append<NW>(big_p, dn_p, j | (probe_p << 24), lp.reg.l, size_p, dn_p ? (uint32_t)dr_p.rec : kItemDenseNone, lr.len, seed_i,
+                      lr.rd, mk, ps.q);
+      item_append<NW>(big_m, dn_m, j | (probe_m << 24), lm.reg.l, size_m, dn_m ? (uint32_t)dr_m.rec : kItemDenseNone, lr.len, seed_i,
+                      lr.rd, mk, ps.q);
+      n_big += (big_p ? 1u : 0u) + (big_m ? 1u : 0u);
+    }
+    if (valid && !big_p) {  // an item's counts come from k_pe_verify
+      ps.surv_n[(uint64_t)probe_p * ccap + j] = cnt_p;
+      ps.cz[(uint64_t)probe_p * ccap + j] = z0_p | (z1_p << 16);
+    }
+    if (valid && !big_m) {
+      ps.surv_n[(uint64_t)probe_m * ccap + j] = cnt_m;
+      ps.cz[(uint64_t)probe_m * ccap + j] = z0_m | (z1_m << 16);
+    }
+  }
+  wave_append(dead, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, lit_count, lit_list);
+  if (valid && (stage_seed == 0 || dead)) ps.flag[j] = dead ? 1u : 0u;
+}
+
+template <int NW, bool LITERAL>
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1))) void k_pe_stage(
+    IndexView iv, const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
+    uint32_t strand_base, uint32_t max_mm, uint32_t b, const uint32_t* __restrict__ mask_table,
+    unsigned long long* __restrict__ stats, const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ list,
+    PeStage ps, uint32_t* __restrict__ lit_count, uint32_t* __restrict__ lit_list, uint32_t* __restrict__ fb_count,
+    uint32_t* __restrict__ fb_list, uint32_t first, uint32_t last_round, uint32_t stage_seed, uint32_t top_k) {
+  // this round's part of the list: [first, first + ccap); the last round also sends what lies beyond to fb_list
+  uint32_t count = *list_count;
+  count = count > first ? count - first : 0u;
+  if (!last_round && count > ps.ccap) count = ps.ccap;
+  if (count == 0) return;
+  list += first;
+  __shared__ BlockShared sh;
+  __shared__ PreFilter pf;
+  prefilter_stage(pf, iv, strand_base);
+  const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
+  uint32_t n_probe = 0, n_verified = 0, n_big = 0;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < count; base += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = base + threadIdx.x;
+    const bool in = i < count;
+    const uint32_t r = in ? (list[i] & kDeferMask) : 0u;
+    const bool staged = in && i < ps.ccap;
+    wave_append(in && !staged && stage_seed == 0, r, fb_count, fb_list);  // beyond the staged capacity of the pass: the list kernel's
+    pe_stage_dual<NW, LITERAL>(iv, sh, pf, si, codes2, offsets, err, r, staged, (uint32_t)i, strand_base, max_mm, b, ps, lit_count,
+                      lit_list, stage_seed, top_k, n_probe, n_verified, n_big);
+  }
+  pe_flush(0u, n_probe, n_verified, n_big, stats);
+}
+
+// id = j | probe << 24
+struct SurvivorSink {
+  PeStage ps;
+  uint32_t max_mm, top_k;
+  uint32_t* hist;  // 64 LDS words of this wavefront: survivors of the current item by mismatch count (63 = and more)
+  uint32_t id, cnt, bound;  // bound: candidates with at least this many mismatches can no longer enter the heap
+  uint32_t cur;             // number of the chunk that holds survivor cnt - 1 (wave-uniform)
+  uint32_t pos, seed;       // the item's place in the queue and its seed shift (static first chunk)
+  bool dense_kind;
+  bool over;
+  uint32_t gp_, mm_;
+  uint32_t n_verified;
+  static __device__ __forceinline__ uint32_t strand(uint32_t id) { return ((id >> 24) & 7u) >= 3u ? 1u : 0u; }
+  __device__ __forceinline__ void begin(uint32_t id_, uint32_t seed_, uint32_t pos_) {
+    id = id_;
+    seed = seed_;
+    pos = pos_;
+    cnt = 0;
+    bound = 0xFFFFFFFFu;
+    cur = 0;
+    over = false;
+    hist[threadIdx.x & 63] = 0;
+  }
+  __device__ __forceinline__ void add(uint32_t, uint32_t gp, uint32_t mm) { gp_ = gp; mm_ = mm; }
+  // the c-th chunk of this probe: a number from the pool, noted in the probe's chunk table (wave-uniform result)
+  __device__ __forceinline__ uint32_t take_chunk(uint32_t c) {
+    const uint32_t j = id & 0xFFFFFFu, probe = (id >> 24) & 7u;
+    uint32_t v = 0;
+    const bool fixed = c == 0 && dense_kind && pos < ps.static_n;
+    if ((threadIdx.x & 63) == 0) {
+      v = fixed ? seed * ps.static_n + pos : 3 * ps.static_n + atomicAdd(ps.pool_next, 1u);
+      if (c < kPeChunks && v < ps.pool_chunks) ps.chunk[((uint64_t)probe * kPeChunks + c) * ps.ccap + j] = v;
+    }
+    v = fixed ? seed * ps.static_n + pos : bcast(v, 0);
+    if (c >= kPeChunks || v >= ps.pool_chunks) { over = true; v = 0; }
+    return v;
+  }
+  __device__ __forceinline__ void step() {
+    const uint32_t lane = threadIdx.x & 63;
+    n_verified += mm_ != 0xFFFFFFFFu ? 1u : 0u;
+    const bool pass = mm_ <= max_mm && mm_ < bound;  // paired.cpp:192-195; bound: see the header comment
+    const unsigned long long m = __ballot(pass);
+    if (!m || over) return;
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t at = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t c0 = cnt / kPeChunkEnts, c1 = (cnt + n - 1) / kPeChunkEnts;  // at most one chunk boundary in 64 survivors
+    if (cnt % kPeChunkEnts == 0) cur = take_chunk(c0);
+    const uint32_t nxt = c1 != c0 ? take_chunk(c1) : cur;
+    if (pass && !over) ps.pool[(uint64_t)(at / kPeChunkEnts == c0 ? cur : nxt) * kPeChunkEnts + at % kPeChunkEnts] = make_uint2(gp_, mm_);
+    cur = nxt;
+    if (pass) atomicAdd(&hist[mm_ < 63u ? mm_ : 63u], 1u);
+    cnt += n;
+    if (cnt >= top_k) {
+      // smallest t with top_k survivors of at most t mismatches: the heap is then full of candidates that good
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      uint32_t total;
+      const uint32_t h = hist[lane];
+      const uint32_t before = wave_excl_scan_u32(h, lane, total);
+      const unsigned long long ge = __ballot(before + h >= top_k);
+      const uint32_t t = ge ? (uint32_t)__ffsll((long long)ge) - 1u : 63u;
+      bound = t < 63u ? t : 0xFFFFFFFFu;  // bucket 63 lumps larger counts together: no bound from it
+    }
+  }
+  __device__ __forceinline__ void end() {
+    const uint32_t j = id & 0xFFFFFFu, probe = (id >> 24) & 7u;
+    if ((threadIdx.x & 63) == 0) {
+      ps.surv_n[(uint64_t)probe * ps.ccap + j] = cnt | 0x80000000u;
+      const uint32_t h0 = hist[0], h1 = h0 + hist[1];
+      ps.cz[(uint64_t)probe * ps.ccap + j] = (h0 < 0xFFFFu ? h0 : 0xFFFFu) | ((h1 < 0xFFFFu ? h1 : 0xFFFFu) << 16);
+      if (over) atomicOr(&ps.flag[j], 2u);
+    }
+  }
+};
+
+template <int NW, bool DENSE>
+__global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_pe_verify(
+    IndexView iv, uint32_t strand_base, uint32_t max_mm, uint32_t top_k, unsigned long long* __restrict__ stats, PeStage ps) {
+  static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
+  const uint32_t n_items = ps.q.ctl[DENSE ? 0 : 1];
+  if (n_items == 0) return;
+  __shared__ uint32_t s_start[kLdsChroms + 1];
+  __shared__ uint32_t s_hist[kBlock / 64][64];
+  const bool fits = iv.n_chrom <= kLdsChroms;
+  if (fits)
+    for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  __syncthreads();
+  SurvivorSink sink;
+  sink.ps = ps; sink.max_mm = max_mm; sink.top_k = top_k; sink.hist = s_hist[threadIdx.x >> 6]; sink.n_verified = 0;
+  sink.gp_ = 0; sink.mm_ = 0xFFFFFFFFu; sink.dense_kind = DENSE;
+  if (fits) item_stream<NW, DENSE, true>(iv, strand_base, ps.q, n_items, s_start, sink);
+  else item_stream<NW, DENSE, false>(iv, strand_base, ps.q, n_items, s_start, sink);
+  pe_flush(0u, 0u, sink.n_verified, 0u, stats);
+}
+
 #endif  // WALT_SEEDPATTERN == 3
 
 constexpr uint32_t kListHeapSlots = 768;  // HeapEnt slots per wave (6 KB): 15 heaps of top_k = 50, 2 of top_k = 300
@@ -446,6 +840,92 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uin
   }
   pe_flush(shortv, n_probe, n_verified, n_big, stats);
 }
+
+#if WALT_SEEDPATTERN == 3
+// k_pe_push (staged path, see k_pe_stage): the staged reads of a round, one per lane, heaps in LDS like the list
+// kernel's.  Most staged reads keep a handful of survivors, so the kernel runs twice: SMALL = true visits every read
+// and maps those whose six probes kept at most kPushSmall survivors together -- their heap never holds more, so
+// kPushSmall slots do and all 64 lanes of a wavefront work -- and lists the others; SMALL = false maps the listed
+// ones with top_k slots each (kListHeapSlots / top_k reads per wavefront).
+constexpr uint32_t kPushSmall = 12;
+template <bool SMALL>
+__global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ list,
+                                                    PeStage ps, uint32_t top_k, Candidate* __restrict__ ranked,
+                                                    uint32_t* __restrict__ heap_n, uint32_t* __restrict__ fb_count,
+                                                    uint32_t* __restrict__ fb_list, uint32_t first,
+                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
+  __shared__ HeapEnt s_heap[kBlock / 64][kListHeapSlots];
+  uint32_t count;
+  if (SMALL) {
+    count = *list_count;
+    count = count > first ? count - first : 0u;
+    if (count > ps.ccap) count = ps.ccap;
+  } else {
+    count = *big_count;
+  }
+  if (count == 0) return;
+  list += first;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t total_waves = gridDim.x * waves_per_block;
+  const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+  const uint32_t cap = SMALL ? kPushSmall : top_k;
+  const uint32_t rpw_max = kListHeapSlots / cap < 64 ? kListHeapSlots / cap : 64;  // top_k <= 300: at least 2
+  uint32_t rpw = (count + total_waves - 1) / total_waves;
+  rpw = rpw < 1 ? 1 : (rpw > rpw_max ? rpw_max : rpw);
+  HeapEnt* heap = &s_heap[threadIdx.x >> 6][(lane < rpw ? lane : 0) * cap];
+  const uint64_t ccap = ps.ccap;
+  for (uint64_t base = (uint64_t)wave * rpw; base < count; base += (uint64_t)total_waves * rpw) {
+    const uint64_t i = base + lane;
+    const bool in = lane < rpw && i < count;
+    const uint64_t j = in ? (SMALL ? i : (uint64_t)big_list[i]) : 0;
+    const uint32_t r = in ? (list[j] & kDeferMask) : 0u;
+    bool go = in;
+    if (SMALL) {
+      const uint32_t fl = in ? ps.flag[j] : 1u;
+      wave_append(in && !(fl & 1u) && (fl & 2u), r, fb_count, fb_list);  // a probe outgrew its chunks: the list kernel maps the read
+      go = in && fl == 0;
+      uint32_t total = 0;
+#pragma unroll
+      for (uint32_t probe = 0; probe < 6; ++probe) total += go ? (ps.surv_n[(uint64_t)probe * ccap + j] & 0x7FFFFFFFu) : 0u;
+      const bool big = go && total > kPushSmall && top_k > kPushSmall;
+      wave_append(big, (uint32_t)j, big_count, big_list);
+      go = go && !big;
+    }
+    if (!go) continue;
+    uint32_t hsize = 0;
+    for (uint32_t fi = 0; fi < 2; ++fi) {
+      for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
+        // paired.cpp:133-149 (top only decreases: per-seed predicates equal the reference's `break`)
+        const bool full = hsize >= top_k;
+        const uint32_t top_mm = hsize ? heap_mm(heap[0]) : 0xFFFFFFFFu;
+        if ((full && top_mm == 0 && seed_i) || (full && top_mm == 1 && seed_i >= kExitOneMismatch)) continue;
+        const uint32_t probe = 3 * fi + seed_i;
+        const uint32_t sn = ps.surv_n[(uint64_t)probe * ccap + j];
+        const uint32_t n = sn & 0x7FFFFFFFu;
+        const bool chunked = (sn >> 31) != 0;
+        uint32_t ch = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+          if (chunked && k % kPeChunkEnts == 0) ch = ps.chunk[((uint64_t)probe * kPeChunks + k / kPeChunkEnts) * ccap + j];
+          const uint2 c = chunked ? ps.pool[(uint64_t)ch * kPeChunkEnts + k % kPeChunkEnts]
+                                  : ps.inl[((uint64_t)probe * kPeMidRegion + k) * ccap + j];
+          HeapEnt e; e.pos = c.x; e.mms = c.y | (fi << 31);
+          topk_push(heap, hsize, top_k, e);  // paired.cpp:195
+        }
+      }
+    }
+    // paired.cpp:685-692: pop everything; ranked[r][i] = i-th popped (descending mismatch)
+    heap_n[r] = hsize;
+    Candidate* out = ranked + (uint64_t)r * top_k;
+    uint32_t i2 = 0;
+    while (hsize) {
+      const HeapEnt e = heap_pop(heap, hsize);
+      Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
+      out[i2++] = c;
+    }
+  }
+}
+#endif  // WALT_SEEDPATTERN == 3
 
 // Pairs whose candidate lists span more than kLightCombos (i, j) combinations are
 // left to k_pe_merge_heavy: one such lane would otherwise hold its whole wave for
@@ -622,6 +1102,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
 // ---------------------------------------------------------------------------
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+constexpr uint32_t kPeInlineHost = 16, kPeChunksHost = 8;  // = kPeMidRegion, kPeChunks (defined with the pattern-3 kernels)
 struct PeWorkspace {
   uint32_t* err;
   unsigned long long* shards[2];
@@ -632,7 +1113,25 @@ struct PeWorkspace {
   uint64_t stride;
   uint64_t total_bytes;
   uint32_t cap_reads;  // reads per mate the pass's codes2 / ranked arrays have room for
+  // staged path (k_pe_stage): per mate, the fallback list and the survivors / counts / flags / items of ccap reads
+  uint32_t* fb_list[2];
+  uint32_t* big_list[2];
+  uint2* inl[2];
+  uint32_t* surv_n[2];
+  uint32_t* cz[2];
+  uint32_t* chunk_tab[2];
+  uint2* pool[2];
+  uint32_t* sflag[2];
+  uint4* items[2];
+  uint32_t ccap, pool_chunks;
 };
+// staged reads per pass and mate: a sixteenth of the pass (complex reads and filter hits are ~4 % of the reads
+// of an hg19-like genome), all of it when the pass is small
+static uint32_t pe_stage_cap(uint32_t chunk) {
+  if (chunk <= 65536) return chunk ? chunk : 1;
+  const uint32_t c = chunk / 16;
+  return (uint32_t)align_up(c > 65536 ? c : 65536, 64);
+}
 
 static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, uint32_t max_read_len) {
   PeWorkspace w;
@@ -652,6 +1151,20 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
   for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take(3 * w.stride * 4 + 64));  // literal list, its sorted copy, complex list
   for (int m = 0; m < 2; ++m) w.codes2[m] = reinterpret_cast<uint32_t*>(take(codes2_words((uint64_t)chunk * max_read_len) * 4 + 64));
   for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
+  w.ccap = pe_stage_cap(chunk);
+  w.pool_chunks = w.ccap * 2 > 4096 ? w.ccap * 2 : 4096;  // 128 survivors per staged read on average; three quarters static
+  const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
+  for (int m = 0; m < 2; ++m) {
+    w.fb_list[m] = reinterpret_cast<uint32_t*>(take(w.stride * 4 + 64));
+    w.big_list[m] = reinterpret_cast<uint32_t*>(take((uint64_t)w.ccap * 4 + 64));
+    w.inl[m] = reinterpret_cast<uint2*>(take((uint64_t)6 * kPeInlineHost * w.ccap * 8));
+    w.surv_n[m] = reinterpret_cast<uint32_t*>(take((uint64_t)6 * w.ccap * 4));
+    w.cz[m] = reinterpret_cast<uint32_t*>(take((uint64_t)6 * w.ccap * 4));
+    w.chunk_tab[m] = reinterpret_cast<uint32_t*>(take((uint64_t)6 * kPeChunksHost * w.ccap * 4));
+    w.pool[m] = reinterpret_cast<uint2*>(take((uint64_t)w.pool_chunks * 64 * 8));
+    w.sflag[m] = reinterpret_cast<uint32_t*>(take((uint64_t)w.ccap * 4));
+    w.items[m] = reinterpret_cast<uint4*>(take((uint64_t)6 * w.ccap * quads * 16));
+  }
   w.total_bytes = off;
   return w;
 }
@@ -661,7 +1174,7 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
                           uint64_t stride, uint32_t n, uint32_t sb,
                           uint32_t max_mm, uint32_t b, uint32_t top_k, uint32_t* heap_n,
                           Candidate* ranked, unsigned long long* stats, uint32_t* ctl, uint32_t* defer_list,
-                          hipStream_t stream) {
+                          const PeWorkspace& w, int mate, hipStream_t stream) {
   // ctl: [0] literal-list count, [8..23] its bins (launch_bin_deferred), [24] complex-list count
   uint32_t* lit_count = ctl;
   uint32_t* cplx_count = ctl + 24;
@@ -669,7 +1182,7 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
   uint32_t* lit_sorted = defer_list + stride;
   uint32_t* cplx_list = defer_list + 2 * stride;
 #if WALT_SEEDPATTERN != 3
-  (void)lit_sorted; (void)cplx_list; (void)cplx_count;
+  (void)lit_sorted; (void)cplx_list; (void)cplx_count; (void)w; (void)mate;
   // patterns 5 / 7: the strand-major list kernel over every read with the directory/key search, Bloom hits
   // deferred to the literal list
   hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(1536), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
@@ -679,10 +1192,91 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
   return WALT_OK;
 #else
   const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
+  const unsigned g2 = 1536;  // x 4 waves: the list kernels size their per-wave share from the list length
+  // WALT_AMD_PE=list: complex reads and filter hits mapped by the list kernels only (the path before the staged one)
+  const char* pe_mode = getenv("WALT_AMD_PE");
+  const bool list_only = pe_mode && !strcmp(pe_mode, "list");
+  uint32_t* over_count = ctl + 25;  // zeroed with the control block at the start of the pass
+  if (!list_only) {
+    static_assert(kPeMidRegion == kPeInlineHost && kPeChunks == kPeChunksHost && kPeChunkEnts == 64, "carve_pe sizes the survivor storage");
+    // ctl: [26] fallback-list count, [27] pool chunks handed out, [28..31] the item queue's counters
+    PeStage ps;
+    ps.inl = w.inl[mate]; ps.surv_n = w.surv_n[mate]; ps.cz = w.cz[mate]; ps.chunk = w.chunk_tab[mate]; ps.pool = w.pool[mate];
+    ps.pool_next = ctl + 27; ps.pool_chunks = w.pool_chunks; ps.static_n = w.pool_chunks / 4; ps.flag = w.sflag[mate];
+    ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 6 * w.ccap;
+    ps.ccap = w.ccap;
+    uint32_t* fb_count = ctl + 26;
+    uint32_t* fb_list = w.fb_list[mate];
+    static const unsigned vg_dense = [] {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pe_verify<NW, NW <= 10>, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+      return (unsigned)nb * 256u;
+    }();
+    static const unsigned vg_gather = [] {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pe_verify<NW, false>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
+      return (unsigned)nb * 256u;
+    }();
+    const unsigned gs = grid_for(w.ccap) < kPersistentGrid ? grid_for(w.ccap) : kPersistentGrid;
+    auto verify = [&]() {
+      if constexpr (NW <= 10)
+        hipLaunchKernelGGL((k_pe_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps);
+      hipLaunchKernelGGL((k_pe_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps);
+    };
+    // the staged state holds ccap reads: a list is taken in rounds of ccap (the list's length is on the device: a
+    // fixed number of rounds, the empty ones cost a few launches), the last round hands the rest to the list kernel
+    constexpr uint32_t kRounds = 4;  // a quarter of the pass
+    uint32_t* big_count = ctl + 1;  // reads of the round with more than kPushSmall survivors
+    uint32_t* big_list = w.big_list[mate];
+    auto clear_round = [&]() {  // pool + queue, the push kernels' list
+      return hipMemsetAsync(ctl + 27, 0, 5 * sizeof(uint32_t), stream) == hipSuccess &&
+             hipMemsetAsync(big_count, 0, sizeof(uint32_t), stream) == hipSuccess;
+    };
+    auto push = [&](const uint32_t* count, const uint32_t* list, uint32_t* over_n, uint32_t* over_l, uint32_t first) {
+      hipLaunchKernelGGL(k_pe_push<true>, dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
+                         first, big_count, big_list);
+      hipLaunchKernelGGL(k_pe_push<false>, dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
+                         first, big_count, big_list);
+    };
+    auto clear_queue = [&]() { return hipMemsetAsync(ctl + 28, 0, 4 * sizeof(uint32_t), stream) == hipSuccess; };
+    // pass 1 with ONE list: filter hits (tagged) and complex reads both go to the staged kernels
+    hipLaunchKernelGGL(k_pe_topk_dual<NW>, dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n, sb,
+                       max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, cplx_count, cplx_list, cplx_count,
+                       cplx_list);
+    for (uint32_t rd = 0; rd < kRounds; ++rd) {
+      if (rd && !clear_round()) return fail(WALT_EHIP, "hipMemsetAsync failed");
+      for (uint32_t seed = 0; seed < 3; ++seed) {  // seed by seed: what a seed found decides which probes the next one makes
+        if (seed && !clear_queue()) return fail(WALT_EHIP, "hipMemsetAsync failed");
+        hipLaunchKernelGGL((k_pe_stage<NW, false>), dim3(gs), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb, max_mm, b,
+                           idx->d_mask_table, stats, cplx_count, cplx_list, ps, lit_count, lit_list, fb_count, fb_list,
+                           rd * w.ccap, rd + 1 == kRounds ? 1u : 0u, seed, top_k);
+        verify();
+      }
+      push(cplx_count, cplx_list, fb_count, fb_list, rd * w.ccap);
+    }
+    // what the staged round could not hold: the list kernel, as before (it may add to the literal list)
+    hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
+                       max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, fb_count, fb_list, lit_count,
+                       lit_list, 0u);
+    // second round: the reads with a truly dangerous probe, sorted by the iteration of that probe; the complex
+    // list's area is free again and takes what this round cannot hold
+    launch_bin_deferred(lit_count, lit_list, lit_sorted, stream);
+    if (!clear_round()) return fail(WALT_EHIP, "hipMemsetAsync failed");
+    for (uint32_t seed = 0; seed < 3; ++seed) {
+      if (seed && !clear_queue()) return fail(WALT_EHIP, "hipMemsetAsync failed");
+      hipLaunchKernelGGL((k_pe_stage<NW, true>), dim3(gs), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb, max_mm, b,
+                         idx->d_mask_table, stats, lit_count, lit_sorted, ps, nullptr, nullptr, over_count, cplx_list, 0u, 1u, seed,
+                         top_k);
+      verify();
+    }
+    push(lit_count, lit_sorted, over_count, cplx_list, 0u);
+    hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
+                       max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, over_count, cplx_list, nullptr, nullptr, 0u);
+    return WALT_OK;
+  }
   hipLaunchKernelGGL(k_pe_topk_dual<NW>, dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, cplx_count,
                      cplx_list);
-  const unsigned g2 = 1536;  // x 4 waves: the list kernels size their per-wave share from the list length
   hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, cplx_count, cplx_list, lit_count,
                      lit_list, 0u);
@@ -691,7 +1285,6 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
   // contigs a tenth of the reads is here); the few reads with more candidates overflow into the complex list's
   // area, which is free again, and are mapped with full heaps
   const uint32_t kSmallHeap = 8u | (getenv("WALT_AMD_SMALL_HEAPS") ? 0x80000000u : 0u);  // env: force (tests)
-  uint32_t* over_count = ctl + 25;  // zeroed with the control block at the start of the pass
   hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr, 0u,
                      kSmallHeap, over_count, cplx_list);
@@ -742,15 +1335,15 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
     launch_ascii_to_2bit(bases[m], offs[m], n, w.codes2[m], view.batch_cap_bytes, pack_err, stream);
     int rc;
     switch (nw) {
-      case 7: rc = launch_pe_topk<7>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 8: rc = launch_pe_topk<8>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 7: rc = launch_pe_topk<7>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], w, m, stream); break;
+      case 8: rc = launch_pe_topk<8>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], w, m, stream); break;
 #if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
-      case 10: rc = launch_pe_topk<10>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 16: rc = launch_pe_topk<16>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      case 32: rc = launch_pe_topk<32>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
-      default: rc = launch_pe_topk<64>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      case 10: rc = launch_pe_topk<10>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], w, m, stream); break;
+      case 16: rc = launch_pe_topk<16>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], w, m, stream); break;
+      case 32: rc = launch_pe_topk<32>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], w, m, stream); break;
+      default: rc = launch_pe_topk<64>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], w, m, stream); break;
 #else
-      default: rc = launch_pe_topk<10>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], stream); break;
+      default: rc = launch_pe_topk<10>(idx, view, w.codes2[m], offs[m], pack_err, w.stride, n, sb, max_mm, b, top_k, w.heap_n[m], w.ranked[m], st, ctl, w.defer_list[m], w, m, stream); break;
 #endif
     }
     if (rc) return rc;

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "map_common.h"
+#include "map_items.h"
 
 namespace walt {
 
@@ -327,44 +328,6 @@ struct HeavyStage {
   uint32_t first;    // heavy-list index of the chunk's first read
   uint32_t stage;    // 0..2: seed shift of the stage, 3: final fold
 };
-constexpr uint32_t kItemDenseNone = 0xFFFFFFFFu;
-// A work item carries everything k_se_verify needs, so that the verifier's only dependent loads are the
-// candidates' own (no read offsets, no packed read, no mask table):
-//   word 0..3  j | strand << 31, first slot l, size, first dense record (records stay below 2^32, build_windows)
-//   word 4..7  read length, 0, 0, 0
-//   then the converted read rd[NW] and its compare masks mk[NW] for this seed shift, padded to 16 bytes
-template <int NW>
-constexpr uint32_t item_quads() { return 2u + (2u * NW + 3u) / 4u; }
-template <int NW>
-__device__ __forceinline__ void wave_append_item(bool take, bool dense, uint32_t jfi, uint32_t l, uint32_t size,
-                                                 uint32_t rec, uint32_t len, const uint32_t* rd, const uint32_t* mk,
-                                                 const HeavyStage& hs) {
-  constexpr uint32_t Q = item_quads<NW>();
-  const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-  for (int side = 0; side < 2; ++side) {
-    const bool mine = take && (dense == (side == 0));
-    const unsigned long long m = __ballot(mine);
-    if (!m) continue;
-    const int leader = (int)__ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(&hs.ctl[side], (uint32_t)__popcll(m));
-    base = bcast(base, leader);
-    if (mine) {
-      const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      const uint64_t at = side == 0 ? k : (uint64_t)2 * hs.hcap - 1 - k;
-      uint4* it = hs.items + Q * at;
-      it[0] = make_uint4(jfi, l, size, rec);
-      it[1] = make_uint4(len, 0u, 0u, 0u);
-      uint32_t w[4 * (Q - 2)];
-#pragma unroll
-      for (uint32_t t = 0; t < 4 * (Q - 2); ++t) w[t] = t < (uint32_t)NW ? rd[t] : (t < 2u * NW ? mk[t - NW] : 0u);
-#pragma unroll
-      for (uint32_t q = 0; q + 2 < Q; ++q) it[2 + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-    }
-  }
-}
-
 template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
                                                 const uint32_t* __restrict__ codes2, uint64_t o_first,
@@ -617,7 +580,11 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         const bool bigr = my_size > kMidRegion;
         const DenseRange& dr = fi ? dr_m : dr_p;
         const bool dense = bigr && dr.hi > dr.lo;
-        wave_append_item<NW>(bigr, dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone, lr.len, lr.rd, mk, hs);
+        {
+          ItemQueue q;
+          q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
+          item_append<NW>(bigr, dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone, lr.len, seed_i, lr.rd, mk, q);
+        }
         if (bigr) { ++ctr.big; if (fi) pend_m = true; else pend_p = true; }
       }
       unsigned long long big = STAGED ? 0ull : __ballot(my_size > kMidRegion);
@@ -855,22 +822,11 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
 }
 
 // ---------------------------------------------------------------------------
-// k_se_verify: the work items of one heavy stage (HeavyStage), one region per wavefront.  An item brings the
-// read, its masks and the region (wave_append_item), all wave-uniform, so a lane carries little besides the
-// records it has in flight and the kernel runs at high occupancy; wavefronts take items in batches of
-// kVerifyBatch from a device counter (regions run from 17 to `-b` candidates: a static deal leaves a long tail).
-//   DENSE = true:  every candidate has a dense record (core.h dense_range): 32 (48) sequential bytes each, 64
-//                  candidates per step, and the NEXT step's records -- of this item or of the next one -- are
-//                  requested before the current step is evaluated (every path issues the same loads, so the wait
-//                  for the current step leaves them in flight);
-//   DENSE = false: index entry, then the genome window (coop_verify_groups' gather route).
+// k_se_verify: the work items of one heavy stage (HeavyStage), one region per wavefront (map_items.h item_stream).
 // The RegionSummary of a region is order-free once the slot order is kept in the lanes: minimum, number of
 // candidates holding it, the first and the last of them in slot order (core.h summary_merge) -- accumulated per
 // lane over its slots (ascending) and reduced once per item.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kVerifyBatch = 8;
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
-
 struct LaneBest {  // this lane's slots of one region, ascending
   uint32_t mm, cnt, f_k, f_gp, l_k, l_gp;
 };
@@ -893,194 +849,47 @@ __device__ __forceinline__ uint4 lane_best_reduce(const LaneBest& a) {
   const unsigned long long fm = __ballot(eq && a.f_k == fk), lm = __ballot(eq && a.l_k == lk);
   return make_uint4(mn, cnt, bcast(a.f_gp, (int)__ffsll((long long)fm) - 1), bcast(a.l_gp, (int)__ffsll((long long)lm) - 1));
 }
-
-// A pointer the kernel got inside a by-value struct is a generic pointer to the compiler, and a load through it a
-// FLAT load: it counts as vector-memory AND as LDS traffic, so that waiting for one -- or for any LDS read
-// while one is pending -- waits for every record in flight.  These loads are global by construction.
-template <class T>
-__device__ __forceinline__ T load_global(const T* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef uint32_t __attribute__((address_space(1))) gword;
-  const gword* q = reinterpret_cast<const gword*>(reinterpret_cast<uintptr_t>(p));
-  T v;
-  uint32_t* w = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = q[i];
-  return v;
-#else
-  return *p;
-#endif
-}
-
-// the item loop of k_se_verify; FITS: the chromosome starts are in LDS (s_start), else in HBM
-template <int NW, bool DENSE, bool FITS>
-__device__ __forceinline__ void verify_items(const IndexView& iv, uint32_t strand_base, const HeavyStage& hs, uint32_t n_items,
-                                             const uint32_t* s_start, uint32_t& n_verified) {
-  constexpr uint32_t Q = item_quads<NW>();
-  const uint32_t n_chrom = iv.n_chrom, top_step = top_step_of(n_chrom);
-  uint32_t* const cursor = &hs.ctl[DENSE ? 2 : 3];
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t seed_i = hs.stage;
-  const uint4 zero = make_uint4(0, 0, 0, 0);
-  auto header = [&](uint32_t i, bool on) {  // lane q < Q: quad q of item i
-    const uint64_t at = DENSE ? (uint64_t)i : (uint64_t)2 * hs.hcap - 1 - i;
-    // branch-free (a value loaded under a branch is waited for where the branch ends): idle lanes read quad 0
-    return load_global(hs.items + ((on && lane < Q) ? Q * at + lane : 0ull));
-  };
-  auto grab = [&]() {  // lane 0 holds the batch start once the atomic has returned
-    uint32_t v = 0;
-    if (lane == 0) v = atomicAdd(cursor, kVerifyBatch);
-    return v;
-  };
-  auto chrom_bounds = [&](uint32_t pos, uint32_t& c_lo, uint32_t& c_hi) {
-    if constexpr (FITS) {
-      const uint32_t chr = chrom_id_steps(s_start, n_chrom, top_step, pos);
-      c_lo = s_start[chr]; c_hi = s_start[chr + 1];
-    } else {
-      const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
-      c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
-    }
-  };
-  uint32_t nb_v = grab();
-  uint32_t b0 = bcast(nb_v, 0), t = 0;
-  nb_v = grab();
-  bool have = b0 < n_items;
-  uint4 hd = header(b0, have);
-  // the current item, wave-uniform
-  uint32_t jfi = 0, l = 0, size = 1, rec0 = 0, len = 0, rd[NW], mk[NW];
-  auto decode = [&](const uint4& h) {
-    jfi = bcast(h.x, 0); l = bcast(h.y, 0); size = bcast(h.z, 0); rec0 = bcast(h.w, 0);
-    len = bcast(h.x, 1);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const int a = 8 + w, c = 8 + NW + w;
-      const uint32_t va = (a & 3) == 0 ? h.x : (a & 3) == 1 ? h.y : (a & 3) == 2 ? h.z : h.w;
-      const uint32_t vc = (c & 3) == 0 ? h.x : (c & 3) == 1 ? h.y : (c & 3) == 2 ? h.z : h.w;
-      rd[w] = bcast(va, a >> 2);
-      mk[w] = bcast(vc, c >> 2);
-    }
-  };
-  // the item after it: index (the batch's next, or the first of the batch grabbed meanwhile) and header load
-  uint4 hdn = zero;
-  bool hn = false;
-  auto fetch_next = [&]() {
-    uint32_t ni;
-    if (t + 1 < kVerifyBatch) {
-      ++t;
-      ni = b0 + t;
-    } else {
-      b0 = bcast(nb_v, 0);
-      nb_v = grab();
-      t = 0;
-      ni = b0;
-    }
-    hn = ni < n_items;
-    hdn = header(ni, hn);
-  };
-  if (!have) return;
-  decode(hd);
-  fetch_next();
-  LaneBest acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-  if constexpr (DENSE) {
-    // Two record buffers used in turn (a register COPY of a loaded value waits for the load, so the buffers swap
-    // roles instead): while step s is evaluated from one, step s + 1 -- of this item, or the first of the next --
-    // is on its way into the other.  Every step issues the same loads whatever it is (uniform selects on the
-    // addresses, no branch around a load), so the wait before the evaluation leaves exactly them in flight.
-    uint4 ra0 = zero, rc0 = zero, re0 = zero, ra1 = zero, rc1 = zero, re1 = zero;
-    auto issue = [&](uint32_t fi, uint32_t r0, uint32_t sz, uint32_t base, uint4& a, uint4& c, uint4& e) {
-      const StrandView& sv = iv.s[strand_base + fi];
-      const uint32_t k = base + lane;
-      const uint64_t rec = (uint64_t)r0 + (k < sz ? k : sz - 1);
-      const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * rec;
-      a = load_global(rp);
-      c = load_global(rp + 1);
-      if constexpr (NW > 7) e = load_global(reinterpret_cast<const uint4*>(sv.win2) + rec);
-    };
-    uint32_t base = 0;
-    bool done = false;
-    auto step = [&](uint4& xa, uint4& xc, uint4& xe, uint4& ya, uint4& yc, uint4& ye) {
-      const bool last = base + 64 >= size;
-      // what the other buffer gets: this item's next step, the next item's first, or (nothing left) a repeat
-      uint32_t n_fi = jfi >> 31, n_rec0 = rec0, n_size = size, n_base = last ? 0u : base + 64;
-      if (last && hn) { n_fi = bcast(hdn.x, 0) >> 31; n_size = bcast(hdn.z, 0); n_rec0 = bcast(hdn.w, 0); }
-      issue(n_fi, n_rec0, n_size, n_base, ya, yc, ye);
-      {
-        const uint32_t k = base + lane;
-        const uint32_t pos = xa.x;
-        uint32_t c_lo, c_hi;
-        chrom_bounds(pos, c_lo, c_hi);
-        const uint32_t g = pos - seed_i;
-        const bool ok = k < size && (pos - c_lo >= seed_i) && (g + len < c_hi);  // mapping.cpp:280-286
-        uint32_t wv[NW + 1];
-        const uint32_t first[11] = {xa.y, xa.z, xa.w, xc.x, xc.y, xc.z, xc.w,
-                                    NW > 7 ? xe.x : 0u, NW > 7 ? xe.y : 0u, NW > 7 ? xe.z : 0u, NW > 7 ? xe.w : 0u};
-#pragma unroll
-        for (int w = 0; w <= NW; ++w) wv[w] = w < 11 ? first[w] : 0u;
-        const uint32_t m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
-        n_verified += ok ? 1u : 0u;
-        lane_best_add(acc, k, ok ? g : 0u, ok ? m : 0xFFFFFFFFu);
-      }
-      if (last) {
-        const uint4 res = lane_best_reduce(acc);
-        if (lane == 0) hs.sums[(uint64_t)(2 * seed_i + (jfi >> 31)) * hs.hcap + (jfi & 0x7FFFFFFFu)] = res;
-        acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-        if (hn) {
-          decode(hdn);
-          fetch_next();
-          base = 0;
-        } else {
-          done = true;
-        }
-      } else {
-        base += 64;
-      }
-    };
-    issue(jfi >> 31, rec0, size, 0u, ra0, rc0, re0);
-    for (;;) {
-      step(ra0, rc0, re0, ra1, rc1, re1);
-      if (done) break;
-      step(ra1, rc1, re1, ra0, rc0, re0);
-      if (done) break;
-    }
-  } else {
-    const uint32_t* si = FITS ? s_start : iv.start_index;
-    for (;;) {
-      const uint32_t fi = jfi >> 31;
-      const StrandView& sv = iv.s[strand_base + fi];
-      DenseRange none;
-      none.lo = none.hi = l;
-      none.rec = 0;
-      for (uint32_t base = 0; base < size; base += 64) {
-        uint32_t gp[1], mm[1];
-        coop_verify_groups<NW, 1>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, none, gp, mm);
-        n_verified += mm[0] != 0xFFFFFFFFu ? 1u : 0u;
-        lane_best_add(acc, base + lane, gp[0], mm[0]);
-      }
-      const uint4 res = lane_best_reduce(acc);
-      if (lane == 0) hs.sums[(uint64_t)(2 * seed_i + fi) * hs.hcap + (jfi & 0x7FFFFFFFu)] = res;
-      acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
-      if (!hn) break;
-      decode(hdn);
-      fetch_next();
-    }
+// item id = chunk position j | strand << 31; the summary goes to sums[(2 * seed + strand) * hcap + j]
+struct SummarySink {
+  uint4* sums;
+  uint32_t hcap;
+  uint32_t id, seed_i;
+  LaneBest acc;
+  uint32_t n_verified;
+  static __device__ __forceinline__ uint32_t strand(uint32_t id) { return id >> 31; }
+  __device__ __forceinline__ void begin(uint32_t id_, uint32_t seed_, uint32_t) {
+    id = id_; seed_i = seed_;
+    acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
   }
-}
+  __device__ __forceinline__ void add(uint32_t k, uint32_t gp, uint32_t mm) {
+    n_verified += mm != 0xFFFFFFFFu ? 1u : 0u;
+    lane_best_add(acc, k, gp, mm);
+  }
+  __device__ __forceinline__ void step() {}
+  __device__ __forceinline__ void end() {
+    const uint4 res = lane_best_reduce(acc);
+    if ((threadIdx.x & 63) == 0) sums[(uint64_t)(2 * seed_i + (id >> 31)) * hcap + (id & 0x7FFFFFFFu)] = res;
+  }
+};
 
 template <int NW, bool DENSE>
 __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
     IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs) {
   static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
-  const uint32_t n_items = hs.ctl[DENSE ? 0 : 1];
+  ItemQueue q;
+  q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
+  const uint32_t n_items = q.ctl[DENSE ? 0 : 1];
   if (n_items == 0) return;
   __shared__ uint32_t s_start[kLdsChroms + 1];
   const bool fits = iv.n_chrom <= kLdsChroms;
   if (fits)
     for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
   __syncthreads();
-  uint32_t n_verified = 0;
-  if (fits) verify_items<NW, DENSE, true>(iv, strand_base, hs, n_items, s_start, n_verified);
-  else verify_items<NW, DENSE, false>(iv, strand_base, hs, n_items, s_start, n_verified);
-  flush_counters({0u, n_verified, 0u}, 0u, stats);
+  SummarySink sink;
+  sink.sums = hs.sums; sink.hcap = hs.hcap; sink.n_verified = 0;
+  if (fits) item_stream<NW, DENSE, true>(iv, strand_base, q, n_items, s_start, sink);
+  else item_stream<NW, DENSE, false>(iv, strand_base, q, n_items, s_start, sink);
+  flush_counters({0u, sink.n_verified, 0u}, 0u, stats);
 }
 
 #endif  // WALT_SEEDPATTERN == 3
