@@ -126,6 +126,41 @@ def test_gpu_heavy_pass_and_dense_windows_vs_oracle(wa, repeat_case, win, monkey
     idx.close()
 
 
+@pytest.mark.parametrize("mode", ["mono_list", "small_state"])
+def test_gpu_staged_paths_and_their_fallbacks_vs_oracle(wa, repeat_case, mode, monkeypatch):
+    """The staged heavy pass (map_se.hip k_se_verify) and the staged paired-end path (map_pe.hip k_pe_stage /
+    k_pe_verify / k_pe_push) are the default and run in every other test; here
+    mono_list:   the one-kernel heavy pass and the list-kernel paired-end path they replaced (kept for comparison),
+    small_state: the staged paths with tiny state -- the heavy list in eight chunks, the staged paired-end reads in
+                 four rounds of 128 with the rest handed to the list kernel -- so that chunking, rounds, stage lists
+                 and the fallback are all exercised on a batch of a few thousand reads.
+    Same records as the oracle in every mode."""
+    seqs, db = repeat_case
+    if mode == "mono_list":
+        monkeypatch.setenv("WALT_AMD_HEAVY", "mono")
+        monkeypatch.setenv("WALT_AMD_PE", "list")
+    else:
+        monkeypatch.setenv("WALT_AMD_HEAVY_CHUNK", "320")
+        monkeypatch.setenv("WALT_AMD_PE_STAGE_CAP", "128")
+    idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_bits=-1)
+    rng = random.Random(11)
+    for conv, lens, m, b in (("CT", [100], 6, 5000), ("GA", [150], 10, 300), ("CT", [60, 100, 128, 150, 200], 6, 5000)):
+        reads = _reads(rng, seqs, 2500, conv, lens)
+        want, _ = refio.oracle_se(db, reads, ag=conv == "GA", max_mm=m, b=b)
+        got, st = idx.map_se_batch(*wa.pack_reads(reads), ag_wildcard=conv == "GA", max_mismatches=m, b=b)
+        assert_best_equal(got, want, "%s %s m=%d b=%d mode=%s" % (conv, lens, m, b, mode))
+    r1 = _reads(rng, seqs, 1500, "CT", [100])
+    r2 = _reads(rng, seqs, 1500, "GA", [100])
+    for k in (5, 50, 300):
+        want, _, _ = refio.oracle_pe(db, r1, r2, max_mm=6, b=5000, top_k=k, frag_range=1000)
+        res, _ = idx.map_pe_batch(*wa.pack_reads(r1), *wa.pack_reads(r2), max_mismatches=6, top_k=k)
+        for f in ("best_times", "frag_len", "best_i", "best_j", "pair_mm"):
+            assert np.array_equal(res[f], want[f]), (mode, k, f)
+        assert_best_equal(res["m1"], want["m1"], "pair m1 k=%d %s" % (k, mode))
+        assert_best_equal(res["m2"], want["m2"], "pair m2 k=%d %s" % (k, mode))
+    idx.close()
+
+
 def test_gpu_device_api_refuses_reads_beyond_max_read_len(wa, g1_index_path, g1_db):
     """with max_read_len = 100 the 7-word kernels would take a 112-base read silently and the 2-bit
     conversion would run past the workspace.  Now such reads are refused in the kernels (record left as

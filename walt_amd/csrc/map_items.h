@@ -23,6 +23,10 @@ constexpr uint32_t kItemDenseNone = 0xFFFFFFFFu;
 // serves about a hundred million of those per second -- a million items taken eight at a time spent half the
 // verifier's time queueing for the cursor.  So: a quarter of a wavefront's fair share, at most kVerifyBatchMax.
 constexpr uint32_t kVerifyBatchMax = 32;
+// Dense regions above this size would go to a second queue verified four groups per step (item_stream's G): measured
+// SLOWER on the hg19-like genome (17.7 against 16.3 ms: the wider steps cost occupancy, and most candidates sit in
+// such regions), so the queue is off; the code path stays for genomes whose regions are few and huge.
+constexpr uint32_t kGiantRegion = 0xFFFFFFFFu;
 
 struct ItemQueue {
   uint4* items;   // cap items of item_quads<NW>() quads
@@ -34,12 +38,15 @@ template <int NW>
 constexpr uint32_t item_quads() { return 2u + (2u * NW + 3u) / 4u; }
 
 // All 64 lanes call this; lanes with `take` append one item each (one atomic per wavefront and kind).
+// Returns false for a lane whose item found no room (a queue smaller than the number of items that can come:
+// the giant queue; the caller puts the item elsewhere; the verifier clamps the count it reads to q.cap).
 template <int NW>
-__device__ __forceinline__ void item_append(bool take, bool dense, uint32_t id, uint32_t l, uint32_t size, uint32_t rec,
+__device__ __forceinline__ bool item_append(bool take, bool dense, uint32_t id, uint32_t l, uint32_t size, uint32_t rec,
                                             uint32_t len, uint32_t seed_i, const uint32_t* rd, const uint32_t* mk,
                                             const ItemQueue& q) {
   constexpr uint32_t Q = item_quads<NW>();
   const uint32_t lane = threadIdx.x & 63;
+  bool placed = true;
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
     const bool mine = take && (dense == (side == 0));
@@ -49,8 +56,9 @@ __device__ __forceinline__ void item_append(bool take, bool dense, uint32_t id, 
     uint32_t base = 0;
     if ((int)lane == leader) base = atomicAdd(&q.ctl[side], (uint32_t)__popcll(m));
     base = bcast(base, leader);
-    if (mine) {
-      const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (mine && k >= q.cap) placed = false;
+    if (mine && k < q.cap) {
       const uint64_t at = side == 0 ? k : (uint64_t)q.cap - 1 - k;
       uint4* it = q.items + Q * at;
       it[0] = make_uint4(id, l, size, rec);
@@ -62,6 +70,7 @@ __device__ __forceinline__ void item_append(bool take, bool dense, uint32_t id, 
       for (uint32_t qd = 0; qd + 2 < Q; ++qd) it[2 + qd] = make_uint4(w[4 * qd], w[4 * qd + 1], w[4 * qd + 2], w[4 * qd + 3]);
     }
   }
+  return placed;
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
@@ -99,7 +108,7 @@ __device__ __forceinline__ T load_global(const T* p) {
 // Sink (all calls wave-uniform):  strand(id) -> 0 / 1;  begin(id, seed_i, position in the queue);  add(k, gp, mm) per lane and step
 // (k = slot offset in the region, mm = 0xFFFFFFFF when the slot is beyond the region or fails the edge filters of
 // mapping.cpp:280-286 / paired.cpp:166-171);  step() after every 64 candidates;  end().
-template <int NW, bool DENSE, bool FITS, class Sink>
+template <int NW, bool DENSE, bool FITS, class Sink, int G = 1>
 __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand_base, const ItemQueue& q, uint32_t n_items,
                                             const uint32_t* s_start, Sink& sink) {
   constexpr uint32_t Q = item_quads<NW>();
@@ -182,35 +191,45 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
   fetch_next();
   sink.begin(id, seed_i, cur_i);
   if constexpr (DENSE && NW <= 10) {
-    uint4 ra0 = zero, rc0 = zero, re0 = zero, ra1 = zero, rc1 = zero, re1 = zero;
-    auto issue = [&](uint32_t fi, uint32_t r0, uint32_t sz, uint32_t base, uint4& a, uint4& c, uint4& e) {
+    // G groups of 64 candidates per step (G = 4 for the queue of very large regions: a region of 5,000 candidates
+    // taken 64 at a time is 79 dependent steps, and one such item set the duration of every launch)
+    struct Buf { uint4 a[G], c[G], e[G]; };
+    Buf b0_, b1_;
+#pragma unroll
+    for (int u = 0; u < G; ++u) { b0_.a[u] = b0_.c[u] = b0_.e[u] = zero; b1_.a[u] = b1_.c[u] = b1_.e[u] = zero; }
+    auto issue = [&](uint32_t fi, uint32_t r0, uint32_t sz, uint32_t base, Buf& y) {
       const StrandView& sv = iv.s[strand_base + fi];
-      const uint32_t k = base + lane;
-      const uint64_t rec = (uint64_t)r0 + (k < sz ? k : sz - 1);
-      const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * rec;
-      a = load_global(rp);
-      c = load_global(rp + 1);
-      if constexpr (NW > 7) e = load_global(reinterpret_cast<const uint4*>(sv.win2) + rec);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t k = base + 64 * u + lane;
+        const uint64_t rec = (uint64_t)r0 + (k < sz ? k : sz - 1);
+        const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * rec;
+        y.a[u] = load_global(rp);
+        y.c[u] = load_global(rp + 1);
+        if constexpr (NW > 7) y.e[u] = load_global(reinterpret_cast<const uint4*>(sv.win2) + rec);
+      }
     };
     uint32_t base = 0;
     bool done = false;
-    auto step = [&](uint4& xa, uint4& xc, uint4& xe, uint4& ya, uint4& yc, uint4& ye) {
-      const bool last = base + 64 >= size;
+    auto step = [&](Buf& x, Buf& y) {
+      const bool last = base + 64 * G >= size;
       // what the other buffer gets: this item's next step, the next item's first, or (nothing left) a repeat
       uint32_t n_fi = Sink::strand(id), n_rec0 = rec0, n_size = size;
-      const uint32_t n_base = last ? 0u : base + 64;
+      const uint32_t n_base = last ? 0u : base + 64 * G;
       if (last && hn) { n_fi = Sink::strand(bcast(hdn.x, 0)); n_size = bcast(hdn.z, 0); n_rec0 = bcast(hdn.w, 0); }
-      issue(n_fi, n_rec0, n_size, n_base, ya, yc, ye);
-      {
-        const uint32_t k = base + lane;
-        const uint32_t pos = xa.x;
+      issue(n_fi, n_rec0, n_size, n_base, y);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (G > 1 && base + 64 * u >= size) break;  // uniform
+        const uint32_t k = base + 64 * u + lane;
+        const uint32_t pos = x.a[u].x;
         uint32_t c_lo, c_hi;
         chrom_bounds(pos, c_lo, c_hi);
         const uint32_t g = pos - seed_i;
         const bool ok = k < size && (pos - c_lo >= seed_i) && (g + len < c_hi);
         uint32_t wv[NW + 1];
-        const uint32_t first[11] = {xa.y, xa.z, xa.w, xc.x, xc.y, xc.z, xc.w,
-                                    NW > 7 ? xe.x : 0u, NW > 7 ? xe.y : 0u, NW > 7 ? xe.z : 0u, NW > 7 ? xe.w : 0u};
+        const uint32_t first[11] = {x.a[u].y, x.a[u].z, x.a[u].w, x.c[u].x, x.c[u].y, x.c[u].z, x.c[u].w,
+                                    NW > 7 ? x.e[u].x : 0u, NW > 7 ? x.e[u].y : 0u, NW > 7 ? x.e[u].z : 0u, NW > 7 ? x.e[u].w : 0u};
 #pragma unroll
         for (int w = 0; w <= NW; ++w) wv[w] = w < 11 ? first[w] : 0u;
         const uint32_t m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
@@ -229,14 +248,14 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
           done = true;
         }
       } else {
-        base += 64;
+        base += 64 * G;
       }
     };
-    issue(Sink::strand(id), rec0, size, 0u, ra0, rc0, re0);
+    issue(Sink::strand(id), rec0, size, 0u, b0_);
     for (;;) {
-      step(ra0, rc0, re0, ra1, rc1, re1);
+      step(b0_, b1_);
       if (done) break;
-      step(ra1, rc1, re1, ra0, rc0, re0);
+      step(b1_, b0_);
       if (done) break;
     }
   } else {

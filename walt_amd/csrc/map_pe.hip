@@ -1128,6 +1128,10 @@ struct PeWorkspace {
 // staged reads per pass and mate: a sixteenth of the pass (complex reads and filter hits are ~4 % of the reads
 // of an hg19-like genome), all of it when the pass is small
 static uint32_t pe_stage_cap(uint32_t chunk) {
+  if (const char* e = getenv("WALT_AMD_PE_STAGE_CAP")) {  // test hook: several rounds and the list-kernel fallback on a small batch
+    const long v = atol(e);
+    if (v > 0) return (uint32_t)align_up((uint64_t)v, 64);
+  }
   if (chunk <= 65536) return chunk ? chunk : 1;
   const uint32_t c = chunk / 16;
   return (uint32_t)align_up(c > 65536 ? c : 65536, 64);

@@ -319,6 +319,7 @@ struct HeavyStage {
   uint4* sums;       // [6][hcap]: RegionSummary of (seed, strand) = sums[(2 * seed + strand) * hcap + j]
   uint32_t* flag;    // [hcap]: 1 = the read went to the literal list at an earlier stage
   uint4* items;      // 2 * hcap items of item_quads<NW>() 16-byte words; dense items from the front, gather items from the back
+  uint4* giants;     // hcap / 8 items: dense regions of more than kGiantRegion candidates (counters: ctl[5], cursor ctl[7])
   uint32_t* ctl;     // this (chunk, stage)'s counters: [0] dense items, [1] gather items, [2] [3] the verifiers' cursors,
                      // [4] reads that go on to the next stage
   const uint32_t* list_in;  // stages 1, 2: the chunk positions j this stage visits (count in count_in[4]); else every j
@@ -581,9 +582,13 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         const DenseRange& dr = fi ? dr_m : dr_p;
         const bool dense = bigr && dr.hi > dr.lo;
         {
-          ItemQueue q;
+          ItemQueue q, gq;
           q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
-          item_append<NW>(bigr, dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone, lr.len, seed_i, lr.rd, mk, q);
+          gq.items = hs.giants; gq.ctl = hs.ctl + 5; gq.cap = hs.hcap / 8;
+          const bool giant = dense && my_size > kGiantRegion;
+          const bool placed = item_append<NW>(giant, true, j | (fi << 31), my_l, my_size, (uint32_t)dr.rec, lr.len, seed_i, lr.rd, mk, gq);
+          item_append<NW>(bigr && !(giant && placed), dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone,
+                          lr.len, seed_i, lr.rd, mk, q);
         }
         if (bigr) { ++ctr.big; if (fi) pend_m = true; else pend_p = true; }
       }
@@ -872,13 +877,16 @@ struct SummarySink {
   }
 };
 
-template <int NW, bool DENSE>
-__global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
+template <int NW, bool DENSE, int G = 1>
+__global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
     IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs) {
   static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
+  static_assert(G == 1 || DENSE, "the giant queue holds dense items");
   ItemQueue q;
-  q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
-  const uint32_t n_items = q.ctl[DENSE ? 0 : 1];
+  if (G > 1) { q.items = hs.giants; q.ctl = hs.ctl + 5; q.cap = hs.hcap / 8; }
+  else { q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap; }
+  uint32_t n_items = q.ctl[DENSE ? 0 : 1];
+  if (G > 1 && n_items > q.cap) n_items = q.cap;
   if (n_items == 0) return;
   __shared__ uint32_t s_start[kLdsChroms + 1];
   const bool fits = iv.n_chrom <= kLdsChroms;
@@ -887,8 +895,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
   __syncthreads();
   SummarySink sink;
   sink.sums = hs.sums; sink.hcap = hs.hcap; sink.n_verified = 0;
-  if (fits) item_stream<NW, DENSE, true>(iv, strand_base, q, n_items, s_start, sink);
-  else item_stream<NW, DENSE, false>(iv, strand_base, q, n_items, s_start, sink);
+  if (fits) item_stream<NW, DENSE, true, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink);
+  else item_stream<NW, DENSE, false, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink);
   flush_counters({0u, sink.n_verified, 0u}, 0u, stats);
 }
 
@@ -939,12 +947,16 @@ uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 constexpr uint32_t kHeavyCtlWords = 256;  // 8 words per (chunk, stage): up to 8 chunks x 3 stages
 static uint32_t se_heavy_chunk(uint32_t n) {
   const uint64_t eighth = ((uint64_t)n + 7) / 8;
+  if (const char* e = getenv("WALT_AMD_HEAVY_CHUNK")) {  // test hook: several chunks on a small batch (at most 8 are made)
+    const uint64_t v = (uint64_t)atol(e);
+    if (v >= eighth && v > 0) return (uint32_t)align_up(v, 64);
+  }
   return (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (eighth > 65536 ? eighth : 65536), 64);
 }
 static uint64_t se_heavy_bytes(uint32_t n, int nw) {
   const uint64_t hcap = se_heavy_chunk(n);
   const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
-  return 16 + kHeavyCtlWords * 4 + 3 * hcap * 4 + hcap * 6 * 16 + 2 * hcap * quads * 16;  // flag + two stage lists
+  return 16 + kHeavyCtlWords * 4 + 3 * hcap * 4 + hcap * 6 * 16 + (2 * hcap + hcap / 8) * quads * 16;  // flag + two stage lists; items + giants
 }
 
 // WALT_AMD_ABLATE (diagnostic builds of the measurement only; results are WRONG when
@@ -1001,7 +1013,8 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
   debug_sync("pass 1", stream);
   // WALT_AMD_HEAVY=mono: the one-kernel heavy pass (large regions verified by the whole wavefront of their read's
   // lane) instead of the staged one (large regions streamed by k_se_verify); same results, kept for comparison
-  static const bool mono = [] { const char* e = getenv("WALT_AMD_HEAVY"); return e && !strcmp(e, "mono"); }();
+  const char* heavy_mode = getenv("WALT_AMD_HEAVY");
+  const bool mono = heavy_mode && !strcmp(heavy_mode, "mono");
   if (diag2 && mono)
     hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
@@ -1019,6 +1032,7 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
     uint32_t* const lists = hs.flag + hcap;  // [2][hcap]: what stage 0 hands to stage 1, stage 1 to stage 2
     hs.sums = reinterpret_cast<uint4*>(lists + 2 * (uint64_t)hcap);
     hs.items = hs.sums + (uint64_t)6 * hcap;  // 2 * hcap items of item_quads<NW>() quads
+    hs.giants = hs.items + (uint64_t)2 * hcap * item_quads<NW>();
     hs.hcap = hcap;
     uint32_t* const ctl0 = heavy_area;
     static const unsigned vg_dense = [] {
@@ -1029,6 +1043,11 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
     static const unsigned vg_gather = [] {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, false>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
+      return (unsigned)nb * 256u;
+    }();
+    static const unsigned vg_giant = [] {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, NW <= 10, NW <= 10 ? 4 : 1>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
       return (unsigned)nb * 256u;
     }();
     for (uint32_t c = 0; c < chunks; ++c) {
@@ -1050,8 +1069,11 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                              heavy_list, 0u, nullptr, hs);
         if (stage == 3) break;
-        if constexpr (NW <= 10)
+        if constexpr (NW <= 10) {
+          if (kGiantRegion != 0xFFFFFFFFu)
+            hipLaunchKernelGGL((k_se_verify<NW, true, 4>), dim3(vg_giant), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
           hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
+        }
         hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
       }
     }
