@@ -38,7 +38,7 @@ if st:
         if is_ours(r["Name"]):
             nm = r["Name"].split("(")[0].replace("void ", "")
             kern_ms[nm] = float(r["TotalDurationNs"]) / 1e6 / steps
-            if float(r["TotalDurationNs"]) / 1e6 / steps < 0.05 and "k_map" not in nm and "k_pe" not in nm:
+            if float(r["TotalDurationNs"]) / 1e6 / steps < 0.05 and "k_map" not in nm and "k_pe" not in nm and "k_se_verify" not in nm:
                 continue
             lines.append("| %s | %s | %.3f | %.3f | %.3f | %.3f |" % (nm, r["Calls"], float(r["AverageNs"]) / 1e6,
                                                                    float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6,
@@ -54,7 +54,7 @@ def pmc(sub):
             if not is_ours(k):
                 continue
             # index-building kernels run once, before the steps: not part of a step's traffic
-            if not any(x in k for x in ("k_map_se", "k_pe_", "k_ascii_to_2bit", "k_bin_", "k_reduce_stats")):
+            if not any(x in k for x in ("k_map_se", "k_se_verify", "k_pe_", "k_ascii_to_2bit", "k_bin_", "k_reduce_stats")):
                 continue
             tot[k.split("(")[0].replace("void ", "")][r["Counter_Name"]] += float(r["Counter_Value"])
     return tot
