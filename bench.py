@@ -494,7 +494,7 @@ def pe_report(cx, args, leg, job, n, read_len, sel_all, nu, traffic_key):
     roof = {"bound": "hbm", "achieved": bytes_per_pair * n / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": traffic,
             "traffic_frac": (traffic / step_s / HBM_PEAK) if traffic else None,
-            "kernel": "whole paired-end step (k_pe_topk_dual + list kernels of both mates, k_pe_merge)",
+            "kernel": "whole paired-end step (k_pe_topk_dual, staged k_pe_stage / k_pe_verify / k_pe_push of both mates, k_pe_merge)",
             "step_ms_median": step_s * 1e3, "step_ms_min": float(np.min(leg["per_step"])) * 1e3,
             "algorithmic_bytes_per_pair": bytes_per_pair,
             "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate outside the dense windows, 2 per "
@@ -678,7 +678,7 @@ def worker(args):
             jobs.append({"bases": d_bases.view(n, args.read_len)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
                          "read_len": args.read_len, "max_mm": args.max_mismatches, "b": args.bucket, "ag": args.ag,
                          "timed_first": int(uni.numel()), "sel": sel, "leg": leg, "n": n, "nu": int(uni.numel()),
-                         "traffic_key": "se%d%s" % (args.read_len, "ag" if args.ag else ""), "kernel": "k_map_se<%d> (+ literal pass)" % (7 if args.read_len <= 112 else 10),
+                         "traffic_key": "se%d%s" % (args.read_len, "ag" if args.ag else ""), "kernel": "single-end mapping kernels: k_map_se<%d> pass 1 + heavy stages, k_se_verify, k_map_se_literal" % (7 if args.read_len <= 112 else 10),
                          "target": out})
         # ---- extra leg on the same index: 150 bp single-end at -m 10 (configs[4]'s read length on the C->T side)
         leg150 = None
@@ -700,7 +700,7 @@ def worker(args):
                 jobs.append({"bases": b150.view(n150, 150)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
                              "read_len": 150, "max_mm": 10, "b": args.bucket, "ag": False, "timed_first": int(uni.numel()),
                              "sel": sel, "leg": leg150, "n": n150, "nu": int(uni.numel()), "traffic_key": "se150",
-                             "kernel": "k_map_se<10> (+ literal pass)", "target": line})
+                             "kernel": "single-end mapping kernels: k_map_se<10> pass 1 + heavy stages, k_se_verify, k_map_se_literal", "target": line})
             del b150, o150
         if run_cpu and jobs:
             t0 = time.perf_counter()
@@ -821,7 +821,7 @@ def worker(args):
                 se_jobs.append({"bases": b150.view(n150, 150)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
                                 "read_len": 150, "max_mm": 10, "b": args.bucket, "ag": True, "timed_first": int(uni.numel()),
                                 "sel": sel, "leg": legA, "n": n150, "nu": int(uni.numel()), "traffic_key": "se150ag",
-                                "kernel": "k_map_se<10> (+ literal pass)", "target": lineA})
+                                "kernel": "single-end mapping kernels: k_map_se<10> pass 1 + heavy stages, k_se_verify, k_map_se_literal", "target": lineA})
             del b150, o150
         if run_cpu and jobs:
             t0 = time.perf_counter()
