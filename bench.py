@@ -731,6 +731,11 @@ def worker(args):
         pe_cfgs.append(("configs[2]", npe, 100, 6, False, args.extra_steps, 1))
         pe_cfgs.append(("configs[4]", max(1, npe // 2), 150, 10, True, args.extra_steps, 1))
     if pe_cfgs:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        free_b, total_b = torch.cuda.mem_get_info()
+        log("before the 4-strand index: %.1f GB free of %.1f (torch holds %.1f GB)" % (free_b / 1e9, total_b / 1e9, torch.cuda.memory_allocated() / 1e9))
         t0 = time.perf_counter()
         idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local,
                                           strands=walt_amd.STRANDS_ALL, dir_bits=args.dir_bits)
