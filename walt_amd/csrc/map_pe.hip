@@ -430,7 +430,7 @@ struct PeStage {
                          // atomic: same-address atomics run at ~10 ns each, and nearly every item takes one chunk);
                          // the dynamic part starts at 3 * static_n
   uint32_t* flag;    // [j]: 1 = gone to the literal list, 2 = a probe outgrew its chunks or the pool
-  ItemQueue q;       // 6 * ccap items; id = j | probe << 24, probe = 3 * strand + seed shift
+  ItemQueue q;       // 2 * ccap items (emptied after every seed); id = j | probe << 24, probe = 3 * strand + seed shift
   uint32_t ccap;     // staged reads per pass and mate
 };
 
@@ -1125,8 +1125,10 @@ struct PeWorkspace {
   uint4* items[2];
   uint32_t ccap, pool_chunks;
 };
-// staged reads per pass and mate: a sixteenth of the pass (complex reads and filter hits are ~4 % of the reads
-// of an hg19-like genome), all of it when the pass is small
+// staged reads per round, pass and mate: a sixteenth of the pass (complex reads and filter hits are a fifth of the
+// reads of an hg19-like genome: four rounds; the state of a staged read is 2.2 KB and the paired-end index leaves
+// little room -- with rounds of an eighth the survivor pool had to shrink and a tenth of the staged reads fell
+// back to the list kernel: 359 ms against 315), all of it when the pass is small
 static uint32_t pe_stage_cap(uint32_t chunk) {
   if (const char* e = getenv("WALT_AMD_PE_STAGE_CAP")) {  // test hook: several rounds and the list-kernel fallback on a small batch
     const long v = atol(e);
@@ -1167,7 +1169,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
     w.chunk_tab[m] = reinterpret_cast<uint32_t*>(take((uint64_t)6 * kPeChunksHost * w.ccap * 4));
     w.pool[m] = reinterpret_cast<uint2*>(take((uint64_t)w.pool_chunks * 64 * 8));
     w.sflag[m] = reinterpret_cast<uint32_t*>(take((uint64_t)w.ccap * 4));
-    w.items[m] = reinterpret_cast<uint4*>(take((uint64_t)6 * w.ccap * quads * 16));
+    w.items[m] = reinterpret_cast<uint4*>(take((uint64_t)2 * w.ccap * quads * 16));  // the queue is emptied after every seed: two probes per read
   }
   w.total_bytes = off;
   return w;
@@ -1207,7 +1209,7 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     PeStage ps;
     ps.inl = w.inl[mate]; ps.surv_n = w.surv_n[mate]; ps.cz = w.cz[mate]; ps.chunk = w.chunk_tab[mate]; ps.pool = w.pool[mate];
     ps.pool_next = ctl + 27; ps.pool_chunks = w.pool_chunks; ps.static_n = w.pool_chunks / 4; ps.flag = w.sflag[mate];
-    ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 6 * w.ccap;
+    ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 2 * w.ccap;
     ps.ccap = w.ccap;
     uint32_t* fb_count = ctl + 26;
     uint32_t* fb_list = w.fb_list[mate];
