@@ -719,6 +719,7 @@ def worker(args):
                         args.bucket, jobs[0]["cores"])
                 except Exception as e:  # never let the extra leg break the bench line
                     out["cpu_baseline"]["reference_binary"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
+        j = None  # (the loop variable above still referred to the last job: its leg's workspace and result tensors)
         del jobs, leg, leg150, d_bases, d_off
         idx.close()
         torch.cuda.empty_cache()

@@ -757,7 +757,7 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 #if WALT_SEEDPATTERN == 3
 // pass 1: every read of the batch, one per lane (HEAVY = false); pass 1b: the reads of the heavy list (HEAVY = true)
 template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
-__global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
+__global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? (STAGED ? 4 : 3) : (NW <= 10 ? (STAGED ? 3 : 2) : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
                                                     const uint64_t* __restrict__ offsets,
                                                     uint32_t* __restrict__ err,
                                                     uint32_t n_all, uint32_t strand_base,
