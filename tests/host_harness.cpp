@@ -314,6 +314,50 @@ int hh_region_check(void* hp, const char* bases, const uint64_t* offsets, uint32
   return 0;
 }
 
+// core.h kary_round (the heavy stages' round-by-round slot search, two slots advanced together) against
+// slot_kary_search on random sorted slots: returns the number of differing answers.  Keys are drawn from few
+// values so that equal ranges are long; masks of 1..32 key characters; targets present and absent.
+long hh_kary_check(uint32_t seed, uint32_t n_cases) {
+  uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1);
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  long bad = 0;
+  for (uint32_t c = 0; c < n_cases; ++c) {
+    const uint32_t n = 1 + (uint32_t)(rnd() % (c % 7 == 0 ? 5000 : 90));
+    const uint32_t distinct = 1 + (uint32_t)(rnd() % (c % 3 == 0 ? 4 : 40));
+    const uint32_t nk = 1 + (uint32_t)(rnd() % kKeyChars);
+    const uint64_t M = key_mask(nk);
+    std::vector<uint64_t> vals(distinct);
+    for (auto& v : vals) v = rnd();
+    std::vector<uint64_t> keys(n);
+    for (auto& k : keys) k = vals[rnd() % distinct];
+    std::sort(keys.begin(), keys.end(), [&](uint64_t a, uint64_t b) { return (a & M) < (b & M) || ((a & M) == (b & M) && a < b); });
+    std::vector<Ent> ent(n + 8);
+    for (uint32_t i = 0; i < n; ++i) { ent[i].key_hi = (uint32_t)(keys[i] >> 32); ent[i].key_lo = (uint32_t)keys[i]; ent[i].pos = i; }
+    StrandView sv;
+    memset(&sv, 0, sizeof(sv));
+    sv.ent = ent.data();
+    sv.index_size = n;
+    for (int t = 0; t < 6; ++t) {
+      const uint64_t T = (t < 4 ? vals[rnd() % distinct] : rnd()) & M;
+      const uint32_t lo = (uint32_t)(rnd() % n), hi = lo + 1 + (uint32_t)(rnd() % (n - lo));
+      uint32_t a1 = 0, u1 = 0, a2 = 0, u2 = 0;
+      const bool f1 = slot_kary_search(sv, lo, hi, T, M, a1, u1);
+      KaryState ks, other;
+      kary_init(ks, lo, hi);
+      kary_init(other, 0, (uint32_t)(rnd() % 2 ? n : 0));  // a second search running beside it, as in probe_resolve_dual
+      uint32_t rounds = 0;
+      while (kary_busy(ks) || kary_busy(other)) {
+        kary_round(sv, ks, T, M, lo);
+        kary_round(sv, other, T ^ 1, M, 0);
+        if (++rounds > 64) break;
+      }
+      const bool f2 = kary_result(ks, a2, u2);
+      if (rounds > 64 || f1 != f2 || (f1 && (a1 != a2 || u1 != u2))) ++bad;
+    }
+  }
+  return bad;
+}
+
 // expose the literal tables for tests/test_seedtab.py
 int hh_pattern() { return (int)kPat; }
 void hh_get_nocare(uint32_t* out /* kPat x 150 */) {

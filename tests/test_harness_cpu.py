@@ -253,3 +253,13 @@ def test_harness_outlier_stress_low_entropy(scratch, seed):
             for j in range(800):
                 assert np.array_equal(r[j][:n[j]]["genome_pos"], ro[j][:no[j]]["genome_pos"]), j
         h.close()
+
+
+def test_round_based_kary_search_equals_the_two_sided_search():
+    """core.h kary_round (heavy stages: both strands' slots advanced in one loop, eight pivots per round, shared by
+    the lower- and the upper-bound search while their ranges coincide) must return the equal range that
+    slot_kary_search returns: 3,000 random sorted slots of 1..5,000 entries with long runs of equal keys, masks of
+    1..32 key characters, six targets each (present and absent), sub-ranges of the slot."""
+    for seed in range(3):
+        assert refio.harness().hh_kary_check(seed, 1000) == 0
+
