@@ -198,6 +198,11 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
 #pragma unroll
     for (int u = 0; u < G; ++u) { b0_.a[u] = b0_.c[u] = b0_.e[u] = zero; b1_.a[u] = b1_.c[u] = b1_.e[u] = zero; }
     auto issue = [&](uint32_t fi, uint32_t r0, uint32_t sz, uint32_t base, Buf& y) {
+      // fi is wave-uniform; saying so keeps the strand's record pointer a SCALAR load -- as a vector load it was
+      // waited for with vmcnt(0), i.e. together with every record in flight (the paired-end sink's strand())
+      fi = (uint32_t)__builtin_amdgcn_readfirstlane((int)fi);
+      r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
+      sz = (uint32_t)__builtin_amdgcn_readfirstlane((int)sz);
       const StrandView& sv = iv.s[strand_base + fi];
 #pragma unroll
       for (int u = 0; u < G; ++u) {
