@@ -905,12 +905,23 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
         const uint32_t n = sn & 0x7FFFFFFFu;
         const bool chunked = (sn >> 31) != 0;
         uint32_t ch = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-          if (chunked && k % kPeChunkEnts == 0) ch = ps.chunk[((uint64_t)probe * kPeChunks + k / kPeChunkEnts) * ccap + j];
-          const uint2 c = chunked ? ps.pool[(uint64_t)ch * kPeChunkEnts + k % kPeChunkEnts]
-                                  : ps.inl[((uint64_t)probe * kPeMidRegion + k) * ccap + j];
-          HeapEnt e; e.pos = c.x; e.mms = c.y | (fi << 31);
-          topk_push(heap, hsize, top_k, e);  // paired.cpp:195
+        // eight survivors per round of loads (one load per push made a read with 200 survivors 200 round trips)
+        for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+          if (chunked && k0 % kPeChunkEnts == 0) ch = ps.chunk[((uint64_t)probe * kPeChunks + k0 / kPeChunkEnts) * ccap + j];
+          uint2 c[8];
+#pragma unroll
+          for (uint32_t t = 0; t < 8; ++t) {
+            const uint32_t k = k0 + t < n ? k0 + t : n - 1;  // (a chunk holds 64: eight from k0 stay inside it)
+            c[t] = chunked ? ps.pool[(uint64_t)ch * kPeChunkEnts + k % kPeChunkEnts]
+                           : ps.inl[((uint64_t)probe * kPeMidRegion + k) * ccap + j];
+          }
+#pragma unroll
+          for (uint32_t t = 0; t < 8; ++t) {
+            if (k0 + t < n) {
+              HeapEnt e; e.pos = c[t].x; e.mms = c[t].y | (fi << 31);
+              topk_push(heap, hsize, top_k, e);  // paired.cpp:195
+            }
+          }
         }
       }
     }
