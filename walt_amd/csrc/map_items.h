@@ -23,16 +23,21 @@ constexpr uint32_t kItemDenseNone = 0xFFFFFFFFu;
 // serves about a hundred million of those per second -- a million items taken eight at a time spent half the
 // verifier's time queueing for the cursor.  So: a quarter of a wavefront's fair share, at most kVerifyBatchMax.
 constexpr uint32_t kVerifyBatchMax = 32;
-// Dense regions above this size would go to a second queue verified four groups per step (item_stream's G): measured
-// SLOWER on the hg19-like genome (17.7 against 16.3 ms: the wider steps cost occupancy, and most candidates sit in
-// such regions), so the queue is off; the code path stays for genomes whose regions are few and huge.
-constexpr uint32_t kGiantRegion = 0xFFFFFFFFu;
+// (item_stream's G: groups of 64 candidates per step; 4 was measured slower than 1 -- DESIGN.md section 12)
 
 struct ItemQueue {
   uint4* items;   // cap items of item_quads<NW>() quads
   uint32_t* ctl;  // [0] dense items, [1] gather items, [2] [3] the verifiers' cursors (zeroed by the host)
   uint32_t cap;   // items the array has room for, both kinds together
+  // Largest first: dense items of more than kBigFirst candidates go to their own array and the dense verifier takes
+  // them BEFORE the others (item numbers [0, bigs) are this array's), dealt round robin over the wavefronts -- a
+  // region of thousands of candidates is tens of dependent steps, and a wavefront that met two or three of them at
+  // the end of its share set the duration of the launch.  nullptr: no such array.
+  uint4* bigs;
+  uint32_t* big_n;   // items in it (zeroed by the host)
+  uint32_t big_cap;
 };
+constexpr uint32_t kBigFirst = 1024;
 
 template <int NW>
 constexpr uint32_t item_quads() { return 2u + (2u * NW + 3u) / 4u; }
@@ -47,20 +52,24 @@ __device__ __forceinline__ bool item_append(bool take, bool dense, uint32_t id, 
   constexpr uint32_t Q = item_quads<NW>();
   const uint32_t lane = threadIdx.x & 63;
   bool placed = true;
+  bool in_bigs = false;  // this lane's item went to the largest-first array
 #pragma unroll
-  for (int side = 0; side < 2; ++side) {
-    const bool mine = take && (dense == (side == 0));
+  for (int side = -1; side < 2; ++side) {  // -1: the largest-first array
+    if (side < 0 && q.bigs == nullptr) continue;
+    const bool mine = side < 0 ? (take && dense && size > kBigFirst) : (take && !in_bigs && (dense == (side == 0)));
     const unsigned long long m = __ballot(mine);
     if (!m) continue;
     const int leader = (int)__ffsll((long long)m) - 1;
     uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(&q.ctl[side], (uint32_t)__popcll(m));
+    if ((int)lane == leader) base = atomicAdd(side < 0 ? q.big_n : &q.ctl[side], (uint32_t)__popcll(m));
     base = bcast(base, leader);
     const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (mine && k >= q.cap) placed = false;
-    if (mine && k < q.cap) {
-      const uint64_t at = side == 0 ? k : (uint64_t)q.cap - 1 - k;
-      uint4* it = q.items + Q * at;
+    const uint32_t room = side < 0 ? q.big_cap : q.cap;
+    if (side < 0) in_bigs = mine && k < room;       // no room: the item goes to the ordinary dense side below
+    else if (mine && k >= room) placed = false;
+    if (mine && k < room) {
+      const uint64_t at = side <= 0 ? k : (uint64_t)q.cap - 1 - k;
+      uint4* it = (side < 0 ? q.bigs : q.items) + Q * at;
       it[0] = make_uint4(id, l, size, rec);
       it[1] = make_uint4(len, seed_i, 0u, 0u);
       uint32_t w[4 * (Q - 2)];
@@ -110,16 +119,18 @@ __device__ __forceinline__ T load_global(const T* p) {
 // mapping.cpp:280-286 / paired.cpp:166-171);  step() after every 64 candidates;  end().
 template <int NW, bool DENSE, bool FITS, class Sink, int G = 1>
 __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand_base, const ItemQueue& q, uint32_t n_items,
-                                            const uint32_t* s_start, Sink& sink) {
+                                            const uint32_t* s_start, Sink& sink, uint32_t n_big = 0) {
+  // n_items counts the n_big items of q.bigs (taken first) and the dense (or gather) items of q.items
   constexpr uint32_t Q = item_quads<NW>();
   const uint32_t n_chrom = iv.n_chrom, top_step = top_step_of(n_chrom);
   uint32_t* const cursor = &q.ctl[DENSE ? 2 : 3];
   const uint32_t lane = threadIdx.x & 63;
   const uint4 zero = make_uint4(0, 0, 0, 0);
   auto header = [&](uint32_t i, bool on) {  // lane t < Q: quad t of item i
-    const uint64_t at = DENSE ? (uint64_t)i : (uint64_t)q.cap - 1 - i;
+    const bool big = DENSE && i < n_big;
+    const uint64_t at = big ? (uint64_t)i : (DENSE ? (uint64_t)(i - n_big) : (uint64_t)q.cap - 1 - i);
     // branch-free (a value loaded under a branch is waited for where the branch ends): idle lanes read quad 0
-    return load_global(q.items + ((on && lane < Q) ? Q * at + lane : 0ull));
+    return load_global((big ? q.bigs : q.items) + ((on && lane < Q) ? Q * at + lane : 0ull));
   };
   // The first batch of every wavefront is dealt statically (wave w: items [w * batch, (w + 1) * batch)), the cursor
   // hands out what lies behind those: a launch with few items -- the later stages -- makes no atomic at all
@@ -150,7 +161,9 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
       c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
     }
   };
-  uint32_t b0 = wave * first_batch, t = 0;
+  // (the statically dealt items of a wavefront are n_waves apart: the largest come first in the numbering and are
+  // spread over the wavefronts this way)
+  uint32_t b0 = wave, t = 0, stride = n_waves;
   uint32_t cur_batch = first_batch;  // items of the batch being worked on
   if (b0 >= n_items) return;
   uint32_t nb_v = 0;        // lane 0: start of the next batch, asked for when the current batch's last item begins
@@ -181,13 +194,14 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
   auto fetch_next = [&]() {
     if (t + 1 < cur_batch) {
       ++t;
-      ni = b0 + t;
+      ni = b0 + t * stride;
     } else {
       b0 = asked ? bcast(nb_v, 0) : 0xFFFFFFFFu;  // (asked: the atomic was issued one item ago)
       asked = false;
       t = 0;
       ni = b0;
       cur_batch = batch;
+      stride = 1;
     }
     if (t + 1 == cur_batch && ni < n_items && dealt < n_items) {  // ni is the batch's last item: ask for the batch after it
       nb_v = grab();

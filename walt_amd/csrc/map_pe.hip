@@ -766,7 +766,9 @@ template <int NW, bool DENSE>
 __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_pe_verify(
     IndexView iv, uint32_t strand_base, uint32_t max_mm, uint32_t top_k, unsigned long long* __restrict__ stats, PeStage ps) {
   static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
-  const uint32_t n_items = ps.q.ctl[DENSE ? 0 : 1];
+  uint32_t n_big = DENSE ? *ps.q.big_n : 0u;
+  n_big = n_big < ps.q.big_cap ? n_big : ps.q.big_cap;
+  const uint32_t n_items = ps.q.ctl[DENSE ? 0 : 1] + n_big;
   if (n_items == 0) return;
   __shared__ uint32_t s_start[kLdsChroms + 1];
   __shared__ uint32_t s_hist[kBlock / 64][64];
@@ -777,8 +779,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
   SurvivorSink sink;
   sink.ps = ps; sink.max_mm = max_mm; sink.top_k = top_k; sink.hist = s_hist[threadIdx.x >> 6]; sink.n_verified = 0;
   sink.gp_ = 0; sink.mm_ = 0xFFFFFFFFu; sink.dense_kind = DENSE;
-  if (fits) item_stream<NW, DENSE, true>(iv, strand_base, ps.q, n_items, s_start, sink);
-  else item_stream<NW, DENSE, false>(iv, strand_base, ps.q, n_items, s_start, sink);
+  if (fits) item_stream<NW, DENSE, true>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
+  else item_stream<NW, DENSE, false>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
   pe_flush(0u, 0u, sink.n_verified, 0u, stats);
 }
 
@@ -1134,6 +1136,7 @@ struct PeWorkspace {
   uint2* pool[2];
   uint32_t* sflag[2];
   uint4* items[2];
+  uint4* bigs[2];
   uint32_t ccap, pool_chunks;
 };
 // staged reads per round, pass and mate: a sixteenth of the pass (complex reads and filter hits are a fifth of the
@@ -1181,6 +1184,7 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
     w.pool[m] = reinterpret_cast<uint2*>(take((uint64_t)w.pool_chunks * 64 * 8));
     w.sflag[m] = reinterpret_cast<uint32_t*>(take((uint64_t)w.ccap * 4));
     w.items[m] = reinterpret_cast<uint4*>(take((uint64_t)2 * w.ccap * quads * 16));  // the queue is emptied after every seed: two probes per read
+    w.bigs[m] = reinterpret_cast<uint4*>(take((uint64_t)(w.ccap / 8 + 64) * quads * 16));  // its largest-first array
   }
   w.total_bytes = off;
   return w;
@@ -1221,6 +1225,7 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     ps.inl = w.inl[mate]; ps.surv_n = w.surv_n[mate]; ps.cz = w.cz[mate]; ps.chunk = w.chunk_tab[mate]; ps.pool = w.pool[mate];
     ps.pool_next = ctl + 27; ps.pool_chunks = w.pool_chunks; ps.static_n = w.pool_chunks / 4; ps.flag = w.sflag[mate];
     ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 2 * w.ccap;
+    ps.q.bigs = w.bigs[mate]; ps.q.big_n = ctl + 2; ps.q.big_cap = w.ccap / 8 + 64;
     ps.ccap = w.ccap;
     uint32_t* fb_count = ctl + 26;
     uint32_t* fb_list = w.fb_list[mate];
@@ -1247,7 +1252,7 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     uint32_t* big_list = w.big_list[mate];
     auto clear_round = [&]() {  // pool + queue, the push kernels' list
       return hipMemsetAsync(ctl + 27, 0, 5 * sizeof(uint32_t), stream) == hipSuccess &&
-             hipMemsetAsync(big_count, 0, sizeof(uint32_t), stream) == hipSuccess;
+             hipMemsetAsync(big_count, 0, 2 * sizeof(uint32_t), stream) == hipSuccess;  // ctl[1], and ctl[2]: the queue's largest-first count
     };
     auto push = [&](const uint32_t* count, const uint32_t* list, uint32_t* over_n, uint32_t* over_l, uint32_t first) {
       hipLaunchKernelGGL(k_pe_push<true>, dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
@@ -1255,7 +1260,10 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
       hipLaunchKernelGGL(k_pe_push<false>, dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
                          first, big_count, big_list);
     };
-    auto clear_queue = [&]() { return hipMemsetAsync(ctl + 28, 0, 4 * sizeof(uint32_t), stream) == hipSuccess; };
+    auto clear_queue = [&]() {
+      return hipMemsetAsync(ctl + 28, 0, 4 * sizeof(uint32_t), stream) == hipSuccess &&
+             hipMemsetAsync(ctl + 2, 0, sizeof(uint32_t), stream) == hipSuccess;
+    };
     // pass 1 with ONE list: filter hits (tagged) and complex reads both go to the staged kernels
     hipLaunchKernelGGL(k_pe_topk_dual<NW>, dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n, sb,
                        max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, cplx_count, cplx_list, cplx_count,

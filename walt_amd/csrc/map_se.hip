@@ -319,7 +319,7 @@ struct HeavyStage {
   uint4* sums;       // [6][hcap]: RegionSummary of (seed, strand) = sums[(2 * seed + strand) * hcap + j]
   uint32_t* flag;    // [hcap]: 1 = the read went to the literal list at an earlier stage
   uint4* items;      // 2 * hcap items of item_quads<NW>() 16-byte words; dense items from the front, gather items from the back
-  uint4* giants;     // hcap / 8 items: dense regions of more than kGiantRegion candidates (counters: ctl[5], cursor ctl[7])
+  uint4* giants;     // hcap / 8 items: the dense regions of more than kBigFirst candidates, verified first (count: ctl[5])
   uint32_t* ctl;     // this (chunk, stage)'s counters: [0] dense items, [1] gather items, [2] [3] the verifiers' cursors,
                      // [4] reads that go on to the next stage
   const uint32_t* list_in;  // stages 1, 2: the chunk positions j this stage visits (count in count_in[4]); else every j
@@ -582,13 +582,10 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         const DenseRange& dr = fi ? dr_m : dr_p;
         const bool dense = bigr && dr.hi > dr.lo;
         {
-          ItemQueue q, gq;
+          ItemQueue q;
           q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
-          gq.items = hs.giants; gq.ctl = hs.ctl + 5; gq.cap = hs.hcap / 8;
-          const bool giant = dense && my_size > kGiantRegion;
-          const bool placed = item_append<NW>(giant, true, j | (fi << 31), my_l, my_size, (uint32_t)dr.rec, lr.len, seed_i, lr.rd, mk, gq);
-          item_append<NW>(bigr && !(giant && placed), dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone,
-                          lr.len, seed_i, lr.rd, mk, q);
+          q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
+          item_append<NW>(bigr, dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone, lr.len, seed_i, lr.rd, mk, q);
         }
         if (bigr) { ++ctr.big; if (fi) pend_m = true; else pend_p = true; }
       }
@@ -881,12 +878,12 @@ template <int NW, bool DENSE, int G = 1>
 __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
     IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs) {
   static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
-  static_assert(G == 1 || DENSE, "the giant queue holds dense items");
   ItemQueue q;
-  if (G > 1) { q.items = hs.giants; q.ctl = hs.ctl + 5; q.cap = hs.hcap / 8; }
-  else { q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap; }
-  uint32_t n_items = q.ctl[DENSE ? 0 : 1];
-  if (G > 1 && n_items > q.cap) n_items = q.cap;
+  q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
+  q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
+  uint32_t n_big = DENSE ? *q.big_n : 0u;
+  n_big = n_big < q.big_cap ? n_big : q.big_cap;
+  const uint32_t n_items = q.ctl[DENSE ? 0 : 1] + n_big;
   if (n_items == 0) return;
   __shared__ uint32_t s_start[kLdsChroms + 1];
   const bool fits = iv.n_chrom <= kLdsChroms;
@@ -895,8 +892,8 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
   __syncthreads();
   SummarySink sink;
   sink.sums = hs.sums; sink.hcap = hs.hcap; sink.n_verified = 0;
-  if (fits) item_stream<NW, DENSE, true, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink);
-  else item_stream<NW, DENSE, false, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink);
+  if (fits) item_stream<NW, DENSE, true, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big);
+  else item_stream<NW, DENSE, false, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big);
   flush_counters({0u, sink.n_verified, 0u}, 0u, stats);
 }
 
@@ -1045,11 +1042,6 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, false>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
       return (unsigned)nb * 256u;
     }();
-    static const unsigned vg_giant = [] {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, NW <= 10, NW <= 10 ? 4 : 1>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
-      return (unsigned)nb * 256u;
-    }();
     for (uint32_t c = 0; c < chunks; ++c) {
       hs.first = c * hcap;
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
@@ -1070,8 +1062,6 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
                              heavy_list, 0u, nullptr, hs);
         if (stage == 3) break;
         if constexpr (NW <= 10) {
-          if (kGiantRegion != 0xFFFFFFFFu)
-            hipLaunchKernelGGL((k_se_verify<NW, true, 4>), dim3(vg_giant), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
           hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
         }
         hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
