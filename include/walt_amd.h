@@ -70,9 +70,13 @@ typedef struct {
  * stat.num_of_short_reads++ at mapping.cpp:230-233 / paired.cpp:112-115). */
 typedef struct {
   uint64_t too_short;
-  uint64_t probes;     /* seed probes into non-empty buckets (diagnostic) */
-  uint64_t candidates; /* candidates verified (diagnostic) */
-  uint64_t big_regions;/* regions handled wave-cooperatively (diagnostic) */
+  /* Diagnostic work counters of the kernels, NOT the reference's: they include probes the kernels make
+   * speculatively (a superset of the reference's on the '-' strand, all probes of a staged paired-end read up to
+   * the exits it can prove), and a read that moves on to the literal pass after part of its work is counted in
+   * both places. */
+  uint64_t probes;     /* seed probes into non-empty buckets */
+  uint64_t candidates; /* candidates verified */
+  uint64_t big_regions;/* regions handed to a wavefront (work items / cooperative verification) */
 } walt_batch_stats;
 
 typedef struct walt_index walt_index;

@@ -17,7 +17,14 @@ int main(int argc, const char** argv) {
     else if ((a == "-o" || a == "-output") && i + 1 < argc) out = argv[++i];
     else if ((a == "-t" || a == "-thread") && i + 1 < argc) threads = atoi(argv[++i]);
     else if ((a == "-g" || a == "-gpu") && i + 1 < argc) device = atoi(argv[++i]);  // extension: build on this GPU
-    else { fprintf(stderr, "Usage: makedb -c <chromosomes .fa file or dir> -o <output .dbindex> [-t threads] [-g gpu]\n"); return EXIT_SUCCESS; }
+    else {
+      fprintf(stderr, "Usage: makedb -c <chromosomes .fa file or dir> -o <output .dbindex> [-t threads] [-g gpu]\n"
+                      "  -g <gpu>  build on this GPU (seconds instead of minutes).  Entries whose 60 care characters are all equal come out\n"
+                      "            in ascending position, not in the order the reference's std::sort leaves them: the files map the same\n"
+                      "            reads with the same counts, but the position reported for an ambiguous read (last one wins) can differ\n"
+                      "            from the reference's; without -g the files are byte-identical to the reference makedb's.\n");
+      return EXIT_SUCCESS;
+    }
   }
   if (chrom.empty() || out.empty()) { fprintf(stderr, "Usage: makedb -c <chromosomes .fa file or dir> -o <output .dbindex>\n"); return EXIT_SUCCESS; }
   if (out.substr(out.find_last_of(".") + 1) != "dbindex") {  // makedb.cpp:120-123
