@@ -939,16 +939,17 @@ __global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const u
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
-// staged heavy pass: reads per chunk of the heavy list (an eighth of the batch, the whole batch when it is small)
+// staged heavy pass: reads per chunk of the heavy list (a quarter of the batch -- one chunk holds the heavy reads of
+// an hg19-like genome, a sixth of all: two chunks of an eighth cost 2.3 ms more -- the whole batch when it is small)
 // and the bytes of its state behind the dense read array: [128 control words][flag][6 summaries][2 x 2 item words]
 constexpr uint32_t kHeavyCtlWords = 256;  // 8 words per (chunk, stage): up to 8 chunks x 3 stages
 static uint32_t se_heavy_chunk(uint32_t n) {
-  const uint64_t eighth = ((uint64_t)n + 7) / 8;
+  const uint64_t share = ((uint64_t)n + 3) / 4;
   if (const char* e = getenv("WALT_AMD_HEAVY_CHUNK")) {  // test hook: several chunks on a small batch (at most 8 are made)
     const uint64_t v = (uint64_t)atol(e);
-    if (v >= eighth && v > 0) return (uint32_t)align_up(v, 64);
+    if (v * 8 >= n && v > 0) return (uint32_t)align_up(v, 64);
   }
-  return (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (eighth > 65536 ? eighth : 65536), 64);
+  return (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (share > 65536 ? share : 65536), 64);
 }
 static uint64_t se_heavy_bytes(uint32_t n, int nw) {
   const uint64_t hcap = se_heavy_chunk(n);
