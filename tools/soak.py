@@ -76,7 +76,11 @@ def main():
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     cases = reads_total = pairs_total = 0
     seed = args.seed0
+    t_note = time.time()
     while time.time() < t_end:
+        if time.time() - t_note > 60:  # a sign of life (runs under a watchdog that takes minutes of silence for a hang)
+            print("soak: %d genomes so far, no difference" % cases, file=sys.stderr, flush=True)
+            t_note = time.time()
         rng = random.Random(seed)
         tmp = tempfile.mkdtemp(prefix="walt_soak_", dir=base)
         try:
