@@ -108,6 +108,7 @@ class Ctx:
 # ------------------------------------------------------------------------------------------------ single-end
 def se_leg(cx, idx, d_bases, d_off, n, read_len, max_mm, b, ag, steps, warmup, timed_barrier=True):
     """K timed steps of the single-end hot path on a resident batch; returns timing + device result tensors."""
+    import numpy as np
     torch, walt_amd = cx.torch, cx.walt_amd
     dev = cx.dev
     d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
@@ -124,13 +125,14 @@ def se_leg(cx, idx, d_bases, d_off, n, read_len, max_mm, b, ag, steps, warmup, t
     for _ in range(warmup):
         step()
     cx.barrier() if timed_barrier else torch.cuda.synchronize()
-    pack_ms, map_ms = [], []
+    pack_ms, map_ms, detail = [], [], []
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
         p_ms, m_ms = idx.profile_last()  # waits for this step's events (same stream)
         pack_ms.append(p_ms)
         map_ms.append(m_ms)
+        detail.append(idx.profile_detail())  # the same call's mapping time by kernel group (HIP events between the groups)
     cx.barrier() if timed_barrier else torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     idx.check_batch(d_ws.data_ptr(), stream)  # no invalid read went unnoticed
@@ -144,7 +146,7 @@ def se_leg(cx, idx, d_bases, d_off, n, read_len, max_mm, b, ag, steps, warmup, t
         off = 64 * 4 + 256 * 16 * 8
         deferred = (d_ws[off:off + 4 * n_def].view(torch.int32) & 0x0FFFFFFF).long()
     return {"elapsed": elapsed, "pack_ms": pack_ms, "map_ms": map_ms, "d_out": d_out, "stats": st, "deferred": deferred,
-            "n_deferred": n_def, "n_heavy": n_heavy, "d_ws": d_ws}
+            "n_deferred": n_def, "n_heavy": n_heavy, "d_ws": d_ws, "detail_ms": np.median(np.array(detail), axis=0).tolist()}
 
 
 def se_sample(cx, leg, n, n_uniform, n_hard):
@@ -268,8 +270,17 @@ def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, tr
                 traffic = t["hbm_bytes_per_launch"]
         except (ValueError, KeyError, AttributeError):
             pass
+    # the kernel groups of the call, timed by HIP events between them (walt_profile_detail); the region verifier's
+    # algorithmic bytes are its dense records alone, so it has a roofline of its own
+    dms = leg.get("detail_ms") or [0.0, 0.0, 0.0, 0.0]
+    by_kernel = {"k_map_se pass 1": {"ms": dms[0]}, "k_map_se heavy stages": {"ms": dms[1]},
+                 "k_se_verify": {"ms": dms[2]}, "k_map_se_literal (+ sort)": {"ms": dms[3]}}
+    if dms[2] > 0 and C_big > 0:
+        vb = rec_bytes * C_big * n
+        by_kernel["k_se_verify"].update({"algorithmic_bytes": vb, "achieved": vb / (dms[2] / 1e3) / 1e9, "unit": "GB/s",
+                                         "frac": vb / (dms[2] / 1e3) / HBM_PEAK})
     roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "frac": achieved / HBM_PEAK, "traffic": traffic, "by_kernel": by_kernel,
             "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
             "kernel": kernel_name, "kernel_ms_median": kern_s * 1e3, "kernel_ms_min": float(np.min(leg["map_ms"])),
             "algorithmic_bytes_per_read": bytes_per_read,

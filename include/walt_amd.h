@@ -258,6 +258,9 @@ void walt_comm_close(walt_comm* comm);
  * the last call's events and returns the two durations in milliseconds. */
 int walt_profile_enable(walt_index* idx, int on);
 int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms);
+/* The last single-end call's mapping time by kernel group, from events between the groups: out4 = milliseconds of
+ * {pass 1, heavy stages, region verifier, literal pass incl. its sort}. */
+int walt_profile_detail(walt_index* idx, float* out4);
 /* Diagnostic (environment WALT_AMD_STAMPS=1): in-kernel s_memtime sums per phase of
  * the single-end mapping kernel, cycles summed over waves; reading clears them. */
 int walt_profile_stamps(unsigned long long* out16);

@@ -175,6 +175,7 @@ def lib(pattern=None):
     L.walt_index_write.argtypes = [vp, c.c_char_p]
     L.walt_profile_enable.argtypes = [vp, ci]
     L.walt_profile_last.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_float)]
+    L.walt_profile_detail.argtypes = [vp, c.POINTER(c.c_float)]
     L.walt_comm_unique_id.argtypes = [vp]
     L.walt_comm_init.argtypes = [ci, ci, ci, vp, c.POINTER(vp)]
     L.walt_stats_allreduce.argtypes = [vp, vp, c.c_size_t]
@@ -339,6 +340,12 @@ class Index:
         a, b = ctypes.c_float(0), ctypes.c_float(0)
         self._ck(self._L.walt_profile_last(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def profile_detail(self):
+        """ms of the last single-end call by kernel group: pass 1, heavy stages, region verifier, literal pass"""
+        buf = (ctypes.c_float * 4)()
+        self._ck(self._L.walt_profile_detail(self._h, buf))
+        return [float(x) for x in buf]
 
     def close(self):
         if self._h:

@@ -35,6 +35,13 @@ struct walt_index {
   bool profile = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before pack, before map, after map
   bool ev_valid = false;
+  // walt_profile_detail: events at the boundaries between the kernel groups of the last single-end call (at most
+  // kDetailEvents - 1 intervals; kind of the interval that ENDS at event i: 0 pass 1, 1 heavy stages, 2 verifier,
+  // 3 literal pass incl. its sort)
+  static constexpr int kDetailEvents = 96;
+  hipEvent_t ev_detail[kDetailEvents] = {};
+  unsigned char ev_kind[kDetailEvents] = {};
+  int n_detail = 0;
   // paired-end (created on first use): two pipeline slots, each with a stream for mate 1 + merge (A, unused in
   // slot 0 of a single-pass call: the caller's stream plays that role) and one for mate 2 (B)
   hipStream_t pe_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};

@@ -922,6 +922,8 @@ void walt_index_close(walt_index* idx) {
     if (p) hipFree(p);
   for (int i = 0; i < 3; ++i)
     if (idx->ev[i]) hipEventDestroy(idx->ev[i]);
+  for (int i = 0; i < walt_index::kDetailEvents; ++i)
+    if (idx->ev_detail[i]) hipEventDestroy(idx->ev_detail[i]);
   for (int k = 0; k < 2; ++k) {
     if (idx->pe_fork[k]) hipEventDestroy(idx->pe_fork[k]);
     if (idx->pe_join[k]) hipEventDestroy(idx->pe_join[k]);

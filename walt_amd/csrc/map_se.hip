@@ -973,7 +973,7 @@ static void debug_sync(const char* what, hipStream_t stream) {
 }
 
 template <int NW>
-static int launch_map_se(const walt_index* idx, const IndexView& view, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
+static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
                          uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
                          uint32_t* heavy_area, hipStream_t stream) {
@@ -1000,6 +1000,16 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
   const char* sm = getenv("WALT_AMD_STAMPS");
   const int stamp_mode = sm ? atoi(sm) : 0;
   const bool diag1 = diag && stamp_mode != 2, diag2 = diag && stamp_mode != 3;
+  // walt_profile_detail: an event after every kernel group (profiling on: bench.py)
+  idx->n_detail = 0;
+  auto mark = [&](unsigned char kind) {
+    if (!idx->profile || idx->n_detail >= walt_index::kDetailEvents) return;
+    hipEvent_t& e = idx->ev_detail[idx->n_detail];
+    if (!e && hipEventCreate(&e) != hipSuccess) return;
+    if (hipEventRecord(e, stream) != hipSuccess) return;
+    idx->ev_kind[idx->n_detail++] = kind;
+  };
+  mark(255);  // start
   if (diag1)
     hipLaunchKernelGGL((k_map_se<NW, true, false>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
@@ -1009,6 +1019,7 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                        heavy_list, 0u, nullptr);
   debug_sync("pass 1", stream);
+  mark(0);
   // WALT_AMD_HEAVY=mono: the one-kernel heavy pass (large regions verified by the whole wavefront of their read's
   // lane) instead of the staged one (large regions streamed by k_se_verify); same results, kept for comparison
   const char* heavy_mode = getenv("WALT_AMD_HEAVY");
@@ -1061,15 +1072,18 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
           hipLaunchKernelGGL((k_map_se<NW, false, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                              heavy_list, 0u, nullptr, hs);
+        mark(1);
         if (stage == 3) break;
         if constexpr (NW <= 10) {
           hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
         }
         hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
+        mark(2);
       }
     }
   }
   debug_sync("heavy pass", stream);
+  mark(1);  // (the one-kernel heavy pass, when that is what ran)
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
@@ -1078,6 +1092,7 @@ static int launch_map_se(const walt_index* idx, const IndexView& view, const uin
   hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                      strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_sorted, 0u);
   debug_sync("literal pass", stream);
+  mark(3);
   return WALT_OK;
 #endif
 }
@@ -1189,6 +1204,18 @@ int walt_profile_stamps(unsigned long long* out16) {
   WALT_HIP(hipDeviceSynchronize());
   WALT_HIP(hipMemcpy(out16, g_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   WALT_HIP(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
+  return WALT_OK;
+}
+
+int walt_profile_detail(walt_index* idx, float* out4) {
+  if (!idx || !out4 || !idx->profile || !idx->ev_valid) return fail(WALT_EINVAL, "no profiled call recorded");
+  WALT_HIP(hipEventSynchronize(idx->ev[2]));
+  for (int k = 0; k < 4; ++k) out4[k] = 0.f;
+  for (int i = 1; i < idx->n_detail; ++i) {
+    float ms = 0.f;
+    WALT_HIP(hipEventElapsedTime(&ms, idx->ev_detail[i - 1], idx->ev_detail[i]));
+    if (idx->ev_kind[i] < 4) out4[idx->ev_kind[i]] += ms;
+  }
   return WALT_OK;
 }
 
