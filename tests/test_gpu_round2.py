@@ -161,6 +161,23 @@ def test_gpu_staged_paths_and_their_fallbacks_vs_oracle(wa, repeat_case, mode, m
     idx.close()
 
 
+def test_gpu_profile_detail_accounts_for_the_mapping_time(wa, repeat_case):
+    """walt_profile_detail (bench.py's roofline.by_kernel): the four kernel groups of a single-end call, timed by
+    events between them, add up to what walt_profile_last reports for the mapping kernels."""
+    seqs, db = repeat_case
+    idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_CT, dir_bits=-1)
+    idx.profile_enable(True)
+    reads = _reads(random.Random(3), seqs, 4000, "CT", [100])
+    idx.map_se_batch(*wa.pack_reads(reads), max_mismatches=6, b=5000)
+    pack_ms, map_ms = idx.profile_last()
+    detail = idx.profile_detail()
+    assert len(detail) == 4 and all(x >= 0 for x in detail)
+    assert detail[0] > 0 and detail[1] > 0 and detail[2] > 0  # pass 1, heavy stages, verifier all ran on this genome
+    assert 0.5 * map_ms <= sum(detail) <= 1.05 * map_ms + 0.05, (detail, map_ms)
+    idx.profile_enable(False)
+    idx.close()
+
+
 def test_gpu_device_api_refuses_reads_beyond_max_read_len(wa, g1_index_path, g1_db):
     """with max_read_len = 100 the 7-word kernels would take a 112-base read silently and the 2-bit
     conversion would run past the workspace.  Now such reads are refused in the kernels (record left as
