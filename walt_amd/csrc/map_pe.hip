@@ -659,7 +659,7 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
 }
 
 template <int NW, bool LITERAL>
-__global__ __launch_bounds__(kBlock, (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1))) void k_pe_stage(
+__global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_pe_stage(
     IndexView iv, const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
     uint32_t strand_base, uint32_t max_mm, uint32_t b, const uint32_t* __restrict__ mask_table,
     unsigned long long* __restrict__ stats, const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ list,
