@@ -901,7 +901,7 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
 
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
 template <int NW, bool LITERAL = true>
-__global__ __launch_bounds__(kBlock) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
+__global__ __launch_bounds__(kBlock, NW <= 8 ? 5 : 1) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
                                                             const uint64_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ err, uint32_t strand_base,
                                                             uint32_t max_mm,
@@ -962,7 +962,7 @@ static uint64_t se_heavy_bytes(uint32_t n, int nw) {
 // bit 2 skips the lookup.  Used to attribute HBM requests to the phases.
 static uint32_t g_ablate = 0;
 static unsigned long long* g_stamps = nullptr;  // WALT_AMD_STAMPS=1: device buffer of kStampPhases sums (diagnostic)
-constexpr unsigned kLiteralGrid = 1024;  // blocks of the deferred-read pass (grid-stride)
+constexpr unsigned kLiteralGrid = 2048;  // blocks of the deferred-read pass (grid-stride)
 
 // WALT_AMD_SYNC_DEBUG=1 (diagnostic): wait after every launch of the single-end path and say which one returned
 static void debug_sync(const char* what, hipStream_t stream) {
