@@ -41,6 +41,34 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 
 
+def csrc_sha():
+    """Content hash of the kernel sources (walt_amd/csrc, include/): profiles/traffic.json carries the hash of the
+    sources its PMC counters were collected on, and roofline.traffic is dropped when the kernels have changed since
+    (.git does not travel to the GPU box, so the files themselves are hashed)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "walt_amd", "csrc")
+    files = []
+    for d, _, fs in os.walk(base):
+        files += [os.path.join(d, f) for f in fs if f.endswith((".h", ".hip", ".cpp")) or f == "Makefile"]
+    files.append(os.path.join(ROOT, "include", "walt_amd.h"))
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_entry(key):
+    """profiles/traffic.json[key] when it was measured on the kernels as they are now, else None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except (OSError, ValueError):
+        return None
+    if not t or t.get("csrc_sha") != csrc_sha():
+        return None
+    return t
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench] " + msg, file=sys.stderr, flush=True)
@@ -70,10 +98,16 @@ def parse_args(argv):
     ap.add_argument("--frag-range", type=int, default=1000)
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_lines legs (configs[2], configs[4])")
     ap.add_argument("--extra-pairs", type=int, default=0, help="pairs of the extra paired-end legs (default: --reads, 150 bp: half)")
-    ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--extra-steps", type=int, default=10)
     ap.add_argument("--ref-sample", type=int, default=2_000_000,
                     help="reads the real reference binary (oracle/_ref/walt) maps beside the oracle port at N=1 "
                          "(0 = skip; needs ~35 GB of RAM-backed scratch for the index copy)")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000,
+                    help="reads of the end-to-end leg (walt_amd/bin/walt FASTQ -> SAM on RAM-backed scratch, N = 1; 0 = skip)")
+    ap.add_argument("--e2e-batch", type=int, default=10_000_000, help="-N of the end-to-end leg")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip cpu_baseline.calibration (configs[0]: reference binary vs oracle port at -t 1 / -t N on a chr2-length genome)")
+    ap.add_argument("--calibrate", action="store_true", help="run ONLY the configs[0] calibration leg and print its JSON")
     ap.add_argument("--slot-table", action="store_true",
                     help="build the opt-in direct-mapped slot table (WALT_AMD_TABLE=1: +51.5 GB per strand at hg19 scale)")
     ap.add_argument("--seed-offset", type=int, default=0,
@@ -257,19 +291,16 @@ def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, tr
     lines = (1.0 if table else 2.0) * P + (C - C_big)
     bytes_per_read = 128.0 * lines + 12.0 * (C - C_big) + rec_bytes * C_big + read_len / 4.0 + 16
     useful = read_len / 4.0 + 16 + P * (8 + 12) + C * (12 + read_len / 4.0 + 8)
-    kern_s = float(np.median(leg["map_ms"])) / 1e3
+    # N > 1: the slowest rank's kernel time (MAX over ranks of the per-rank median), so that `frac` is what every GPU
+    # of the job at least reaches; counters and sample are rank 0's (every rank draws its reads from the same model)
+    kern_s = float(leg.get("kern_ms_ranks_max") or np.median(leg["map_ms"])) / 1e3
     achieved = bytes_per_read * n / kern_s
     survey = read_len + 16 + 8 * P + S * 4.25 + C * (4 + read_len / 4.0)
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):
-        try:
-            t = json.load(open(tj)).get(traffic_key)
-            if t and t.get("reads_per_launch") == n and t.get("genome") == args.genome and not args.contigs and not table \
-                    and args.pattern == 3 and t.get("genome_bp") == cx.genome_bp:
-                traffic = t["hbm_bytes_per_launch"]
-        except (ValueError, KeyError, AttributeError):
-            pass
+    t = traffic_entry(traffic_key)
+    if t and t.get("reads_per_launch") == n and t.get("genome") == args.genome and not args.contigs and not table \
+            and args.pattern == 3 and t.get("genome_bp") == cx.genome_bp:
+        traffic = t.get("hbm_bytes_per_launch")
     # the kernel groups of the call, timed by HIP events between them (walt_profile_detail); the region verifier's
     # algorithmic bytes are its dense records alone, so it has a roofline of its own
     dms = leg.get("detail_ms") or [0.0, 0.0, 0.0, 0.0]
@@ -297,7 +328,88 @@ def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, tr
     return cpu, roof
 
 
-def reference_binary_leg(cx, idx, d_bases, d_out, read_len, n_ref, max_mm, b, cores):
+def write_fastq(path, host_bases, n, read_len):
+    """@r<9 digits>\\n<seq>\\n+\\n<qual>\\n per read, built with numpy (no per-read Python)."""
+    import numpy as np
+    rec = np.dtype([("at", "S2"), ("num", "S9"), ("nl0", "S1"), ("seq", "S%d" % read_len), ("mid", "S3"),
+                    ("qual", "S%d" % read_len), ("nl1", "S1")])
+    with open(path, "wb") as f:
+        for s0 in range(0, n, 1 << 20):
+            m = min(1 << 20, n - s0)
+            a = np.zeros(m, dtype=rec)
+            a["at"], a["nl0"], a["mid"], a["nl1"] = b"@r", b"\n", b"\n+\n", b"\n"
+            a["num"] = np.char.zfill(np.arange(s0, s0 + m).astype("S9"), 9)
+            a["seq"] = host_bases[s0 * read_len:(s0 + m) * read_len].view("S%d" % read_len)
+            a["qual"] = b"I" * read_len
+            f.write(a.tobytes())
+
+
+def read_mapstats(path):
+    stats = {}
+    for ln in open(path):
+        k, _, v = ln.strip().partition(":")
+        if v.strip().lstrip("-").replace(".", "", 1).isdigit():
+            stats[k.strip()] = v.strip()
+    return stats
+
+
+def e2e_leg(cx, scratch, dbi, host_bases, times_host, read_len, n_e2e, max_mm, b, cores, batch):
+    """End to end through the product's own command line, index files and reads on RAM-backed scratch:
+    walt_amd/bin/walt -i <dbindex> -r <fastq> -o <sam> -sam -a -u (FASTQ parse -> N draws -> upload -> kernels -> SAM
+    formatting -> write), several -N batches.  The bench's own index has been closed by now (the GPU is the binary's).
+    reads/s is quoted with the one-time index load excluded (the reference reloads its index per batch,
+    mapping.cpp:491-492) and, beside it, on the whole wall clock; the stage times are the binary's own (-v)."""
+    import re
+    import subprocess
+
+    import numpy as np
+    our_bin = os.path.join(ROOT, "walt_amd", "bin", "walt")
+    if not os.path.exists(our_bin):
+        return {"skipped": "walt_amd/bin/walt is not built"}
+    fq = os.path.join(scratch, "e2e.fastq")
+    t0 = time.perf_counter()
+    write_fastq(fq, host_bases, n_e2e, read_len)
+    t_fq = time.perf_counter() - t0
+    out = os.path.join(scratch, "e2e.sam")
+    cmd = [our_bin, "-i", dbi, "-r", fq, "-o", out, "-m", str(max_mm), "-b", str(b), "-a", "-u", "-sam", "-t", str(cores),
+           "-N", str(batch), "-v"]
+    t0 = time.perf_counter()
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    wall = time.perf_counter() - t0
+    if pr.returncode != 0:
+        return {"skipped": "bin/walt failed: " + pr.stdout[-300:]}
+    stages = {}
+    for ln in pr.stdout.splitlines():
+        if ln.startswith("[walt_amd:"):
+            for key, pat in (("index_s", r"index ([0-9.]+) s"), ("ingest_not_hidden_s", r"previous batch ([0-9.]+) s"),
+                             ("map_s", r"map ([0-9.]+) s"), ("format_s", r"format ([0-9.]+) s"), ("write_s", r"write ([0-9.]+) s")):
+                mt = re.search(pat, ln)
+                if mt:
+                    stages[key] = float(mt.group(1))
+    st = read_mapstats(out + ".mapstats")
+    t = times_host[:n_e2e]
+    mine = {"unique": int((t == 1).sum()), "ambiguous": int((t >= 2).sum()), "unmapped": int((t == 0).sum())}
+    key_of = {"unique": "unique_mapped_reads", "ambiguous": "ambiguous_mapped_reads", "unmapped": "unmapped_reads"}
+    same = all(int(st.get(key_of[k], st.get(k, -1))) == v for k, v in mine.items())
+    sam_bytes = os.path.getsize(out)
+    resident = wall - stages.get("index_s", 0.0)
+    line = {"metric": "reads/s end to end, FASTQ -> SAM through walt_amd/bin/walt (%d bp single-end, -m %d -b %d -a -u -sam), "
+                      "index load excluded" % (read_len, max_mm, b),
+            "value": n_e2e / resident, "unit": "reads/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "the first %d reads of the headline batch as a FASTQ file (%.1f GB) and the headline index as "
+                                   ".dbindex files, both on RAM-backed scratch; -N %d (%d batches), -t %d host threads" % (
+                                       n_e2e, os.path.getsize(fq) / 1e9, batch, (n_e2e + batch - 1) // batch, cores)},
+            "wall_s": wall, "reads_per_s_whole_wall": n_e2e / wall, "stages_s": stages, "sam_bytes": sam_bytes,
+            "fastq_write_s": t_fq, "mapstats_equal_gpu_records": bool(same), "host_threads": cores}
+    for f in (fq, out):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return line
+
+
+def reference_binary_leg(cx, idx, d_bases, d_out, read_len, n_ref, max_mm, b, cores, keep=None, extra_bytes=0):
     """The REAL reference binary (oracle/_ref/walt, built from the reference sources by oracle/Makefile.ref;
     test infrastructure) on the same box in the same run: the resident index is written in the reference's
     .dbindex format to a RAM-backed scratch directory, the first n_ref reads of the batch go to a FASTQ file,
@@ -311,7 +423,7 @@ def reference_binary_leg(cx, idx, d_bases, d_out, read_len, n_ref, max_mm, b, co
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "walt")
     if not os.path.exists(ref_bin):
         return {"skipped": "oracle/_ref/walt is not built"}
-    need = 2 * (idx.genome_len + 4 * (idx.index_size(0) + (1 << 24) + 8)) + n_ref * (2 * read_len + 20) * 2
+    need = 2 * (idx.genome_len + 4 * (idx.index_size(0) + (1 << 24) + 8)) + n_ref * (2 * read_len + 20) * 2 + extra_bytes
     base = None
     for cand in (os.environ.get("WALT_AMD_SCRATCH"), "/dev/shm", "/tmp"):
         if cand and os.path.isdir(cand) and shutil.disk_usage(cand).free > 1.3 * need:
@@ -334,17 +446,7 @@ def reference_binary_leg(cx, idx, d_bases, d_out, read_len, n_ref, max_mm, b, co
         t_write = time.perf_counter() - t0
         host = d_bases[:n_ref * read_len].cpu().numpy()
         fq = os.path.join(scratch, "sample.fastq")
-        rec = np.dtype([("at", "S2"), ("num", "S9"), ("nl0", "S1"), ("seq", "S%d" % read_len), ("mid", "S3"),
-                        ("qual", "S%d" % read_len), ("nl1", "S1")])
-        with open(fq, "wb") as f:
-            for s0 in range(0, n_ref, 1 << 20):
-                m = min(1 << 20, n_ref - s0)
-                a = np.zeros(m, dtype=rec)
-                a["at"], a["nl0"], a["mid"], a["nl1"] = b"@r", b"\n", b"\n+\n", b"\n"
-                a["num"] = np.char.zfill(np.arange(s0, s0 + m).astype("S9"), 9)
-                a["seq"] = host[s0 * read_len:(s0 + m) * read_len].view("S%d" % read_len)
-                a["qual"] = b"I" * read_len
-                f.write(a.tobytes())
+        write_fastq(fq, host, n_ref, read_len)
         out = os.path.join(scratch, "ref.mr")
         cmd = [ref_bin, "-i", dbi, "-r", fq, "-o", out, "-m", str(max_mm), "-b", str(b), "-t", str(cores)]
         t0 = time.perf_counter()
@@ -352,15 +454,16 @@ def reference_binary_leg(cx, idx, d_bases, d_out, read_len, n_ref, max_mm, b, co
         wall = time.perf_counter() - t0
         if pr.returncode != 0:
             return {"skipped": "reference binary failed: " + pr.stdout[-300:]}
-        stats = {}
-        for ln in open(out + ".mapstats"):
-            k, _, v = ln.strip().partition(":")
-            if v.strip().lstrip("-").replace(".", "", 1).isdigit():
-                stats[k.strip()] = v.strip()
+        stats = read_mapstats(out + ".mapstats")
+        for f in (fq, out):
+            os.remove(f)
         times = d_out[:n_ref * 16].view(torch.int32).view(n_ref, 4)[:, 1]
         mine = {"unique": int((times == 1).sum().item()), "ambiguous": int((times >= 2).sum().item()),
                 "unmapped": int((times == 0).sum().item())}
-        same = all(int(stats.get(k, -1)) == v for k, v in mine.items())
+        key_of = {"unique": "unique_mapped_reads", "ambiguous": "ambiguous_mapped_reads", "unmapped": "unmapped_reads"}
+        same = all(int(stats.get(key_of[k], stats.get(k, -1))) == v for k, v in mine.items())
+        if keep is not None:
+            keep["scratch"], keep["dbi"] = scratch, dbi
         return {"value": n_ref / wall, "unit": "reads/s", "cores": cores, "kind": "reference",
                 "sample": "oracle/_ref/walt -t %d on the first %d reads of the batch, wall clock of the whole run "
                           "including its read of both strand index files (%.0f GB, RAM-backed) -- the reference "
@@ -368,6 +471,116 @@ def reference_binary_leg(cx, idx, d_bases, d_out, read_len, n_ref, max_mm, b, co
                               cores, n_ref, 2 * (idx.genome_len + 4 * (idx.index_size(0) + (1 << 24) + 8)) / 1e9),
                 "wall_s": wall, "index_write_s": t_write, "mapstats_equal_gpu": bool(same)}
     finally:
+        if keep is None or "scratch" not in keep:
+            shutil.rmtree(scratch, ignore_errors=True)
+
+
+def calibration_leg(cx, local, cores, n=100_000, read_len=100, max_mm=6, b=5000):
+    """BASELINE configs[0]: a chr2-length genome (243,199,373 bp, one sequence; the hg19-like
+    families scaled to it), 100,000 x 100 bp single-end C->T reads, -m 6 -- the REAL reference binary (oracle/_ref/walt,
+    test infrastructure) at -t 1 and -t <cores> beside the oracle port at the same thread counts, on this box in this run.
+    What it pins: (i) the three SAM texts are the same bytes -- reference -t 1, reference -t N, and the port's records
+    through the restated writer (tests/refio.py) -- and the GPU's records equal the port's; (ii) the port is not slower
+    than real WALT, as a number: reads/s of the mapping work alone, which for the binary is its wall clock minus the wall
+    clock of the same command on ONE read (index read, start-up and allocation: the reference reloads its index per
+    batch, mapping.cpp:491-492), for the port the two strand passes over indexes already in memory."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    import refio
+    import synth
+    torch, walt_amd = cx.torch, cx.walt_amd
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "walt")
+    if not os.path.exists(ref_bin):
+        return {"skipped": "oracle/_ref/walt is not built"}
+    dev = cx.dev
+    genome_ascii, lens, names = synth.make_genome(torch, dev, 1.0, seed=2, kind="chr2like")
+    idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local, strands=walt_amd.STRANDS_CT)
+    d_bases, d_off = synth.make_reads(torch, dev, genome_ascii, n, read_len, seed=7000, lowq=False)
+    del genome_ascii
+    torch.cuda.synchronize()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    scratch = tempfile.mkdtemp(prefix="walt_amd_calib_", dir=base)
+    try:
+        # the GPU's records for the same reads, through the C ABI
+        d_out = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        d_ws = torch.empty(walt_amd.lib().walt_se_workspace_bytes(n, read_len), dtype=torch.uint8, device=dev)
+        idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, read_len, d_out.data_ptr(), d_stats.data_ptr(),
+                                d_ws.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, ag_wildcard=False,
+                                max_mismatches=max_mm, b=b)
+        torch.cuda.synchronize()
+        gpu = d_out.cpu().numpy().view(walt_amd.best_match_dtype).reshape(-1)
+        host = d_bases.cpu().numpy()
+        dbi = os.path.join(scratch, "chr2.dbindex")
+        idx.write(dbi)
+        for sfx in ("_GA10", "_GA11"):  # the binary only checks that all four strand files exist
+            open(dbi + sfx, "wb").close()
+        fq, fq1 = os.path.join(scratch, "reads.fastq"), os.path.join(scratch, "one.fastq")
+        write_fastq(fq, host, n, read_len)
+        write_fastq(fq1, host, 1, read_len)
+        ref = {}
+        sams = {}
+        for t in sorted({1, cores}):
+            walls = []
+            for f, tag in ((fq, "full"), (fq1, "one")):
+                o = os.path.join(scratch, "ref_%s_t%d.sam" % (tag, t))
+                cmd = [ref_bin, "-i", dbi, "-r", f, "-o", o, "-m", str(max_mm), "-b", str(b), "-a", "-u", "-sam", "-t", str(t)]
+                t0 = time.perf_counter()
+                pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                walls.append(time.perf_counter() - t0)
+                if pr.returncode != 0:
+                    return {"skipped": "reference binary failed: " + pr.stdout[-300:]}
+            sams[t] = open(os.path.join(scratch, "ref_full_t%d.sam" % t), "rb").read()
+            ref[t] = {"wall_s": walls[0], "wall_one_read_s": walls[1],
+                      "reads_per_s": n / max(1e-9, walls[0] - walls[1])}
+        # the port: both strand passes with the index in memory, at the same thread counts
+        orc = refio.oracle()
+        start = np.zeros(len(lens) + 1, dtype=np.uint32)
+        start[1:] = np.cumsum(lens, dtype=np.uint64).astype(np.uint32)
+        strands = [idx.export_strand(k) for k in (0, 1)]
+        xs = [refio.make_orc_strand(g, cnt, ix, start) for g, cnt, ix in strands]
+        offs = np.arange(n + 1, dtype=np.uint64) * read_len
+        port = {}
+        rec = None
+        for t in sorted({1, cores}):
+            rec = np.zeros(n, dtype=refio.best_dtype)
+            orc.orc_se_init(rec.ctypes.data, n, max_mm)
+            work = np.zeros(1, dtype=refio.work_dtype)
+            t0 = time.perf_counter()
+            for k, ch in ((0, b"+"), (1, b"-")):
+                orc.orc_se_map_strand_trace(ctypes.addressof(xs[k]), ch, host.ctypes.data, offs.ctypes.data, n, 0, b, t,
+                                            rec.ctypes.data, work.ctypes.data, None)  # no per-read trace: the plain port
+            dt = time.perf_counter() - t0
+            port[t] = {"map_s": dt, "reads_per_s": n / dt}
+        same_gpu = all(np.array_equal(gpu[f], rec[f]) for f in ("genome_pos", "times", "strand", "mismatch"))
+
+        class Db:  # what refio's writers read
+            pass
+        db = Db()
+        db.names, db.lengths, db.start_index, db.n_chrom = list(names), np.array(lens, dtype=np.uint32), start, len(lens)
+        db.chrom_of = lambda pos: int(np.searchsorted(start, pos, side="right") - 1) if len(lens) > 1 else 0
+        seqs = host.view("S%d" % read_len)
+        qual = "I" * read_len
+        out = [refio.sam_header(db)]
+        for i in range(n):
+            out.append(refio.se_sam_line(db, rec[i], "r%09d" % i, seqs[i].decode(), qual, True, True))
+        port_sam = "".join(out).encode()
+        t_lo, t_hi = min(ref), max(ref)
+        return {"workload": "configs[0]: chr2-length synthetic genome (%d bp, 1 sequence), %d x %d bp single-end C->T reads, "
+                            "-m %d -b %d -a -u -sam" % (sum(lens), n, read_len, max_mm, b),
+                "reference_binary": {"t%d" % t: ref[t] for t in ref}, "port": {"t%d" % t: port[t] for t in port},
+                "port_over_reference": {"t%d" % t: port[t]["reads_per_s"] / ref[t]["reads_per_s"] for t in ref},
+                "sam_reference_t%d_equals_t%d" % (t_lo, t_hi): bool(sams[t_lo] == sams[t_hi]),
+                "sam_port_equals_reference": bool(port_sam == sams[t_lo]), "sam_bytes": len(sams[t_lo]),
+                "gpu_records_equal_port": bool(same_gpu),
+                "unique_frac": float((rec["times"] == 1).mean()),
+                "note": "reads/s of the mapping work alone: the binary's wall clock minus the same command on one read "
+                        "(index read, start-up); the port maps with both strand indexes already in memory"}
+    finally:
+        idx.close()
         shutil.rmtree(scratch, ignore_errors=True)
 
 
@@ -408,7 +621,10 @@ def pe_leg(cx, idx, d1, d2, d_off, n, read_len, max_mm, b, top_k, frag_range, st
 
 
 def oracle_pe_jobs(cx, idx, jobs, lens):
-    """job: dict(m1, m2 numpy bases, m, read_len, max_mm, b, top_k, frag_range, swap) -> out (pair records), cpu_s, works.
+    """job: dict(m1, m2 numpy bases, m, nu, read_len, max_mm, b, top_k, frag_range) -> out (pair records), cpu_s, works.
+    The first `nu` pairs of a job are its UNIFORM sample: only they are timed (cpu_s) and counted (works: probes,
+    candidates, candidates in regions of more than 16 slots) -- the hard classes behind them are mapped for the
+    exactness check alone (they are the candidate-rich pairs; timing or counting them would bias both figures).
     The two strand indexes of one mate are in host memory at a time; both exports serve every job."""
     import numpy as np
     import refio
@@ -428,29 +644,41 @@ def oracle_pe_jobs(cx, idx, jobs, lens):
             for f, _ in refio.OrcStrand._fields_:
                 setattr(arr[k], f, getattr(x, f))
         for j in jobs:
-            m, L, top_k = j["m"], j["read_len"], j["top_k"]
+            m, L, top_k, nu = j["m"], j["read_len"], j["top_k"], min(j["nu"], j["m"])
             offs = np.arange(m + 1, dtype=np.uint64) * L
             r = np.zeros((m, top_k), dtype=refio.cand_dtype)
             c = np.zeros(m, dtype=np.uint32)
-            work = np.zeros(1, dtype=refio.work_dtype)
             bases = np.ascontiguousarray(j["m1"] if mate == 0 else j["m2"])
-            t0 = time.perf_counter()
-            orc.orc_pe_topk_batch(ctypes.addressof(arr), bases.ctypes.data, offs.ctypes.data, m, mate, j["max_mm"], j["b"],
-                                  top_k, cores, r.ctypes.data, c.ctypes.data, work.ctypes.data)
-            j["cpu_s"] += time.perf_counter() - t0
+            for lo, hi, timed in ((0, nu, True), (nu, m, False)):
+                if hi <= lo:
+                    continue
+                work = np.zeros(1, dtype=refio.work_dtype)
+                t0 = time.perf_counter()
+                orc.orc_pe_topk_batch(ctypes.addressof(arr), bases.ctypes.data + lo * L, offs[:hi - lo + 1].ctypes.data,
+                                      hi - lo, mate, j["max_mm"], j["b"], top_k, cores,
+                                      r.ctypes.data + lo * top_k * r.dtype.itemsize, c.ctypes.data + lo * 4, work.ctypes.data)
+                if timed:
+                    j["cpu_s"] += time.perf_counter() - t0
+                    j["works"].append((float(work[0]["probes"]), float(work[0]["cands"]), float(work[0]["cands_big"])))
             j["ranked"].append(r)
             j["counts"].append(c)
-            j["works"].append((float(work[0]["probes"]), float(work[0]["cands"]), float(work[0]["cands_big"])))
         del keep, arr
     for j in jobs:
-        m, L = j["m"], j["read_len"]
+        m, L, nu, top_k = j["m"], j["read_len"], min(j["nu"], j["m"]), j["top_k"]
         offs = np.arange(m + 1, dtype=np.uint64) * L
         out = np.zeros(m, dtype=refio.pair_dtype)
-        t0 = time.perf_counter()
-        orc.orc_pe_merge_batch(j["ranked"][0].ctypes.data, j["counts"][0].ctypes.data, j["ranked"][1].ctypes.data,
-                               j["counts"][1].ctypes.data, j["top_k"], offs.ctypes.data, offs.ctypes.data, m,
-                               start.ctypes.data, len(lens), j["frag_range"], j["max_mm"], out.ctypes.data)
-        j["cpu_s"] += time.perf_counter() - t0
+        r0, r1, c0, c1 = j["ranked"][0], j["ranked"][1], j["counts"][0], j["counts"][1]
+        for lo, hi, timed in ((0, nu, True), (nu, m, False)):
+            if hi <= lo:
+                continue
+            t0 = time.perf_counter()
+            orc.orc_pe_merge_batch(r0.ctypes.data + lo * top_k * r0.dtype.itemsize, c0.ctypes.data + lo * 4,
+                                   r1.ctypes.data + lo * top_k * r1.dtype.itemsize, c1.ctypes.data + lo * 4, top_k,
+                                   offs[:hi - lo + 1].ctypes.data, offs[:hi - lo + 1].ctypes.data, hi - lo,
+                                   start.ctypes.data, len(lens), j["frag_range"], j["max_mm"],
+                                   out.ctypes.data + lo * out.dtype.itemsize)
+            if timed:
+                j["cpu_s"] += time.perf_counter() - t0
         j["out"] = out
 
 
@@ -477,31 +705,30 @@ def pe_report(cx, args, leg, job, n, read_len, sel_all, nu, traffic_key):
     for m in ("m1", "m2"):
         same = same and all(np.array_equal(got[m][f], want[m][f]) for f in ("genome_pos", "times", "strand", "mismatch"))
     m_all = job["m"]
-    cpu = {"value": m_all / job["cpu_s"], "unit": "pairs/s", "cores": job["cores"], "kind": "port",
-           "sample": "%d pairs sampled uniformly over the batch + %d from the hard classes (ambiguous / unpaired), oracle "
-                     "restatement of PairEndMapping on both mates and strands + pair merge, OpenMP; two strand indexes in "
-                     "host memory at a time" % (nu, m_all - nu),
+    nu = min(nu, m_all)
+    cpu = {"value": nu / job["cpu_s"], "unit": "pairs/s", "cores": job["cores"], "kind": "port",
+           "sample": "%d pairs sampled uniformly (stride) over rank 0's batch: oracle restatement of PairEndMapping on both "
+                     "mates and strands + pair merge, OpenMP, two strand indexes in host memory at a time.  %d more pairs from "
+                     "the hard classes (ambiguous / unpaired) are mapped for the exactness check only -- neither timed nor "
+                     "counted" % (nu, m_all - nu),
            "bit_exact_vs_gpu": bool(same)}
     # Same accounting as the single-end line: per pair, P probes and C candidates over both mates (oracle
-    # counters) -> 2 P dependent gathers of one 128-byte line each; a candidate of a region of more than 16 slots
-    # streams as a dense record (32 bytes, 48 above 110 bases), any other costs a 12-byte entry and a scattered
-    # 128-byte line; plus per mate the ranked list written by the top-k kernel and read back by the merge (one
-    # line each way), the packed reads and the 64-byte pair record.  Time = the whole step (the mates' kernels
+    # counters on the UNIFORM sample) -> 2 P dependent gathers of one 128-byte line each; a candidate of a region of
+    # more than 16 slots streams as a dense record (32 bytes, 48 above 110 bases), any other costs a 12-byte entry and
+    # a scattered 128-byte line; plus per mate the ranked list written by the top-k kernel and read back by the merge
+    # (one line each way), the packed reads and the 64-byte pair record.  Time = the whole step (the mates' kernels
     # overlap on several streams).
-    P = sum(w[0] for w in job["works"]) / m_all
-    C = sum(w[1] for w in job["works"]) / m_all
-    C_big = sum(w[2] for w in job["works"]) / m_all if (os.environ.get("WALT_AMD_WIN", "1") != "0" and read_len <= 174) else 0.0
+    P = sum(w[0] for w in job["works"]) / nu
+    C = sum(w[1] for w in job["works"]) / nu
+    C_big = sum(w[2] for w in job["works"]) / nu if (os.environ.get("WALT_AMD_WIN", "1") != "0" and read_len <= 174) else 0.0
     rec_bytes = 32.0 if read_len <= 110 else 48.0
     bytes_per_pair = 128.0 * (2.0 * P + (C - C_big) + 4.0) + 12.0 * (C - C_big) + rec_bytes * C_big + 2 * read_len / 4.0 + 64
-    step_s = float(np.median(leg["per_step"]))
+    step_s = float(leg.get("step_s_ranks_max") or np.median(leg["per_step"]))  # N > 1: the slowest rank's
     traffic = None
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(traffic_key)
-        if t and t.get("pairs_per_step") == n and t.get("genome") == args.genome and t.get("genome_bp") == cx.genome_bp \
-                and args.pattern == 3 and not args.contigs:
-            traffic = t["hbm_bytes_per_step"]
-    except (OSError, ValueError, KeyError, AttributeError):
-        pass
+    t = traffic_entry(traffic_key)
+    if t and t.get("pairs_per_step") == n and t.get("genome") == args.genome and t.get("genome_bp") == cx.genome_bp \
+            and args.pattern == 3 and not args.contigs:
+        traffic = t.get("hbm_bytes_per_step")
     roof = {"bound": "hbm", "achieved": bytes_per_pair * n / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": traffic,
             "traffic_frac": (traffic / step_s / HBM_PEAK) if traffic else None,
@@ -575,13 +802,21 @@ def worker(args):
 
     cx = Ctx()
     cx.torch, cx.walt_amd, cx.dev, cx.pattern = torch, walt_amd, dev, args.pattern
+    if args.calibrate:
+        import refio
+        refio.set_pattern(args.pattern)
+        print(json.dumps({"calibration": calibration_leg(cx, local, walt_amd.effective_cpus())}), flush=True)
+        return
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
     cx.barrier = barrier
-    run_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline  # the CPU legs run at N=1 only
+    # the oracle legs (cpu_baseline, exactness, the counters of the roofline) run on rank 0, on its own shard, at every
+    # N: a line without them is unmeasured.  One strand export at a time is ~15 GB of host memory.  The other ranks
+    # wait at the final barrier.
+    run_cpu = rank == 0 and not args.no_cpu_baseline
     if run_cpu:
         import refio
         refio.set_pattern(args.pattern)
@@ -620,6 +855,7 @@ def worker(args):
         leg = se_leg(cx, idx, d_bases, d_off, n, args.read_len, args.max_mismatches, args.bucket, args.ag, args.steps,
                      args.warmup)
         elapsed = wdist.allreduce_max(leg["elapsed"], device=dev if not shared_gpu else "cpu")  # MAX over ranks
+        leg["kern_ms_ranks_max"] = wdist.allreduce_max(float(np.median(leg["map_ms"])), device=dev if not shared_gpu else "cpu")
         # mapping statistics of the last step; the ONLY data-path collective is this final sum over ranks
         # (RCCL), mirroring StatSingleReads (mapping.hpp:94-100)
         times = leg["d_out"].view(torch.int32).view(n, 4)[:, 1]
@@ -631,13 +867,7 @@ def worker(args):
         total, uniq, amb, unm, short = [int(v) for v in st.tolist()]
         c_abi = None
         if world > 1 and not shared_gpu:  # the same sum through the C ABI (walt_stats_allreduce over RCCL)
-            try:
-                comm = wdist.c_abi_comm(local)
-                v2 = comm.stats_allreduce(vec_local)
-                comm.close()
-                c_abi = "equal" if [int(x) for x in v2.tolist()] == [total, uniq, amb, unm, short] else "DIFFERENT: %s" % v2.tolist()
-            except Exception as e:  # never let the cross-check break the line
-                c_abi = "failed: %s: %s" % (type(e).__name__, e)
+            c_abi = wdist.c_abi_cross_check(local, vec_local, [total, uniq, amb, unm, short])
         if os.environ.get("WALT_AMD_STAMPS"):
             buf = (ctypes.c_ulonglong * 16)()
             if walt_amd.lib().walt_profile_stamps(buf) == 0:
@@ -674,7 +904,8 @@ def worker(args):
                 "mapping": {"total": total, "unique": uniq, "ambiguous": amb, "unmapped": unm, "too_short": short,
                             "unique_frac": uniq / max(1, total)},
                 "kernel_ms": {"pack_reads": float(np.median(leg["pack_ms"])), "map_se": float(np.median(leg["map_ms"])),
-                              "map_se_min": float(np.min(leg["map_ms"])), "map_se_max": float(np.max(leg["map_ms"]))},
+                              "map_se_min": float(np.min(leg["map_ms"])), "map_se_max": float(np.max(leg["map_ms"])),
+                              "by_group": dict(zip(("pass1", "heavy_stages", "se_verify", "literal"), leg["detail_ms"]))},
                 "device_counters_per_read": {"probes": float(leg["stats"][1]) / n, "candidates": float(leg["stats"][2]) / n,
                                              "wave_cooperative_regions_per_step": int(leg["stats"][3]),
                                              "heavy_pass_reads": int(leg["n_heavy"]),
@@ -683,6 +914,7 @@ def worker(args):
             if c_abi:
                 out["stats_allreduce_c_abi"] = c_abi
         jobs = []
+        e2e_keep = {}
         if run_cpu:
             uni, hard = se_sample(cx, leg, n, args.cpu_sample, args.hard_sample)
             sel = torch.cat([uni, hard])
@@ -722,18 +954,40 @@ def worker(args):
                                       j["traffic_key"], j["kernel"])
                 j["target"]["roofline"] = roof
                 j["target"]["cpu_baseline"] = cpu
-            if args.ref_sample > 0 and args.pattern == 3 and not args.ag:
+            if args.ref_sample > 0 and args.pattern == 3 and not args.ag and world == 1:
                 # the real reference binary beside it (slower than the port: it also reads its index files)
+                n_e2e = min(args.e2e_reads, n) if (not args.no_extra and not args.contigs) else 0
                 try:
                     out["cpu_baseline"]["reference_binary"] = reference_binary_leg(
                         cx, idx, d_bases, leg["d_out"], args.read_len, min(args.ref_sample, n), args.max_mismatches,
-                        args.bucket, jobs[0]["cores"])
+                        args.bucket, jobs[0]["cores"], keep=e2e_keep if n_e2e else None,
+                        extra_bytes=n_e2e * (2 * args.read_len + 24 + 3 * args.read_len))
                 except Exception as e:  # never let the extra leg break the bench line
                     out["cpu_baseline"]["reference_binary"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
+                if "scratch" in e2e_keep:
+                    e2e_keep.update({"n": n_e2e, "bases": d_bases[:n_e2e * args.read_len].cpu().numpy(), "cores": jobs[0]["cores"],
+                                     "times": leg["d_out"].view(torch.int32).view(n, 4)[:n_e2e, 1].cpu().numpy()})
         j = None  # (the loop variable above still referred to the last job: its leg's workspace and result tensors)
+        win_cov = {"window_records": [int(idx.window_entries(s0)), int(idx.window_entries(s0 + 1))],
+                   "window_eligible": [int(idx.window_eligible(s0)), int(idx.window_eligible(s0 + 1))]}
+        if rank == 0 and out is not None:
+            # dense candidate windows: records that exist / index slots in runs that qualify for one (a memory budget
+            # that ends early truncates them: the verifier then gathers, same results, slower)
+            out["config"]["dense_window_coverage"] = dict(win_cov, fraction=[
+                (r / e if e else 1.0) for r, e in zip(win_cov["window_records"], win_cov["window_eligible"])])
         del jobs, leg, leg150, d_bases, d_off
         idx.close()
         torch.cuda.empty_cache()
+        if "scratch" in e2e_keep:  # the GPU is free now: the command-line binary opens its own index
+            import shutil
+            try:
+                extra.append(e2e_leg(cx, e2e_keep["scratch"], e2e_keep["dbi"], e2e_keep["bases"], e2e_keep["times"], args.read_len,
+                                     e2e_keep["n"], args.max_mismatches, args.bucket, e2e_keep["cores"], args.e2e_batch))
+            except Exception as e:
+                extra.append({"metric": "reads/s end to end", "skipped": "%s: %s" % (type(e).__name__, e)})
+            finally:
+                shutil.rmtree(e2e_keep["scratch"], ignore_errors=True)
+            e2e_keep.clear()
     # ---------------------------------------------------------------- paired-end legs (headline with --mode pe, else extra)
     pe_cfgs = []
     if args.mode == "pe":
@@ -767,6 +1021,8 @@ def worker(args):
             leg = pe_leg(cx, idx, d1, d2, d_off, npairs, rl, mm, args.bucket, args.top_k, args.frag_range, steps, warm,
                          timed_barrier=headline)
             elapsed = wdist.allreduce_max(leg["elapsed"], device=dev if not shared_gpu else "cpu") if headline else leg["elapsed"]
+            if headline:
+                leg["step_s_ranks_max"] = wdist.allreduce_max(float(np.median(leg["per_step"])), device=dev if not shared_gpu else "cpu")
             log("%s paired-end 2 x %d bp: %.1f ms/step; lists %s" % (tag, rl, 1e3 * elapsed / steps, leg["lists"]))
             log("  device counters per pair: probes %.2f, candidates verified %.1f, large regions %.3f" % (
                 (float(leg["stats"][1]) + float(leg["stats"][5])) / npairs, (float(leg["stats"][2]) + float(leg["stats"][6])) / npairs,
@@ -797,13 +1053,7 @@ def worker(args):
                                 "unique_frac": v[1] / max(1, v[0])},
                     "lists_last_pass": leg["lists"]}
             if headline and world > 1 and not shared_gpu:
-                try:
-                    comm = wdist.c_abi_comm(local)
-                    v2 = comm.stats_allreduce(vec_local)
-                    comm.close()
-                    line["stats_allreduce_c_abi"] = "equal" if [int(x) for x in v2.tolist()] == v else "DIFFERENT"
-                except Exception as e:
-                    line["stats_allreduce_c_abi"] = "failed: %s: %s" % (type(e).__name__, e)
+                line["stats_allreduce_c_abi"] = wdist.c_abi_cross_check(local, vec_local, v)
             if headline:
                 out = line if rank == 0 else None
             else:
@@ -856,6 +1106,14 @@ def worker(args):
                 j["target"]["roofline"] = roof
                 j["target"]["cpu_baseline"] = cpu
         idx.close()
+    if rank == 0 and world == 1 and run_cpu and not args.no_calibration and not args.no_extra and args.pattern == 3 \
+            and out is not None and "cpu_baseline" in out:
+        try:
+            del genome_ascii
+            torch.cuda.empty_cache()
+            out["cpu_baseline"]["calibration"] = calibration_leg(cx, local, walt_amd.effective_cpus())
+        except Exception as e:  # never let the extra leg break the bench line
+            out["cpu_baseline"]["calibration"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if extra:
             out["extra_lines"] = extra

@@ -70,11 +70,13 @@ typedef struct {
  * stat.num_of_short_reads++ at mapping.cpp:230-233 / paired.cpp:112-115). */
 typedef struct {
   uint64_t too_short;
-  /* Diagnostic work counters of the kernels, NOT the reference's: they include probes the kernels make
-   * speculatively (a superset of the reference's on the '-' strand, all probes of a staged paired-end read up to
-   * the exits it can prove), and a read that moves on to the literal pass after part of its work is counted in
-   * both places. */
-  uint64_t probes;     /* seed probes into non-empty buckets */
+  /* Diagnostic work counters of the kernels, NOT the reference's.  `probes` counts seed probes that found a
+   * NON-EMPTY REGION (at least one index slot whose care characters equal the seed's) -- fewer than the probes into
+   * non-empty buckets the reference's loop makes (mapping.cpp:268-274; bench.py's oracle counts those: ~4.0 per
+   * read on the benchmark genome against ~1.4 here), although the kernels issue MORE look-ups than the reference
+   * (a superset on the '-' strand; every probe of a staged paired-end read up to the exits it can prove).  A read
+   * that moves on to the literal pass after part of its work is counted in both places. */
+  uint64_t probes;     /* seed probes whose region is not empty */
   uint64_t candidates; /* candidates verified */
   uint64_t big_regions;/* regions handed to a wavefront (work items / cooperative verification) */
 } walt_batch_stats;
@@ -138,6 +140,9 @@ uint64_t walt_index_outliers(const walt_index* idx, int strand);
 /* index entries whose genome window is also stored in slot order ("dense candidate windows": the regions of
  * thousands of candidates that repeats produce are then verified from contiguous memory) */
 uint64_t walt_index_window_entries(const walt_index* idx, int strand);
+/* index entries in runs that qualify for a dense window; larger than walt_index_window_entries when the memory budget
+ * ended before the last run (those regions are verified from the scattered genome windows: same results, slower) */
+uint64_t walt_index_window_eligible(const walt_index* idx, int strand);
 
 /* ---- single-end: replaces the strand loop + omp loop over SingleEndMapping,
  *      mapping.cpp:486-500 / 224-316 ------------------------------------- */
@@ -241,9 +246,14 @@ int walt_index_write(const walt_index* idx, const char* dbindex_path);
  * (ncclCommInitRank; collective, blocks until all ranks have called).  walt_stats_allreduce sums v[0..n)
  * over the ranks in place (host vector; collective, same n on every rank); with comm == NULL it is
  * the identity, which is what a single process needs.  bin/walt, one process driving several GPUs,
- * adds its per-device blocks on the host instead. */
+ * adds its per-device blocks on the host instead.
+ * walt_comm_available: WALT_OK when librccl could be loaded in this process (no communication) -- a job can
+ * agree on that BEFORE any rank enters the blocking calls (walt_comm_init and walt_stats_allreduce have no
+ * timeout: a rank that never arrives leaves its peers waiting, as with ncclCommInitRank / ncclAllReduce
+ * themselves). */
 #define WALT_COMM_ID_BYTES 128
 typedef struct walt_comm walt_comm;
+int walt_comm_available(void);
 int walt_comm_unique_id(void* id_out /* WALT_COMM_ID_BYTES */);
 int walt_comm_init(int device, int rank, int world, const void* id, walt_comm** out);
 int walt_stats_allreduce(walt_comm* comm, uint64_t* v, size_t n);

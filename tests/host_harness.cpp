@@ -23,6 +23,7 @@ struct HStrand {
   std::vector<Ent> ent;
   std::vector<Outlier> outl;
   std::vector<uint32_t> outl_dir;
+  std::vector<uint32_t> fen[kFenceLevels];
   StrandView view;
 };
 struct HIndex {
@@ -123,6 +124,17 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
   s.view.outl_dir_mask = build_outlier_dir(s.outl.data(), s.view.n_outl, s.outl_dir) - 1;
   s.view.outl_dir = s.outl_dir.data();
   s.view.wbits = nullptr; s.view.wrank = nullptr; s.view.win = nullptr; s.view.win2 = nullptr; s.view.wcap = 0;
+  // fence keys (core.h StrandView::fen; device_index.hip k_make_fences); WALT_AMD_FENCE=0: the k-ary search instead
+  {
+    const char* e = getenv("WALT_AMD_FENCE");
+    const bool on = index_size && !(e && atoi(e) == 0);
+    for (uint32_t k = 0; k < kFenceLevels; ++k) {
+      s.fen[k].clear();
+      if (on)
+        for (uint64_t j = 0; j < index_size; j += 1ull << (4 * (k + 1))) { s.fen[k].push_back(s.ent[j].key_hi); s.fen[k].push_back(s.ent[j].key_lo); }
+      s.view.fen[k] = on ? s.fen[k].data() : nullptr;
+    }
+  }
   h->view.s[strand] = s.view;
   h->view.start_index = h->start.data();
   h->present[strand] = true;
@@ -353,6 +365,49 @@ long hh_kary_check(uint32_t seed, uint32_t n_cases) {
       }
       const bool f2 = kary_result(ks, a2, u2);
       if (rounds > 64 || f1 != f2 || (f1 && (a1 != a2 || u1 != u2))) ++bad;
+    }
+  }
+  return bad;
+}
+
+// slot_fence_search (core.h) on random sorted arrays of up to a few hundred thousand entries, random sub-ranges as slots:
+// the equal range of a masked key must be std::equal_range's.  Returns the number of differing answers.
+long hh_fence_check(uint32_t seed, uint32_t n_cases) {
+  uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1);
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  long bad = 0;
+  for (uint32_t c = 0; c < n_cases; ++c) {
+    const uint32_t n = 1 + (uint32_t)(rnd() % (c % 11 == 0 ? 300000 : (c % 3 == 0 ? 6000 : 300)));
+    const uint32_t distinct = 1 + (uint32_t)(rnd() % (c % 3 == 0 ? 5 : (c % 5 == 0 ? 4000 : 60)));
+    const uint32_t nk = 1 + (uint32_t)(rnd() % kKeyChars);
+    const uint64_t M = key_mask(nk);
+    std::vector<uint64_t> vals(distinct);
+    for (auto& v : vals) v = rnd();
+    std::vector<uint64_t> keys(n);
+    for (auto& k : keys) k = vals[rnd() % distinct];
+    std::sort(keys.begin(), keys.end(), [&](uint64_t a, uint64_t b) { return (a & M) < (b & M) || ((a & M) == (b & M) && a < b); });
+    std::vector<Ent> ent(n + 8);
+    for (uint32_t i = 0; i < n; ++i) { ent[i].key_hi = (uint32_t)(keys[i] >> 32); ent[i].key_lo = (uint32_t)keys[i]; ent[i].pos = i; }
+    std::vector<uint32_t> fen[kFenceLevels];
+    StrandView sv;
+    memset(&sv, 0, sizeof(sv));
+    sv.ent = ent.data();
+    sv.index_size = n;
+    for (uint32_t k = 0; k < kFenceLevels; ++k) {
+      for (uint64_t j = 0; j < n; j += 1ull << (4 * (k + 1))) { fen[k].push_back(ent[j].key_hi); fen[k].push_back(ent[j].key_lo); }
+      sv.fen[k] = fen[k].data();
+    }
+    for (int t = 0; t < 8; ++t) {
+      const uint64_t T = (t < 5 ? vals[rnd() % distinct] : rnd()) & M;
+      const uint32_t lo = t == 0 ? 0u : (uint32_t)(rnd() % n), hi = t == 0 ? n : lo + 1 + (uint32_t)(rnd() % (n - lo));
+      uint32_t a1 = 0, u1 = 0;
+      const bool f1 = slot_fence_search(sv, lo, hi, T, M, a1, u1);
+      uint32_t a2 = lo, u2 = lo;  // reference: first index with masked key >= T, first with masked key > T
+      while (a2 < hi && (keys[a2] & M) < T) ++a2;
+      u2 = a2;
+      while (u2 < hi && (keys[u2] & M) == T) ++u2;
+      const bool f2 = u2 > a2;
+      if (f1 != f2 || (f1 && (a1 != a2 || u1 != u2 - 1))) ++bad;
     }
   }
   return bad;

@@ -263,3 +263,13 @@ def test_round_based_kary_search_equals_the_two_sided_search():
     for seed in range(3):
         assert refio.harness().hh_kary_check(seed, 1000) == 0
 
+
+
+def test_fence_search_equals_the_equal_range():
+    """core.h slot_fence_search (round 3: long slots searched through the fence keys -- every 16th, 256th, 4096th,
+    65536th entry's key, a static B-tree of fan-out 16 without pointers) must return the equal range of the masked
+    key: random sorted arrays of 1..300,000 entries with long runs of equal keys, masks of 1..32 key characters,
+    eight targets each (present and absent), the whole array and random sub-ranges as the slot; compared with a
+    linear scan."""
+    for seed in range(3):
+        assert refio.harness().hh_fence_check(seed, 700) == 0

@@ -61,12 +61,29 @@ def sample(rng, seqs, n, conv, lengths, refio):
     return out
 
 
+class SoakMismatch(AssertionError):
+    pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed0", type=int, default=1)
     ap.add_argument("--pattern", type=int, default=3, choices=[3, 5, 7])
+    ap.add_argument("--genomes", type=int, default=0, help="stop after this many genomes (0: when --seconds are used up)")
     args = ap.parse_args()
+    try:
+        print(run_soak(args.seconds, args.seed0, args.pattern, args.genomes or None))
+    except SoakMismatch as e:
+        print(e)
+        sys.exit(1)
+
+
+def run_soak(seconds, seed0=1, pattern=3, max_genomes=None):
+    """Genomes seed0, seed0 + 1, ... until `seconds` are used up or `max_genomes` are done; returns the summary line,
+    raises SoakMismatch at the first difference (tests/test_gpu_soak.py runs a fixed set of seeds this way)."""
+    from types import SimpleNamespace
+    args = SimpleNamespace(seconds=seconds, seed0=seed0, pattern=pattern)
     import refio
     import walt_amd
     refio.set_pattern(args.pattern)
@@ -77,7 +94,7 @@ def main():
     cases = reads_total = pairs_total = 0
     seed = args.seed0
     t_note = time.time()
-    while time.time() < t_end:
+    while time.time() < t_end and (max_genomes is None or cases < max_genomes):
         if time.time() - t_note > 60:  # a sign of life (runs under a watchdog that takes minutes of silence for a hang)
             print("soak: %d genomes so far, no difference" % cases, file=sys.stderr, flush=True)
             t_note = time.time()
@@ -107,8 +124,7 @@ def main():
                 for f in ("genome_pos", "times", "strand", "mismatch"):
                     if not np.array_equal(got[f], want[f]):
                         bad = int(np.nonzero(got[f] != want[f])[0][0])
-                        print("MISMATCH seed %d %s field %s read %d (%s) D=%d m=%d b=%d" % (seed, conv, f, bad, reads[bad], D, m, b))
-                        sys.exit(1)
+                        raise SoakMismatch("MISMATCH seed %d %s field %s read %d (%s) D=%d m=%d b=%d" % (seed, conv, f, bad, reads[bad], D, m, b))
                 reads_total += len(reads)
             s1 = sample(rng, seqs, 500, "CT", lengths, refio)
             s2 = sample(rng, seqs, 500, "GA", lengths, refio)
@@ -119,21 +135,20 @@ def main():
             for f in ("best_times", "frag_len", "pair_mm", "best_i", "best_j"):
                 if not np.array_equal(res[f], wantp[f]):
                     bad = int(np.nonzero(res[f] != wantp[f])[0][0])
-                    print("MISMATCH seed %d paired-end field %s pair %d D=%d m=%d b=%d k=%d L=%d" % (seed, f, bad, D, m, b, k, L))
-                    sys.exit(1)
+                    raise SoakMismatch("MISMATCH seed %d paired-end field %s pair %d D=%d m=%d b=%d k=%d L=%d" % (seed, f, bad, D, m, b, k, L))
             for mate in ("m1", "m2"):
                 for f in ("genome_pos", "times", "strand", "mismatch"):
                     if not np.array_equal(res[mate][f], wantp[mate][f]):
-                        print("MISMATCH seed %d paired-end %s.%s D=%d m=%d b=%d k=%d L=%d" % (seed, mate, f, D, m, b, k, L))
-                        sys.exit(1)
+                        raise SoakMismatch("MISMATCH seed %d paired-end %s.%s D=%d m=%d b=%d k=%d L=%d" % (seed, mate, f, D, m, b, k, L))
             pairs_total += len(s1)
             idx.close()
             cases += 1
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
         seed += 1
-    print("soak ok: pattern %d, %d genomes, %d single-end reads and %d pairs identical to the oracle (seeds %d..%d)" % (
-        args.pattern, cases, reads_total, pairs_total, args.seed0, seed - 1))
+    os.environ.pop("WALT_AMD_TABLE", None)
+    return "soak ok: pattern %d, %d genomes, %d single-end reads and %d pairs identical to the oracle (seeds %d..%d)" % (
+        args.pattern, cases, reads_total, pairs_total, args.seed0, seed - 1)
 
 
 if __name__ == "__main__":

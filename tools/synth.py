@@ -146,7 +146,7 @@ def _age_mix(torch, g, dev, n, classes):
     return d
 
 
-def genome_hg19like(torch, dev, scale, seed, contigs=0):
+def genome_hg19like(torch, dev, scale, seed, contigs=0, single=None):
     names, lens = hg19_sequences()
     if scale != 1.0:
         lens = [max(600, int(l * scale)) for l in lens]
@@ -154,6 +154,8 @@ def genome_hg19like(torch, dev, scale, seed, contigs=0):
         total = sum(lens)
         lens = [total // contigs] * (contigs - 1) + [total - (total // contigs) * (contigs - 1)]
         names = ["ctg%d" % i for i in range(contigs)]
+    if single:  # one sequence of exactly this many bases, the families scaled to it (BASELINE configs[0]: a chr2-length genome)
+        names, lens = [single[0]], [int(single[1])]
     L = sum(lens)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -291,8 +293,13 @@ def genome_easy(torch, dev, scale, seed, contigs=0):
     return _to_ascii(torch, dev, codes), lens, names
 
 
+CHR2_LEN = HG19_CHROMS[1]  # 243,199,373: SURVEY 8(d) config 1
+
+
 def make_genome(torch, dev, scale, seed, kind="hg19like", contigs=0):
     """-> (ASCII genome tensor on dev, sequence lengths, sequence names)"""
+    if kind == "chr2like":
+        return genome_hg19like(torch, dev, 1.0, seed, 0, single=("chr2", CHR2_LEN))
     if kind == "easy":
         return genome_easy(torch, dev, scale, seed, contigs)
     if kind != "hg19like":

@@ -158,6 +158,8 @@ def lib(pattern=None):
     L.walt_index_outliers.restype = u64
     L.walt_index_window_entries.argtypes = [vp, ci]
     L.walt_index_window_entries.restype = u64
+    L.walt_index_window_eligible.argtypes = [vp, ci]
+    L.walt_index_window_eligible.restype = u64
     L.walt_map_se_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, vp, vp]
     L.walt_se_workspace_bytes.argtypes = [u32, u32]
     L.walt_se_workspace_bytes.restype = c.c_size_t
@@ -176,6 +178,7 @@ def lib(pattern=None):
     L.walt_profile_enable.argtypes = [vp, ci]
     L.walt_profile_last.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_float)]
     L.walt_profile_detail.argtypes = [vp, c.POINTER(c.c_float)]
+    L.walt_comm_available.argtypes = []
     L.walt_comm_unique_id.argtypes = [vp]
     L.walt_comm_init.argtypes = [ci, ci, ci, vp, c.POINTER(vp)]
     L.walt_stats_allreduce.argtypes = [vp, vp, c.c_size_t]
@@ -216,6 +219,11 @@ def pack_reads(seqs):
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_available():
+    """True when librccl loads in this process (walt_comm_available; no communication)."""
+    return lib().walt_comm_available() == 0
 
 
 def comm_unique_id():
@@ -394,6 +402,9 @@ class Index:
 
     def window_entries(self, strand):
         return self._L.walt_index_window_entries(self._h, strand)
+
+    def window_eligible(self, strand):
+        return self._L.walt_index_window_eligible(self._h, strand)
 
     # -- single-end -----------------------------------------------------------
     def map_se_batch(self, bases, offsets, ag_wildcard=False, max_mismatches=6, b=5000):

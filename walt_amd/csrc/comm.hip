@@ -36,13 +36,16 @@ static std::string g_rccl_error;
 
 static void load_rccl() {
   const char* names[] = {getenv("WALT_AMD_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  std::string tried;
   for (const char* nm : names) {
     if (!nm || !*nm) continue;
     g_rccl.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.so) break;
+    const char* why = dlerror();  // may be null
+    tried += std::string(tried.empty() ? "" : "; ") + nm + ": " + (why ? why : "unknown error");
   }
   if (!g_rccl.so) {
-    g_rccl_error = std::string("cannot load librccl: ") + dlerror();
+    g_rccl_error = "cannot load librccl (" + tried + ")";
     return;
   }
   auto sym = [&](const char* s) {
@@ -83,6 +86,8 @@ struct walt_comm {
 
 extern "C" {
 
+int walt_comm_available(void) { return rccl_ready(); }
+
 int walt_comm_unique_id(void* id_out) {
   if (!id_out) return fail(WALT_EINVAL, "walt_comm_unique_id: null buffer");
   int rc = rccl_ready();
@@ -121,7 +126,7 @@ int walt_comm_init(int device, int rank, int world, const void* id, walt_comm** 
 
 int walt_stats_allreduce(walt_comm* c, uint64_t* v, size_t n) {
   if (!v && n) return fail(WALT_EINVAL, "walt_stats_allreduce: null vector");
-  if (!c || n == 0) return WALT_OK;  // a single process: the vector already is the total
+  if (!c || n == 0) return WALT_OK;  // a single process (walt_comm_init was never needed): the vector already is the total
   WALT_HIP(hipSetDevice(c->device));
   if (c->cap < n) {
     if (c->d_buf) WALT_HIP(hipFree(c->d_buf));

@@ -133,7 +133,16 @@ struct StrandView {
   const uint32_t* win2;
   uint32_t wcap;
   uint32_t wpad_;
+  // Fence keys (DERIVED; round 3): fen[k - 1][2 i], [2 i + 1] = {key_hi, key_lo} of ent[i * 16^k], k = 1..kFenceLevels --
+  // every 16th, 256th, 4096th and 65536th entry's key once more, contiguous, so that 16 consecutive fences of a level
+  // are ONE aligned 128-byte line.  A slot of thousands of entries (a read from a repeat family) is then searched
+  // like a static B-tree of fan-out 16 that needs no pointers: the level whose fences number at most 16 inside the
+  // range, then the 15 fences of the next level between two of them, ... then at most 16 entries -- one line per level
+  // where the pivots of a k-ary search over the entries themselves are a line each (core.h fence_plan).
+  // 1/15 of the entries' keys: 1.55 GB per strand at hg19 scale.  nullptr: search the entries (slot_kary_search).
+  const uint32_t* fen[4];
 };
+constexpr uint32_t kFenceLevels = 4;
 constexpr uint32_t kWinMinRun = 17;  // runs of at least this many index slots get dense records (map_se.hip kMidRegion + 1)
 constexpr uint32_t kWinLead = kPat - 1;   // bases in front of pos: the largest seed shift (genome_pos = pos - seed_i)
 constexpr uint32_t kWinWords = 7, kWinWords2 = 4;
@@ -172,6 +181,7 @@ WALT_HD DenseRange dense_range(const StrandView& sv, uint32_t l, uint32_t size, 
     d.rec = r0;
   }
 #else
+  if (sv.wbits == nullptr) return d;
   if (usable && size) {
     const uint32_t last = l + size - 1;
     const unsigned long long b0 = sv.wbits[l >> 6], b1 = sv.wbits[last >> 6];
@@ -654,6 +664,113 @@ WALT_HD bool kary_result(const KaryState& s, uint32_t& a, uint32_t& u) {
   return true;
 }
 
+// ---- fence search (StrandView::fen) ------------------------------------------------------------------------------
+// One round narrows a range [x, y] ("the first entry whose masked key is >= T -- or > T -- lies in [x, y]", as in
+// KaryState) by the fences inside it: the pivots are the multiples of 2^sh in [x, y), sh the smallest of 0, 4, 8, 12,
+// 16 that leaves at most 16 of them (sh == 0: the entries themselves).  Their keys are read in two dependent
+// sub-rounds that touch the same one or two lines: pivots 3, 7, 11, 15 first, then the three pivots of the quarter
+// those select.  c = number of pivots below the target gives the new range (fence_narrow), which lies strictly
+// between two pivots, so the next level down has at most 15 fences inside it.  A 4,096-entry slot: three rounds and
+// four or five lines per search, where the k-ary search over the entries took five or six rounds of eight lines.
+// The result is the equal range of the masked key in a sorted slot, however it is searched.
+struct FencePlan {
+  uint32_t sh, first, m;  // level, fence number of pivot 0, pivots (0: the search is finished)
+};
+WALT_HD uint32_t fence_ceil(uint32_t x, uint32_t sh) { return x ? ((x - 1u) >> sh) + 1u : 0u; }  // ceil(x / 2^sh), no overflow
+WALT_HD FencePlan fence_plan(const StrandView& sv, uint32_t x, uint32_t y) {
+  FencePlan p;
+  p.sh = 0; p.first = x; p.m = 0;
+  if (y <= x) return p;
+  uint32_t sh = 0;
+  if (sv.fen[0] != nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 1; k <= kFenceLevels; ++k) {  // counts fall with the level: the last level whose predecessor has more than 16
+      const uint32_t prev = 4 * (k - 1);
+      sh = (fence_ceil(y, prev) - fence_ceil(x, prev) > 16u) ? 4 * k : sh;
+    }
+  }
+  p.sh = sh;
+  p.first = fence_ceil(x, sh);
+  const uint32_t cnt = fence_ceil(y, sh) - p.first;  // >= 1: a level is only left for a range that holds one of its fences
+  p.m = cnt < 16u ? cnt : 16u;                       // (more than 16 only without fences, or beyond 16 x 65536 entries)
+  return p;
+}
+// where pivot i's key lies (i clamped to the plan's pivots; a finished search reads entry `safe`)
+WALT_HD const uint32_t* fence_ptr(const StrandView& sv, const FencePlan& p, uint32_t i, uint32_t safe) {
+  const uint32_t ii = i < p.m ? i : (p.m ? p.m - 1u : 0u);
+  const uint32_t sh = p.m ? p.sh : 0u;
+  const uint64_t f = p.m ? (uint64_t)p.first + ii : (uint64_t)safe;
+  const uint32_t* base = reinterpret_cast<const uint32_t*>(sv.ent);
+  base = sh == 4 ? sv.fen[0] : base;
+  base = sh == 8 ? sv.fen[1] : base;
+  base = sh == 12 ? sv.fen[2] : base;
+  base = sh == 16 ? sv.fen[3] : base;
+  return base + f * (sh ? 2u : 3u);
+}
+WALT_HD uint64_t fence_load(const uint32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t __attribute__((address_space(1))) gword;  // a global load, not a FLAT one (map_items.h load_global)
+  const gword* q = reinterpret_cast<const gword*>(reinterpret_cast<uintptr_t>(p));
+  const uint32_t hi = q[0], lo = q[1];
+  return ((uint64_t)hi << 32) | lo;
+#else
+  return ((uint64_t)p[0] << 32) | p[1];
+#endif
+}
+WALT_HD void fence_narrow(const FencePlan& p, uint32_t c, uint32_t& x, uint32_t& y) {
+  if (!p.m) return;
+  const uint32_t at_c = (p.first + c) << p.sh;                 // pivot c (used when c < m)
+  const uint32_t past = ((p.first + c - 1u) << p.sh) + 1u;      // one past pivot c - 1 (used when c > 0)
+  const uint32_t nx = c ? past : x, ny = c < p.m ? at_c : y;
+  x = nx; y = ny;
+}
+// pivots below the target among A = {3, 7, 11, 15} (strict: key < T, else key <= T): a prefix, the quarter the B pivots come from
+WALT_HD uint32_t fence_count4(const FencePlan& p, const uint64_t* k, uint32_t first_i, uint32_t step, uint32_t n, uint64_t T,
+                              uint64_t M, bool strict) {
+  uint32_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (uint32_t j = 0; j < 4; ++j) {
+    const uint64_t v = k[j] & M;
+    const bool below = strict ? v < T : v <= T;
+    c += (j < n && first_i + step * j < p.m && below) ? 1u : 0u;
+  }
+  return c;
+}
+// one lane, one slot, both searches in lock-step (the kernels' dual-strand form is map_common.h fence_round_dual)
+WALT_HD bool slot_fence_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a, uint32_t& u) {
+  uint32_t x1 = lo, y1 = hi, x2 = lo, y2 = hi;
+  while (y1 > x1 || y2 > x2) {
+    const FencePlan p1 = fence_plan(sv, x1, y1), p2 = fence_plan(sv, x2, y2);
+    uint64_t a1[4], a2[4], b1[4], b2[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t j = 0; j < 4; ++j) {
+      a1[j] = fence_load(fence_ptr(sv, p1, 4 * j + 3, lo));
+      a2[j] = fence_load(fence_ptr(sv, p2, 4 * j + 3, lo));
+    }
+    const uint32_t q1 = fence_count4(p1, a1, 3, 4, 4, T, M, true), q2 = fence_count4(p2, a2, 3, 4, 4, T, M, false);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t j = 0; j < 3; ++j) {
+      b1[j] = fence_load(fence_ptr(sv, p1, 4 * q1 + j, lo));
+      b2[j] = fence_load(fence_ptr(sv, p2, 4 * q2 + j, lo));
+    }
+    b1[3] = b2[3] = 0;
+    fence_narrow(p1, 4 * q1 + fence_count4(p1, b1, 4 * q1, 1, 3, T, M, true), x1, y1);
+    fence_narrow(p2, 4 * q2 + fence_count4(p2, b2, 4 * q2, 1, 3, T, M, false), x2, y2);
+  }
+  if (x2 <= x1) return false;
+  a = x1;
+  u = x2 - 1;
+  return true;
+}
+
 // The same narrowing for care chars >= 44 on a key-equal range of at most kLookupPos slots whose
 // genome positions are already in registers (the usual case for reads longer than ~134 bp: one
 // candidate).  lit_region would fetch, per character, the slot and then the genome word -- ten
@@ -824,7 +941,7 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     u = a + n_eq - 1;
     out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
   } else {
-    if (!slot_kary_search(sv, lo, hi, T, M, a, u)) return;
+    if (sv.fen[0] != nullptr ? !slot_fence_search(sv, lo, hi, T, M, a, u) : !slot_kary_search(sv, lo, hi, T, M, a, u)) return;
   }
   if (n > kKeyChars) {
     const uint32_t size = u - a + 1;

@@ -176,6 +176,19 @@ __global__ void k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {  
     p[i] = v;
 }
 // slot table (core.h StrandView::tab) from the finished directory: record t belongs to slot t + 1
+// Fence keys (core.h StrandView::fen): thread i copies the key of entry 16 i to level 1, and to the levels above
+// when i is a multiple of 16, 256, 4096.
+__global__ void k_make_fences(const Ent* __restrict__ ent, uint32_t index_size, uint32_t* __restrict__ f1,
+                              uint32_t* __restrict__ f2, uint32_t* __restrict__ f3, uint32_t* __restrict__ f4) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i * 16 >= index_size) return;
+  const Ent e = ent[i * 16];
+  f1[2 * i] = e.key_hi; f1[2 * i + 1] = e.key_lo;
+  if ((i & 15u) == 0) { f2[2 * (i >> 4)] = e.key_hi; f2[2 * (i >> 4) + 1] = e.key_lo; }
+  if ((i & 255u) == 0) { f3[2 * (i >> 8)] = e.key_hi; f3[2 * (i >> 8) + 1] = e.key_lo; }
+  if ((i & 4095u) == 0) { f4[2 * (i >> 12)] = e.key_hi; f4[2 * (i >> 12) + 1] = e.key_lo; }
+}
+
 __global__ void k_make_table(const uint32_t* __restrict__ dir, const Ent* __restrict__ ent, uint64_t slots,
                              uint32_t* __restrict__ tab) {
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < slots; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -238,7 +251,8 @@ int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands, uint6
   // 30 GB for batches, and the GPU builder's peak while it sorts the last strand (24 bytes of keys and
   // positions per entry, 4 of slack) beside the strands already finished.
   if (B == 31 && max_index_size > (1ull << 31)) {
-    const uint64_t strand = 12ull * max_index_size + (4ull << 32) + max_index_size / 3 + (80ull << 20);
+    const uint64_t strand = 12ull * max_index_size + (4ull << 32) + max_index_size / 3 + (80ull << 20) +
+                            8ull * max_index_size / 15;  // entries, directory, genome and bitmaps, small tables, fence keys
     const uint64_t resident = (uint64_t)n_strands * strand + (30ull << 30);
     const uint64_t build_peak = (uint64_t)(n_strands - 1) * strand + 28ull * max_index_size;
     if (resident <= device_bytes && build_peak <= device_bytes) B = 32;
@@ -296,6 +310,19 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   if (herr[1]) {
     return fail(WALT_EFORMAT, "strand index " + std::to_string(strand) + ": " + std::to_string(herr[1]) +
                                   " index positions beyond the genome");
+  }
+  // fence keys of the long-slot search (WALT_AMD_FENCE=0: none, the k-ary search over the entries is used; A/B runs)
+  uint32_t* fen[kFenceLevels] = {nullptr, nullptr, nullptr, nullptr};
+  {
+    const char* e = getenv("WALT_AMD_FENCE");
+    if (index_size && !(e && atoi(e) == 0)) {
+      for (uint32_t k = 0; k < kFenceLevels; ++k) {
+        const uint64_t n_k = (((uint64_t)index_size - 1) >> (4 * (k + 1))) + 1;
+        if ((rc = dev_alloc(idx, &fen[k], 2 * n_k + 32))) return rc;  // (+ slack: a clamped pivot never reads beyond, a whole line may)
+      }
+      hipLaunchKernelGGL(k_make_fences, dim3(grid_for(((uint64_t)index_size + 15) / 16)), dim3(kBlock), 0, stream, ent, index_size,
+                         fen[0], fen[1], fen[2], fen[3]);
+    }
   }
   if (index_size) {
     hipLaunchKernelGGL(k_check_buckets, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, ent, index_size,
@@ -437,6 +464,7 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
   sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1; sv.pre = pre; sv.tab = tab;
   sv.wbits = nullptr; sv.wrank = nullptr; sv.win = nullptr; sv.win2 = nullptr; sv.wcap = 0;  // build_windows, once every strand is resident
+  for (uint32_t k = 0; k < kFenceLevels; ++k) sv.fen[k] = fen[k];
   idx->strand_mask |= 1u << strand;
   return WALT_OK;
 }
@@ -567,48 +595,59 @@ static int build_windows(walt_index* idx) {
     if (budget < 1024.0 * rec_bytes) continue;
     // record numbers must fit 32 bits: the mapping kernels pass them between lanes as one word
     const uint32_t cap_recs = (uint32_t)std::min<double>(budget / (double)rec_bytes, 4.0e9);
-    uint32_t* rank = nullptr;
-    unsigned long long *bits = nullptr, *flag = nullptr;
-    int rc;
-    if ((rc = dev_alloc(idx, &bits, (uint64_t)nw + 1))) return rc;
-    if ((rc = dev_alloc(idx, &rank, (uint64_t)nw + 1))) return rc;
-    WALT_HIP(hipMalloc(reinterpret_cast<void**>(&flag), ((uint64_t)nw + 1) * 8));  // the eq bitmap (temporary)
+    // The windows are an optional accelerator: when memory for them cannot be had after all (the budget came from
+    // hipMemGetInfo a moment ago; another process or a caching allocator may have taken it since) the strand simply
+    // has none and its large regions are verified from ent[] + g2[] -- same results, slower.
+    struct Scoped {  // temporaries: freed on every path
+      void* p = nullptr;
+      ~Scoped() { if (p) (void)hipFree(p); }
+    } flag_buf, cnt_buf, tmp_buf, bits_buf, rank_buf, win_buf, win2_buf;
+    auto give_up = [&](const char* what) {
+      if (getenv("WALT_AMD_VERBOSE")) fprintf(stderr, "[walt_amd index: strand %d: no dense candidate windows (%s)]\n", s, what);
+      (void)hipGetLastError();
+    };
+    if (hipMalloc(&bits_buf.p, ((uint64_t)nw + 1) * 8) != hipSuccess || hipMalloc(&rank_buf.p, ((uint64_t)nw + 1) * 4) != hipSuccess ||
+        hipMalloc(&flag_buf.p, ((uint64_t)nw + 1) * 8) != hipSuccess) { give_up("bitmap allocation failed"); continue; }
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(bits_buf.p);
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(flag_buf.p);
+    uint32_t* rank = reinterpret_cast<uint32_t*>(rank_buf.p);
     hipLaunchKernelGGL(k_win_eq, dim3((unsigned)(((uint64_t)nw * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sv.g2, sv.ent,
                        sv.index_size, flag);
     hipLaunchKernelGGL(k_win_bits, dim3(grid_for(nw)), dim3(kBlock), 0, stream, flag, nw, bits);
-    hipError_t se = hipStreamSynchronize(stream);
-    hipFree(flag);
-    WALT_HIP(se);
-    uint32_t* cnt = nullptr;
-    WALT_HIP(hipMalloc(reinterpret_cast<void**>(&cnt), ((uint64_t)nw + 1) * 4));
+    WALT_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(flag_buf.p);
+    flag_buf.p = nullptr;
+    if (hipMalloc(&cnt_buf.p, ((uint64_t)nw + 1) * 4) != hipSuccess) { give_up("temporary allocation failed"); continue; }
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(cnt_buf.p);
     hipLaunchKernelGGL(k_win_popc, dim3(grid_for(nw)), dim3(kBlock), 0, stream, bits, nw, cnt);
     size_t tmp_bytes = 0;
-    se = rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, rank, 0u, (size_t)nw, rocprim::plus<uint32_t>(), stream);
-    void* tmp = nullptr;
-    if (se == hipSuccess) se = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
-    if (se == hipSuccess) se = rocprim::exclusive_scan(tmp, tmp_bytes, cnt, rank, 0u, (size_t)nw, rocprim::plus<uint32_t>(), stream);
+    WALT_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, rank, 0u, (size_t)nw, rocprim::plus<uint32_t>(), stream));
+    if (hipMalloc(&tmp_buf.p, tmp_bytes ? tmp_bytes : 16) != hipSuccess) { give_up("temporary allocation failed"); continue; }
+    WALT_HIP(rocprim::exclusive_scan(tmp_buf.p, tmp_bytes, cnt, rank, 0u, (size_t)nw, rocprim::plus<uint32_t>(), stream));
     uint32_t last_rank = 0, last_cnt = 0;
-    if (se == hipSuccess) se = hipMemcpyAsync(&last_rank, rank + (nw - 1), 4, hipMemcpyDeviceToHost, stream);
-    if (se == hipSuccess) se = hipMemcpyAsync(&last_cnt, cnt + (nw - 1), 4, hipMemcpyDeviceToHost, stream);
-    if (se == hipSuccess) se = hipStreamSynchronize(stream);
-    if (tmp) hipFree(tmp);
-    hipFree(cnt);
-    WALT_HIP(se);
+    WALT_HIP(hipMemcpyAsync(&last_rank, rank + (nw - 1), 4, hipMemcpyDeviceToHost, stream));
+    WALT_HIP(hipMemcpyAsync(&last_cnt, cnt + (nw - 1), 4, hipMemcpyDeviceToHost, stream));
+    WALT_HIP(hipStreamSynchronize(stream));
     const uint64_t want = (uint64_t)last_rank + last_cnt;
     const uint32_t n_recs = (uint32_t)std::min<uint64_t>(want, cap_recs);
+    idx->window_eligible[s] = want;
     if (getenv("WALT_AMD_VERBOSE"))
       fprintf(stderr, "[walt_amd index: strand %d: %llu of %u index slots (%.2f %%) lie in runs with dense candidate windows; records for "
               "%u of them, %.2f GB]\n", s, (unsigned long long)want, sv.index_size, 100.0 * (double)want / (double)sv.index_size, n_recs,
               (double)n_recs * rec_bytes / 1e9);
-    idx->window_records[s] = n_recs;
     if (n_recs == 0) continue;
-    uint32_t *win = nullptr, *win2 = nullptr;
-    if ((rc = dev_alloc(idx, &win, (uint64_t)n_recs * (kWinWords + 1) + 16))) return rc;
-    if ((rc = dev_alloc(idx, &win2, (uint64_t)n_recs * kWinWords2 + 16))) return rc;
+    if (hipMalloc(&win_buf.p, ((uint64_t)n_recs * (kWinWords + 1) + 16) * 4) != hipSuccess ||
+        hipMalloc(&win2_buf.p, ((uint64_t)n_recs * kWinWords2 + 16) * 4) != hipSuccess) { give_up("record allocation failed"); continue; }
+    uint32_t* win = reinterpret_cast<uint32_t*>(win_buf.p);
+    uint32_t* win2 = reinterpret_cast<uint32_t*>(win2_buf.p);
     hipLaunchKernelGGL(k_win_fill, dim3((unsigned)(((uint64_t)sv.index_size + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sv.g2,
                        sv.ent, sv.index_size, bits, rank, n_recs, win, win2);
     WALT_HIP(hipStreamSynchronize(stream));
     WALT_HIP(hipGetLastError());
+    // the strand keeps them: hand the four arrays over to the index
+    for (Scoped* b : {&bits_buf, &rank_buf, &win_buf, &win2_buf}) { idx->allocs.push_back(b->p); b->p = nullptr; }
+    idx->device_bytes += ((uint64_t)nw + 1) * 12 + ((uint64_t)n_recs * (kWinWords + 1 + kWinWords2) + 32) * 4;
+    idx->window_records[s] = n_recs;
     sv.wbits = bits; sv.wrank = rank; sv.win = win; sv.win2 = win2; sv.wcap = n_recs;
   }
   return WALT_OK;
@@ -950,6 +989,9 @@ uint64_t walt_index_bad_buckets(const walt_index* idx, int strand) {
 }
 uint64_t walt_index_outliers(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->outliers[strand] : 0;
+}
+uint64_t walt_index_window_eligible(const walt_index* idx, int strand) {
+  return idx && strand >= 0 && strand < 4 ? idx->window_eligible[strand] : 0;
 }
 uint64_t walt_index_window_entries(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->window_records[strand] : 0;

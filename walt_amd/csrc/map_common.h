@@ -386,7 +386,8 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
     u = a + n_eq - 1;
     out.npos = n_eq < kLookupPos ? n_eq : kLookupPos;
   } else {
-    if (!slot_kary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
+    if (sv.fen[0] != nullptr ? !slot_fence_search(sv, p.lo, p.lo + p.ne, T, M, a, u)
+                             : !slot_kary_search(sv, p.lo, p.lo + p.ne, T, M, a, u)) return;
   }
   if (n > kKeyChars) {
     const uint32_t size = u - a + 1;
@@ -403,6 +404,69 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
     return;
   }
   out.reg.l = a; out.reg.u = u;
+}
+
+// One fence round (core.h fence_plan) of the four searches of a probe -- lower and upper bound on both strands -- in
+// lock-step: the A pivots of all of them are loaded together, then the B pivots.  While the two searches of a strand
+// still share their range (and quarter) the second one needs no loads of its own; the wavefront skips them when that
+// holds for all of its lanes (a uniform branch: the loads in it are the last before the values are needed anyway).
+__device__ __forceinline__ void fence_round_dual(const StrandView& svp, const StrandView& svm, KaryState* ks, uint64_t T,
+                                                 uint64_t M, uint32_t safe_p, uint32_t safe_m) {
+  FencePlan p1[2], p2[2];
+  bool same[2];
+  uint64_t a1[2][4], a2[2][4], b1[2][4], b2[2][4];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const StrandView& sv = f ? svm : svp;
+    p1[f] = fence_plan(sv, ks[f].x1, ks[f].y1);
+    p2[f] = fence_plan(sv, ks[f].x2, ks[f].y2);
+    same[f] = ks[f].x1 == ks[f].x2 && ks[f].y1 == ks[f].y2;
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) a1[f][j] = fence_load(fence_ptr(f ? svm : svp, p1[f], 4 * j + 3, f ? safe_m : safe_p));
+  if (__ballot(!same[0] || !same[1])) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) a2[f][j] = fence_load(fence_ptr(f ? svm : svp, p2[f], 4 * j + 3, f ? safe_m : safe_p));
+  } else {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) a2[f][j] = a1[f][j];
+  }
+  uint32_t q1[2], q2[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    q1[f] = fence_count4(p1[f], a1[f], 3, 4, 4, T, M, true);
+    q2[f] = fence_count4(p2[f], a2[f], 3, 4, 4, T, M, false);
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+#pragma unroll
+    for (uint32_t j = 0; j < 3; ++j) b1[f][j] = fence_load(fence_ptr(f ? svm : svp, p1[f], 4 * q1[f] + j, f ? safe_m : safe_p));
+    b1[f][3] = 0;
+  }
+  if (__ballot(!same[0] || !same[1] || q1[0] != q2[0] || q1[1] != q2[1])) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (uint32_t j = 0; j < 3; ++j) b2[f][j] = fence_load(fence_ptr(f ? svm : svp, p2[f], 4 * q2[f] + j, f ? safe_m : safe_p));
+      b2[f][3] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) b2[f][j] = b1[f][j];
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    fence_narrow(p1[f], 4 * q1[f] + fence_count4(p1[f], b1[f], 4 * q1[f], 1, 3, T, M, true), ks[f].x1, ks[f].y1);
+    fence_narrow(p2[f], 4 * q2[f] + fence_count4(p2[f], b2[f], 4 * q2[f], 1, 3, T, M, false), ks[f].x2, ks[f].y2);
+  }
 }
 
 // The heavy kernels' form of probe_resolve for BOTH strands of a probe.  Nearly every wavefront of a heavy pass
@@ -458,9 +522,13 @@ __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const 
       kary_init(ks[f], p.lo, p.lo + p.ne);
     }
   }
-  while (kary_busy(ks[0]) || kary_busy(ks[1])) {
-    kary_round(svp, ks[0], T, M, pp.lo);
-    kary_round(svm, ks[1], T, M, pm.lo);
+  if (svp.fen[0] != nullptr && svm.fen[0] != nullptr) {  // uniform
+    while (kary_busy(ks[0]) || kary_busy(ks[1])) fence_round_dual(svp, svm, ks, T, M, pp.lo, pm.lo);
+  } else {
+    while (kary_busy(ks[0]) || kary_busy(ks[1])) {
+      kary_round(svp, ks[0], T, M, pp.lo);
+      kary_round(svm, ks[1], T, M, pm.lo);
+    }
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {

@@ -753,8 +753,8 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
 
 #if WALT_SEEDPATTERN == 3
 // pass 1: every read of the batch, one per lane (HEAVY = false); pass 1b: the reads of the heavy list (HEAVY = true)
-template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
-__global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? (STAGED ? 4 : 3) : (NW <= 10 ? (STAGED ? 3 : 2) : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
+template <int NW, bool DIAG, bool HEAVY, bool STAGED = false, int OCC = 0>  // OCC: wavefronts per SIMD the registers are capped for (0: the default below)
+__global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 : 3) : (NW <= 10 ? (STAGED ? 3 : 2) : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
                                                     const uint64_t* __restrict__ offsets,
                                                     uint32_t* __restrict__ err,
                                                     uint32_t n_all, uint32_t strand_base,
@@ -1054,6 +1054,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, false>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
       return (unsigned)nb * 256u;
     }();
+    static const int stage_occ = [] { const char* e = getenv("WALT_AMD_STAGE_OCC"); return e ? atoi(e) : 0; }();
     for (uint32_t c = 0; c < chunks; ++c) {
       hs.first = c * hcap;
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
@@ -1068,6 +1069,10 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
           hipLaunchKernelGGL((k_map_se<NW, true, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                              heavy_list, g_ablate, g_stamps, hs);
+        else if (NW <= 10 && stage_occ == (NW <= 8 ? 3 : 2))  // A/B knob (WALT_AMD_STAGE_OCC): one wavefront per SIMD fewer, more registers
+          hipLaunchKernelGGL((k_map_se<NW, false, true, true, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+                             n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                             heavy_list, 0u, nullptr, hs);
         else
           hipLaunchKernelGGL((k_map_se<NW, false, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,

@@ -93,3 +93,58 @@ def c_abi_comm(device, group=None):
     box = [walt_amd.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0, group=group)
     return walt_amd.Comm(device, rank, world, box[0])
+
+
+def _all_min(flag, group=None):
+    """MIN of a 0/1 flag over the ranks, carried by the job's own process group (gloo or nccl)."""
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+def c_abi_cross_check(device, vec_local, expect, group=None):
+    """The sum of `vec_local` over the ranks through the C ABI's own communicator (walt_stats_allreduce over RCCL),
+    compared with `expect` (the same sum made by torch.distributed).  COLLECTIVE, and written so that a failure on
+    some ranks cannot leave the others blocked: every step that can fail locally is followed by a MIN over the ranks
+    of an ok flag on the job's process group, and only a unanimous yes enters the next blocking call; the id is
+    broadcast unconditionally (None when rank 0 could not make it).  Returns "equal", "DIFFERENT: ..." or
+    "failed: ...", the same string on every rank up to the local error text."""
+    import torch.distributed as dist
+    import walt_amd
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    err = ""
+    uid = None
+    ok = walt_amd.comm_available()
+    if not ok:
+        err = "librccl did not load on rank %d" % rank
+    elif rank == 0:
+        try:
+            uid = walt_amd.comm_unique_id()
+        except Exception as e:  # WaltError
+            ok, err = False, "walt_comm_unique_id: %s" % e
+    box = [uid]
+    dist.broadcast_object_list(box, src=0, group=group)
+    if not _all_min(ok and box[0] is not None, group):
+        return "failed: %s" % (err or "another rank could not load librccl / make the id")
+    comm = None
+    try:
+        comm = walt_amd.Comm(device, rank, world, box[0])
+    except Exception as e:
+        err = "walt_comm_init: %s" % e
+    if not _all_min(comm is not None, group):
+        if comm is not None:
+            comm.close()
+        return "failed: %s" % (err or "walt_comm_init failed on another rank")
+    res = None
+    try:
+        res = [int(x) for x in comm.stats_allreduce(vec_local).tolist()]
+    except Exception as e:
+        err = "walt_stats_allreduce: %s" % e
+    comm.close()
+    if not _all_min(res is not None, group):
+        return "failed: %s" % (err or "walt_stats_allreduce failed on another rank")
+    return "equal" if res == [int(x) for x in expect] else "DIFFERENT: %s" % res
