@@ -28,7 +28,9 @@ constexpr uint32_t kVerifyBatchMax = 32;
 struct ItemQueue {
   uint4* items;   // cap items of item_quads<NW>() quads
   uint32_t* ctl;  // [0] dense items, [1] gather items, [2] [3] the verifiers' cursors (zeroed by the host)
-  uint32_t cap;   // items the array has room for, both kinds together
+  uint32_t cap;   // items the array has room for, both kinds TOGETHER: dense items fill it from the front, gather items from
+                  // the back, and each side is checked against cap alone -- a caller must size cap for the most items
+                  // that can come (the stage kernels: two per read and stage), or the two sides would meet
   // Largest first: dense items of more than kBigFirst candidates go to their own array and the dense verifier takes
   // them BEFORE the others (item numbers [0, bigs) are this array's), dealt round robin over the wavefronts -- a
   // region of thousands of candidates is tens of dependent steps, and a wavefront that met two or three of them at
@@ -80,6 +82,51 @@ __device__ __forceinline__ bool item_append(bool take, bool dense, uint32_t id, 
     }
   }
   return placed;
+}
+
+// Both strands' items of a probe in ONE call: one atomic per kind for the two of them (every returning atomic is a
+// dependent round trip for the wavefront, and same-address atomics run at ~10 ns each: map_common.h WaveList).
+// Lane arguments with suffix 0 are the '+' strand's item, 1 the '-' strand's.
+template <int NW>
+__device__ __forceinline__ void item_append2(const bool* take, const bool* dense, const uint32_t* id, const uint32_t* l,
+                                             const uint32_t* size, const uint32_t* rec, uint32_t len, uint32_t seed_i,
+                                             const uint32_t* rd, const uint32_t* mk, const ItemQueue& q) {
+  constexpr uint32_t Q = item_quads<NW>();
+  const uint32_t lane = threadIdx.x & 63;
+  bool in_bigs[2] = {false, false};
+#pragma unroll
+  for (int side = -1; side < 2; ++side) {  // -1: the largest-first array
+    if (side < 0 && q.bigs == nullptr) continue;
+    bool mine[2];
+    unsigned long long m[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      mine[f] = side < 0 ? (take[f] && dense[f] && size[f] > kBigFirst) : (take[f] && !in_bigs[f] && (dense[f] == (side == 0)));
+      m[f] = __ballot(mine[f]);
+    }
+    if (!(m[0] | m[1])) continue;
+    const uint32_t n0 = (uint32_t)__popcll(m[0]), n1 = (uint32_t)__popcll(m[1]);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(side < 0 ? q.big_n : &q.ctl[side], n0 + n1);
+    base = bcast(base, 0);
+    const uint32_t room = side < 0 ? q.big_cap : q.cap;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const uint32_t k = base + (f ? n0 : 0u) + (uint32_t)__popcll(m[f] & ((1ull << lane) - 1ull));
+      if (side < 0) in_bigs[f] = mine[f] && k < room;  // no room: the item goes to the ordinary dense side below
+      if (mine[f] && k < room) {
+        const uint64_t at = side <= 0 ? k : (uint64_t)q.cap - 1 - k;
+        uint4* it = (side < 0 ? q.bigs : q.items) + Q * at;
+        it[0] = make_uint4(id[f], l[f], size[f], rec[f]);
+        it[1] = make_uint4(len, seed_i, 0u, 0u);
+        uint32_t w[4 * (Q - 2)];
+#pragma unroll
+        for (uint32_t t = 0; t < 4 * (Q - 2); ++t) w[t] = t < (uint32_t)NW ? rd[t] : (t < 2u * NW ? mk[t - NW] : 0u);
+#pragma unroll
+        for (uint32_t qd = 0; qd + 2 < Q; ++qd) it[2 + qd] = make_uint4(w[4 * qd], w[4 * qd + 1], w[4 * qd + 2], w[4 * qd + 3]);
+      }
+    }
+  }
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }

@@ -227,7 +227,7 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
                                                 uint32_t* __restrict__ heap_n, uint32_t* __restrict__ bloom_count,
                                                 uint32_t* __restrict__ bloom_list, uint32_t* __restrict__ cplx_count,
                                                 uint32_t* __restrict__ cplx_list, uint32_t& n_probe,
-                                                uint32_t& n_verified, uint32_t& len_out) {
+                                                uint32_t& n_verified, uint32_t& len_out, WaveList& wl_cplx) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t top_step = top_step_of(n_chrom);
   const StrandView& svp = iv.s[strand_base];
@@ -339,7 +339,7 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
   const uint32_t total = hsize + n_minus;
   const bool to_cplx = !deferred && valid && (cplx || total > kFastCands || total >= top_k);
   wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, bloom_count, bloom_list);
-  wave_append(to_cplx, r, cplx_count, cplx_list);
+  wavelist_append(wl_cplx, to_cplx, r, cplx_count, cplx_list);  // a fifth of the reads: buffered (map_common.h WaveList)
   if (!deferred && !to_cplx && valid) {
     // the heap never fills: plain pushes in the reference's order, then the drain of paired.cpp:685-692
     if (n_minus > 0) { HeapEnt e; e.pos = mp0; e.mms = mm0 | 0x80000000u; heap_push(fast, hsize, e); }
@@ -366,6 +366,12 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   __shared__ BlockShared sh;
   __shared__ HeapEnt s_fast[kFastCands][kBlock];
   __shared__ PreFilter pf;
+  constexpr uint32_t kCplxBuf = 128;  // (the kernel's 38 KB of LDS leave 2 KB at four blocks per CU)
+  __shared__ uint32_t s_cplx[(kBlock / 64) * kCplxBuf];
+  WaveList wl_cplx;
+  wl_cplx.buf = s_cplx + (threadIdx.x >> 6) * kCplxBuf;
+  wl_cplx.n = 0;
+  wl_cplx.cap = kCplxBuf;
   prefilter_stage(pf, iv, strand_base);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   LdsHeap fast;
@@ -382,10 +388,11 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
     const uint32_t r = valid ? (uint32_t)r64 : 0;
     uint32_t len;
     pe_process_dual<NW>(iv, sh, pf, si, fast, codes2, offsets, err, r, valid, strand_base, max_mm, b, top_k, ranked, heap_n,
-                        bloom_count, bloom_list, cplx_count, cplx_list, n_probe, n_verified, len);
+                        bloom_count, bloom_list, cplx_count, cplx_list, n_probe, n_verified, len, wl_cplx);
     // paired.cpp:112-115: too_short once per strand pass
     shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
+  wavelist_flush(wl_cplx, cplx_count, cplx_list);
   pe_flush(shortv, n_probe, n_verified, 0, stats);
 }
 
@@ -639,10 +646,10 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
     const DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, big_m && win_usable<NW>(svm, lr.len));
     {
       const bool dn_p = big_p && dr_p.hi > dr_p.lo, dn_m = big_m && dr_m.hi > dr_m.lo;
-      item_append<NW>(big_p, dn_p, j | (probe_p << 24), lp.reg.l, size_p, dn_p ? (uint32_t)dr_p.rec : kItemDenseNone, lr.len, seed_i,
-                      lr.rd, mk, ps.q);
-      item_append<NW>(big_m, dn_m, j | (probe_m << 24), lm.reg.l, size_m, dn_m ? (uint32_t)dr_m.rec : kItemDenseNone, lr.len, seed_i,
-                      lr.rd, mk, ps.q);
+      const bool take2[2] = {big_p, big_m}, dense2[2] = {dn_p, dn_m};
+      const uint32_t id2[2] = {j | (probe_p << 24), j | (probe_m << 24)}, l2[2] = {lp.reg.l, lm.reg.l}, size2[2] = {size_p, size_m};
+      const uint32_t rec2[2] = {dn_p ? (uint32_t)dr_p.rec : kItemDenseNone, dn_m ? (uint32_t)dr_m.rec : kItemDenseNone};
+      item_append2<NW>(take2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, ps.q);  // one atomic for both strands' items
       n_big += (big_p ? 1u : 0u) + (big_m ? 1u : 0u);
     }
     if (valid && !big_p) {  // an item's counts come from k_pe_verify

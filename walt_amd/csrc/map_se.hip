@@ -339,7 +339,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
                                                 uint32_t* __restrict__ defer_list, uint32_t* __restrict__ heavy_count,
                                                 uint32_t* __restrict__ heavy_list, MapCounters& ctr_out,
                                                 uint32_t& len_out, uint32_t ablate_rt, StampsT<DIAG>& st,
-                                                const HeavyStage& hs = HeavyStage(), uint32_t j = 0) {
+                                                const HeavyStage& hs = HeavyStage(), uint32_t j = 0,
+                                                WaveList* wl_heavy = nullptr) {
   static_assert(!STAGED || HEAVY, "the staged kernels are heavy-pass kernels");
   if constexpr (STAGED) valid = valid && !(hs.stage && hs.flag[j]);  // gone to the literal list at an earlier stage
   const uint32_t ablate = DIAG ? ablate_rt : 0u;
@@ -572,23 +573,24 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         if (on_m) sum_m = acc;
       }
     }
+    if constexpr (STAGED) {  // both strands' large regions become work items: one atomic for the two (map_items.h item_append2)
+      const bool big2[2] = {size_p > kMidRegion, size_m > kMidRegion};
+      const bool dense2[2] = {big2[0] && dr_p.hi > dr_p.lo, big2[1] && dr_m.hi > dr_m.lo};
+      const uint32_t id2[2] = {j, j | (1u << 31)}, l2[2] = {lp.reg.l, lm.reg.l}, size2[2] = {size_p, size_m};
+      const uint32_t rec2[2] = {dense2[0] ? (uint32_t)dr_p.rec : kItemDenseNone, dense2[1] ? (uint32_t)dr_m.rec : kItemDenseNone};
+      ItemQueue q;
+      q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
+      q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
+      item_append2<NW>(big2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, q);
+      if (big2[0]) { ++ctr.big; pend_p = true; }
+      if (big2[1]) { ++ctr.big; pend_m = true; }
+    }
 #pragma unroll 1
     for (uint32_t fi = 0; fi < 2; ++fi) {
+      if constexpr (STAGED) break;
       const StrandView& sv = fi ? svm : svp;
       const uint32_t my_size = fi ? size_m : size_p;
       const uint32_t my_l = fi ? lm.reg.l : lp.reg.l;
-      if constexpr (STAGED) {
-        const bool bigr = my_size > kMidRegion;
-        const DenseRange& dr = fi ? dr_m : dr_p;
-        const bool dense = bigr && dr.hi > dr.lo;
-        {
-          ItemQueue q;
-          q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
-          q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
-          item_append<NW>(bigr, dense, j | (fi << 31), my_l, my_size, dense ? (uint32_t)dr.rec : kItemDenseNone, lr.len, seed_i, lr.rd, mk, q);
-        }
-        if (bigr) { ++ctr.big; if (fi) pend_m = true; else pend_p = true; }
-      }
       unsigned long long big = STAGED ? 0ull : __ballot(my_size > kMidRegion);
       while (big) {
         const int owner = (int)__ffsll((long long)big) - 1;
@@ -623,7 +625,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         // the next seed is probed on '+' while the best of the '+' strand is above seed_i (mapping.cpp:250-257), and
         // never on '-' otherwise (the '-' bound is at most the '+' best); pending summaries can only lower it
         const uint32_t known = (!pend_p && sum_p.count && sum_p.min_mm < best.mismatch) ? sum_p.min_mm : best.mismatch;
-        wave_append(mappable && known > seed_i, j, &hs.ctl[4], hs.list_out);
+        wavelist_append(*wl_heavy, mappable && known > seed_i, j, &hs.ctl[4], hs.list_out);  // (the staged kernels' use of the buffer)
       }
       break;
     }
@@ -639,7 +641,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     if (best.mismatch > 1) fold_region(best, m2, '-');
   }
   wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, defer_count, defer_list);
-  if constexpr (!HEAVY) wave_append(heavy && !deferred, r, heavy_count, heavy_list);
+  if constexpr (!HEAVY) wavelist_append(*wl_heavy, heavy && !deferred, r, heavy_count, heavy_list);  // (buffered: map_common.h WaveList)
   if constexpr (STAGED) {
     if (hs.stage == 0 ? valid || deferred : deferred) hs.flag[j] = deferred ? 1u : 0u;
     if (hs.stage == 3 && valid) out[r] = best;
@@ -777,6 +779,12 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 
   if (HEAVY && n == 0) return;
   __shared__ BlockShared sh;
   __shared__ PreFilter pf;
+  // per-wavefront list buffers: pass 1's heavy list; a stage kernel's list of the reads that go on to the next stage
+  __shared__ uint32_t s_wl[(HEAVY && !STAGED) ? 1 : (kBlock / 64) * kWaveBuf];
+  WaveList wl_heavy;
+  wl_heavy.buf = s_wl + ((HEAVY && !STAGED) ? 0 : (threadIdx.x >> 6) * kWaveBuf);
+  wl_heavy.n = 0;
+  wl_heavy.cap = kWaveBuf;
   prefilter_stage(pf, iv, strand_base);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   // persistent blocks: the LDS prologue (mask table, chromosome starts, Bloom
@@ -815,10 +823,12 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 
     uint32_t len;
     se_process_dual<NW, DIAG, HEAVY, STAGED>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
                                              out, defer_count, defer_list, heavy_count, heavy_list, ctr, len, ablate, st, hs,
-                                             j_cur);
+                                             j_cur, &wl_heavy);
     // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 sees every read
     if (!HEAVY) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
+  if constexpr (!HEAVY) wavelist_flush(wl_heavy, heavy_count, heavy_list);
+  if constexpr (STAGED) { if (hs.list_out != nullptr) wavelist_flush(wl_heavy, &hs.ctl[4], hs.list_out); }
   stamp_end(st);
   flush_counters(ctr, shortv, stats);
 }
