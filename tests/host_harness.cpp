@@ -326,6 +326,77 @@ int hh_region_check(void* hp, const char* bases, const uint64_t* offsets, uint32
   return 0;
 }
 
+// Care characters >= 44 narrowed by the verifier against IndexRegion: for every safe probe of a
+// read whose seed has more than 44 care characters, the key-equal range [a, u] (care characters 12..43) is searched as
+// the kernels do; when NO entry of the range is a run breaker (an entry with fewer than kTailBreakRoom + 1 bases of its
+// chromosome behind it: device_index.hip k_make_ent / k_win_break end the dense runs there, so these are exactly the
+// ranges the kernels may defer), the set of its candidates whose characters 44..seed_len-1 equal the read's --
+// what item_stream keeps -- must be IndexRegion's [l, u]: contiguous, same ends, or both empty.
+// out[0] long-seed safe probes with a non-empty key-equal range, out[1] of them deferrable (no breaker inside),
+// out[2] deferrable probes whose set differs from lit_region's (must be 0), out[3] ranges that hold a breaker.
+int hh_tail_check(void* hp, const char* bases, const uint64_t* offsets, uint32_t n, int ag, uint64_t* out4) {
+  HIndex* h = reinterpret_cast<HIndex*>(hp);
+  const IndexView& iv = h->view;
+  constexpr int NW = 64;
+  std::vector<uint32_t> rec(packed_fields(NW));
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  const uint32_t* start = h->start.data();
+  for (uint32_t r = 0; r < n; ++r) {
+    uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
+    if (len > kMaxReadLen) return -1;
+    if (len < kMinReadLen) continue;
+    if (!pack_read(reinterpret_cast<const uint8_t*>(bases) + offsets[r], len, ag ? 1 : 0, iv.dir_bits, NW, rec.data(), 1)) return -2;
+    const uint32_t seed_len = seed_len_of(seed_repeats(len));
+    if (seed_len <= kKeyWeight + kKeyChars) continue;
+    for (uint32_t fi = 0; fi < 2; ++fi) {
+      const StrandView& sv = iv.s[(ag ? 2 : 0) + fi];
+      for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
+        const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
+        if (probe_is_dangerous(sv, care, seed_len)) continue;
+        // the key-equal range, as the kernels find it: directory slot, then the equal range of the 32 key characters
+        const uint32_t slot = care[kCareWords], span = care[kCareWords + 1];
+        const uint32_t* dp = sv.dir + (uint32_t)(slot - 1u);
+        const uint32_t lo = dp[1], hi = span == 1 ? dp[0] : sv.dir[(uint32_t)(slot - span)];
+        if (lo >= hi) continue;
+        const uint64_t M = key_mask(kKeyChars), T = target_key(care) & M;
+        uint32_t a = 0, u = 0;
+        if (!slot_fence_search(sv, lo, hi, T, M, a, u)) continue;
+        ++out4[0];
+        bool breaker = false;
+        for (uint32_t j = a; j <= u; ++j) {
+          const uint32_t pos = sv.ent[j].pos;
+          const uint32_t chr = chrom_id(start, iv.n_chrom, pos);
+          if (start[chr + 1] - pos <= kTailBreakRoom) breaker = true;
+        }
+        if (breaker) {
+          ++out4[3];
+          if (!getenv("WALT_AMD_TEST_DEFER_BREAKERS")) continue;  // (test of the test: without the rule, differences must show)
+        }
+        ++out4[1];
+        // what the verifier keeps: candidates whose care characters 44 .. seed_len - 1 equal the read's
+        uint32_t first = 0, last = 0, cnt = 0;
+        bool contiguous = true;
+        for (uint32_t j = a; j <= u; ++j) {
+          bool eq = true;
+          for (uint32_t p = kKeyWeight + kKeyChars; p < seed_len; ++p) {
+            const uint64_t q = (uint64_t)sv.ent[j].pos + care_pos(p);
+            eq = eq && q < sv.genome_len && g2_code(sv.g2, q) == care_char(care, p);
+          }
+          if (!eq) continue;
+          if (cnt && j != last + 1) contiguous = false;
+          if (!cnt) first = j;
+          last = j;
+          ++cnt;
+        }
+        const Region lit = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
+        const bool e2 = lit.l > lit.u;
+        if (!contiguous || (cnt == 0) != e2 || (cnt && (first != lit.l || last != lit.u))) ++out4[2];
+      }
+    }
+  }
+  return 0;
+}
+
 // core.h kary_round (the heavy stages' round-by-round slot search, two slots advanced together) against
 // slot_kary_search on random sorted slots: returns the number of differing answers.  Keys are drawn from few
 // values so that equal ranges are long; masks of 1..32 key characters; targets present and absent.

@@ -157,6 +157,7 @@ def harness():
         L.hh_pe_merge.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, u32, ci, u32, vp]
         L.hh_get_nocare.argtypes = [vp]
         L.hh_region_check.argtypes = [vp, vp, vp, u32, ci, vp]
+        L.hh_tail_check.argtypes = [vp, vp, vp, u32, ci, vp]
         L.hh_kary_check.argtypes = [u32, u32]
         L.hh_kary_check.restype = ctypes.c_long
         L.hh_fence_check.argtypes = [u32, u32]
@@ -328,6 +329,15 @@ class HarnessIndex:
         out = np.zeros(4, dtype=np.uint64)
         rc = harness().hh_region_check(self.h, bases.ctypes.data, offsets.ctypes.data, len(seqs), int(ag),
                                        out.ctypes.data)
+        assert rc == 0, rc
+        return [int(v) for v in out]
+
+    def tail_check(self, seqs, ag=False):
+        """(long-seed safe probes with a key-equal range, of them deferrable, deferrable ones whose verifier-side set
+        differs from IndexRegion's, ranges holding a run breaker) -- host_harness.cpp hh_tail_check"""
+        bases, offsets = pack_reads(seqs)
+        out = np.zeros(4, dtype=np.uint64)
+        rc = harness().hh_tail_check(self.h, bases.ctypes.data, offsets.ctypes.data, len(seqs), int(ag), out.ctypes.data)
         assert rc == 0, rc
         return [int(v) for v in out]
 

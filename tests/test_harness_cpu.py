@@ -273,3 +273,57 @@ def test_fence_search_equals_the_equal_range():
     linear scan."""
     for seed in range(3):
         assert refio.harness().hh_fence_check(seed, 700) == 0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_harness_tail_characters_narrowed_by_the_verifier(scratch, seed, monkeypatch):
+    """DESIGN.md section 4b (round 3): a read above 134 bases has a seed of more than the 44 care characters the entry
+    keys hold; the staged kernels hand the whole key-equal range to the verifier when the range lies in dense candidate
+    windows, and the verifier keeps the candidates whose characters 44.. equal the read's.  That must be IndexRegion's
+    region whenever the range holds no entry with a care character beyond its chromosome's end (the run breakers,
+    core.h kTailBreakRoom).  A genome of one sequence holding eight copies of a motif plus a dozen short chromosomes cut
+    from the same motif: key-equal ranges are long, and a fifth of them hold chromosome-end entries.  Every deferrable
+    range is compared with lit_region (0 differences allowed); and, as a test of the test, with the breaker rule
+    switched off differences must show."""
+    rng = random.Random(2000 + seed)
+    alphabet = "TTTTTTCCAG" if seed % 2 else "ACGT"
+    mlen = 2000 + 500 * (seed % 3)
+    motif = "".join(rng.choice(alphabet) for _ in range(mlen))
+    seqs = []
+    for i in range(12 + seed % 3 * 6):
+        L = rng.choice([150, 160, 170, 180, 185, 190, 200, 215, 260, 330])
+        a = rng.randrange(0, mlen)
+        s = list((motif * 3)[a:a + L])
+        for _ in range(rng.randrange(0, 3)):
+            s[rng.randrange(len(s))] = rng.choice("ACGT")
+        seqs.append(("t%d" % i, "".join(s)))
+    seqs.append(("long", motif * 8))
+    fa = os.path.join(scratch, "tail_%d.fa" % seed)
+    with open(fa, "w") as f:
+        for nm, s in seqs:
+            f.write(">%s\n%s\n" % (nm, s))
+    idxp = os.path.join(scratch, "tail_%d.dbindex" % seed)
+    assert refio.harness().walt_makedb(fa.encode(), idxp.encode(), 4) == 0
+    db = refio.DbIndex(idxp)
+    long_seq = motif * 8
+    reads = []
+    for _ in range(4000):
+        L = rng.choice([140, 143, 150, 150, 150, 152])
+        a = rng.randrange(0, len(long_seq) - L)
+        s = long_seq[a:a + L]
+        if rng.random() < 0.5:
+            s = refio.revcomp(s)
+        s = "".join("T" if (c == "C" and rng.random() < 0.9) else c for c in s)
+        s = "".join(rng.choice("ACGT") if rng.random() < 0.01 else c for c in s)
+        reads.append(s)
+    for D in (24, 28):
+        h = refio.HarnessIndex(db, D)
+        ranges, deferrable, differ, with_breaker = h.tail_check(reads)
+        assert differ == 0, "%d of %d deferrable ranges: the verifier's set differs from IndexRegion's" % (differ, deferrable)
+        assert deferrable > 2000 and with_breaker > 400, (ranges, deferrable, with_breaker)
+        if D == 24:
+            monkeypatch.setenv("WALT_AMD_TEST_DEFER_BREAKERS", "1")
+            _, all_ranges, differ_without_rule, _ = h.tail_check(reads)
+            monkeypatch.delenv("WALT_AMD_TEST_DEFER_BREAKERS")
+            assert all_ranges == ranges and differ_without_rule > 10, (all_ranges, differ_without_rule)
+        h.close()

@@ -3,11 +3,18 @@
 # written bytes per launch, in-kernel phase shares of the heavy stages.  bash tools/prof_stage.sh <tag> [env ...]
 set -u
 TAG=$1; shift
-for e in "$@"; do export "$e"; done
+XARGS=""
+while [ $# -gt 0 ]; do
+  case "$1" in
+    --*) XARGS="$XARGS $1"; if [ $# -gt 1 ] && [ "${2#--}" = "$2" ]; then XARGS="$XARGS $2"; shift; fi ;;
+    *) export "$1" ;;
+  esac
+  shift
+done
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"
 OUT=gpurun_out/stage_$TAG; mkdir -p $OUT
-ARGS="--no-extra --no-cpu-baseline --steps 2 --warmup 1"
+ARGS="--no-extra --no-cpu-baseline --steps 2 --warmup 1 $XARGS"
 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/trace -o t -- python3 bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.log || { tail -5 $OUT/trace.log; exit 1; }
 python3 tools/trace_tail.py $OUT/trace > $OUT/trace_tail.txt; cat $OUT/trace_tail.txt
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $R/$OUT/pmc_rd -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_rd.log || { tail -5 $OUT/pmc_rd.log; exit 1; }

@@ -143,6 +143,9 @@ struct StrandView {
   const uint32_t* fen[4];
 };
 constexpr uint32_t kFenceLevels = 4;
+// an entry with fewer than this many bases of its chromosome behind it has a care character (of the kNumCare a seed can
+// have) beyond the chromosome's end: such slots end the dense runs (device_index.hip k_make_ent / k_win_break)
+constexpr uint32_t kTailBreakRoom = care_pos(kNumCare - 1);
 constexpr uint32_t kWinMinRun = 17;  // runs of at least this many index slots get dense records (map_se.hip kMidRegion + 1)
 constexpr uint32_t kWinLead = kPat - 1;   // bases in front of pos: the largest seed shift (genome_pos = pos - seed_i)
 constexpr uint32_t kWinWords = 7, kWinWords2 = 4;
@@ -1023,6 +1026,34 @@ WALT_HD uint32_t count_mismatch_regs(const uint32_t* g /*[NW + 1]*/, uint32_t sh
     mm += popc32((x | (x >> 1)) & mask[w]);
   }
   return mm;
+}
+
+// the same, and beside it the mismatches under a second mask (the seed's care characters >= 44, which the verifier
+// tests for the candidates of a key-equal range: DESIGN.md section 4b); tmask all zero: tmm = 0
+template <int NW>
+WALT_HD uint32_t count_mismatch_regs2(const uint32_t* g /*[NW + 1]*/, uint32_t sh, const uint32_t* rd, const uint32_t* mask,
+                                      const uint32_t* tmask, uint32_t& tmm) {
+  uint32_t mm = 0, t = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t x = funnel_r(g[w], g[w + 1], sh) ^ rd[w];
+    const uint32_t d = x | (x >> 1);
+    mm += popc32(d & mask[w]);
+    t += popc32(d & tmask[w]);
+  }
+  tmm = t;
+  return mm;
+}
+// bit 2k of word w set for every read offset 16 w + k that holds care character p of seed shift seed_i, p in [p0, p1)
+WALT_HD uint32_t care_mask_word(uint32_t w, uint32_t seed_i, uint32_t p0, uint32_t p1) {
+  uint32_t m = 0;
+  for (uint32_t p = p0; p < p1; ++p) {
+    const uint32_t o = seed_i + care_pos(p);
+    if ((o >> 4) == w) m |= 1u << (2 * (o & 15u));
+  }
+  return m;
 }
 
 // compare mask word w for (seed shift, repeats, read_len): table part + tail

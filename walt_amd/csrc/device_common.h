@@ -29,6 +29,8 @@ struct walt_index {
   uint64_t device_bytes = 0;
   uint64_t bad_buckets[4] = {0, 0, 0, 0};
   uint64_t outliers[4] = {0, 0, 0, 0};
+  uint32_t* brk[4] = {nullptr, nullptr, nullptr, nullptr};  // index slots of the chromosome-end entries (k_make_ent), for build_windows
+  uint32_t n_brk[4] = {0, 0, 0, 0};
   uint32_t window_records[4] = {0, 0, 0, 0};  // index slots with a dense candidate window (core.h StrandView::win)
   uint64_t window_eligible[4] = {0, 0, 0, 0};  // index slots in runs that qualify for one (more than the records when the budget ended first)
   unsigned strand_mask = 0;

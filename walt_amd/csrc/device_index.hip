@@ -110,7 +110,7 @@ __device__ __forceinline__ uint32_t ent_prefix_dev(const uint32_t* __restrict__ 
 __global__ void k_make_ent(const uint32_t* __restrict__ g2, uint32_t genome_len,
                            const uint32_t* __restrict__ index, uint32_t n, Ent* __restrict__ ent,
                            const uint32_t* __restrict__ start, uint32_t n_chrom, Outlier* __restrict__ outl,
-                           uint32_t outl_cap, uint32_t* __restrict__ err) {
+                           uint32_t outl_cap, uint32_t* __restrict__ err, uint32_t* __restrict__ brk, uint32_t brk_cap) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   uint32_t pos = index[j];
@@ -125,6 +125,13 @@ __global__ void k_make_ent(const uint32_t* __restrict__ g2, uint32_t genome_len,
   ent[j] = e;
   const uint32_t chr = chrom_id(start, n_chrom, pos);
   const uint32_t room = start[chr + 1] - pos;
+  // run breakers (core.h kTailBreakRoom): slots whose care characters -- ANY of the kNumCare a seed can have -- run
+  // over their chromosome's end.  build_windows ends the dense runs at them, so that a range of slots that is dense
+  // holds only entries sorted on real characters (care characters >= 44 narrowed by the verifier)
+  if (room <= kTailBreakRoom) {
+    const uint32_t k = atomicAdd(err + 4, 1u);
+    if (k < brk_cap) brk[k] = j;
+  }
   if (room <= care_pos(kKeyWeight + kKeyChars - 1)) {
     const uint32_t k = atomicAdd(err + 3, 1u);
     if (k < outl_cap) {
@@ -291,20 +298,23 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     void* p = nullptr;
     ~Scoped() { if (p) hipFree(p); }
   } err_buf, tmp_buf, cnt_buf;
-  WALT_HIP(hipMalloc(&err_buf.p, 4 * sizeof(uint32_t)));
+  WALT_HIP(hipMalloc(&err_buf.p, 8 * sizeof(uint32_t)));
   err = reinterpret_cast<uint32_t*>(err_buf.p);
-  WALT_HIP(hipMemsetAsync(err, 0, 4 * sizeof(uint32_t), stream));
+  WALT_HIP(hipMemsetAsync(err, 0, 8 * sizeof(uint32_t), stream));
   WALT_HIP(hipMemsetAsync(bad, 0, kNumBuckets / 8, stream));
   WALT_HIP(hipMemcpyAsync(cnt, d_counter, ((uint64_t)kNumBuckets + 1) * 4, hipMemcpyDeviceToDevice, stream));
   const uint32_t n_chrom = (uint32_t)idx->head.lengths.size();
   const uint32_t outl_cap = n_chrom * 100 + 16;  // <= 94 positions per chromosome have room in [37, 130]
   Outlier* outl = nullptr;
   if ((rc = dev_alloc(idx, &outl, outl_cap))) return rc;
+  const uint32_t brk_cap = n_chrom * (kTailBreakRoom + 1) + 16;  // at most one indexed position per base of a chromosome's last kTailBreakRoom
+  uint32_t* brk = nullptr;
+  if ((rc = dev_alloc(idx, &brk, brk_cap))) return rc;
   if (index_size) {
     hipLaunchKernelGGL(k_make_ent, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, genome_len, d_index,
-                       index_size, ent, idx->view.start_index, n_chrom, outl, outl_cap, err);
+                       index_size, ent, idx->view.start_index, n_chrom, outl, outl_cap, err, brk, brk_cap);
   }
-  uint32_t herr[4] = {0, 0, 0, 0};
+  uint32_t herr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   WALT_HIP(hipMemcpyAsync(herr, err, sizeof(herr), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipStreamSynchronize(stream));
   if (herr[1]) {
@@ -460,6 +470,9 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   }
   idx->bad_buckets[strand] = nbad;
   idx->outliers[strand] = n_outl;
+  if (herr[4] > brk_cap) return fail(WALT_EFORMAT, "more chromosome-end entries than a makedb index can hold");
+  idx->brk[strand] = brk;
+  idx->n_brk[strand] = herr[4];
   sv.outl = outl; sv.n_outl = n_outl;
   sv.g2 = g2; sv.cnt = cnt; sv.bad = bad; sv.dir = dir; sv.ent = ent;
   sv.index_size = index_size; sv.genome_len = genome_len; sv.ga = ga; sv.bloom = bloom; sv.bloom_mask = bloom_blocks - 1; sv.pre = pre; sv.tab = tab;
@@ -508,6 +521,14 @@ __global__ void k_win_eq(const uint32_t* __restrict__ g2, const Ent* __restrict_
   }
   const unsigned long long m = __ballot(same);
   if ((threadIdx.x & 63) == 0 && t < index_size) eq[t >> 6] = m;
+}
+// eq bits j - 1 and j of every breaker slot j cleared: the slot is a run of its own
+__global__ void k_win_break(const uint32_t* __restrict__ brk, uint32_t n, unsigned long long* __restrict__ eq) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t j = brk[t];
+  atomicAnd(&eq[j >> 6], ~(1ull << (j & 63u)));
+  if (j) atomicAnd(&eq[(j - 1) >> 6], ~(1ull << ((j - 1) & 63u)));
 }
 // bitmap of the slots with dense records: every slot of a run of at least kWinMinRun slots.  The run of slot j
 // reaches L slots down and R slots up, each counted to 16 on the eq bits around j: one thread per 64-slot word.
@@ -613,6 +634,8 @@ static int build_windows(walt_index* idx) {
     uint32_t* rank = reinterpret_cast<uint32_t*>(rank_buf.p);
     hipLaunchKernelGGL(k_win_eq, dim3((unsigned)(((uint64_t)nw * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sv.g2, sv.ent,
                        sv.index_size, flag);
+    if (idx->n_brk[s])  // no run crosses a chromosome-end entry (k_make_ent)
+      hipLaunchKernelGGL(k_win_break, dim3(grid_for(idx->n_brk[s])), dim3(kBlock), 0, stream, idx->brk[s], idx->n_brk[s], flag);
     hipLaunchKernelGGL(k_win_bits, dim3(grid_for(nw)), dim3(kBlock), 0, stream, flag, nw, bits);
     WALT_HIP(hipStreamSynchronize(stream));
     (void)hipFree(flag_buf.p);

@@ -478,10 +478,19 @@ __device__ __forceinline__ void fence_round_dual(const StrandView& svp, const St
 //      (the small-region verification and lit_region_small want them in registers),
 //   3. each strand finishes as probe_resolve does (tail characters of long seeds).
 // Same regions as probe_resolve: the equal range of a key in a sorted slot does not depend on how it is searched.
-template <bool LONG_SEED>
+// DEFER (the staged kernels, reads above 134 bases): a key-equal range of more than `defer_min` slots that lies inside
+// dense candidate windows is NOT narrowed here by the care characters behind the key (>= 44; lit_region: a
+// LowerBound / UpperBound bisection per character, each step an entry load and a dependent genome load) -- the whole
+// range becomes the region, defer_x is set, and the verifier tests those characters on the records it streams
+// anyway (map_items.h item_stream).  Dense ranges hold no chromosome-end entry
+// (device_index.hip k_win_break), so inside them the index is sorted on the real characters and IndexRegion's
+// result IS the set of candidates whose characters equal the read's.
+template <bool LONG_SEED, bool DEFER = false>
 __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const StrandView& svm, const SlotProbe& pp,
                                                    const SlotProbe& pm, const uint32_t* care, uint32_t seed_len,
-                                                   Lookup& lp, Lookup& lm, bool& tail_p, bool& tail_m) {
+                                                   Lookup& lp, Lookup& lm, bool& tail_p, bool& tail_m,
+                                                   bool* defer_p = nullptr, bool* defer_m = nullptr, uint32_t defer_min = 0,
+                                                   bool win_ok = false) {
   const uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0u;
   const uint32_t nk = n < kKeyChars ? n : kKeyChars;
   const uint64_t M = key_mask(nk);
@@ -568,11 +577,21 @@ __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const 
     out.reg = empty_region();
 #pragma unroll
     for (uint32_t i = 0; i < kLookupPos; ++i) out.pos[i] = pos[f][i];
+    bool deferred_here = false;
+    if constexpr (DEFER && LONG_SEED) {  // (every lane issues dense_range's four loads: no load under a divergent branch)
+      const uint32_t sz = found[f] ? u[f] - a[f] + 1 : 0u;
+      const DenseRange d = dense_range(sv, a[f], sz, n > kKeyChars && sz > defer_min && win_ok);
+      deferred_here = d.hi > d.lo;
+      *(f ? defer_m : defer_p) = deferred_here;
+    }
     if (!found[f]) continue;
     out.npos = npos[f];
     if (n > kKeyChars) {
       const uint32_t size = u[f] - a[f] + 1;
-      if (LONG_SEED && size == 1 && out.npos == 1) {
+      if (deferred_here) {
+        out.npos = 0;
+        out.reg.l = a[f]; out.reg.u = u[f];
+      } else if (LONG_SEED && size == 1 && out.npos == 1) {
         tail_check = true;  // IndexRegion on one slot (mapping.cpp:206-211)
         out.reg.l = a[f]; out.reg.u = a[f];
       } else if (LONG_SEED && size <= kLookupPos && out.npos == size) {

@@ -7,7 +7,8 @@
 // needs, so the verifier's only dependent loads are the candidates' own:
 //   quad 0   id (the producer's: which read / probe), first slot l, size, first dense record or kItemDenseNone
 //            (record numbers stay below 2^32, device_index.hip build_windows)
-//   quad 1   read length, seed shift, 0, 0
+//   quad 1   read length, seed shift, tail, 0   (tail != 0: the region is a key-equal RANGE whose candidates still owe
+//            the seed's care characters >= 44 -- the verifier tests them and counts the matches for -b; section 4b)
 //   then     the converted read rd[NW] and its compare masks mk[NW] for that seed shift, padded to 16 bytes
 // Items whose candidates all have dense records (core.h dense_range) are queued from the front of the array,
 // the others from its back; each kind has its own verifier instance.
@@ -90,7 +91,8 @@ __device__ __forceinline__ bool item_append(bool take, bool dense, uint32_t id, 
 template <int NW>
 __device__ __forceinline__ void item_append2(const bool* take, const bool* dense, const uint32_t* id, const uint32_t* l,
                                              const uint32_t* size, const uint32_t* rec, uint32_t len, uint32_t seed_i,
-                                             const uint32_t* rd, const uint32_t* mk, const ItemQueue& q) {
+                                             const uint32_t* rd, const uint32_t* mk, const ItemQueue& q,
+                                             const bool* tail = nullptr) {
   constexpr uint32_t Q = item_quads<NW>();
   const uint32_t lane = threadIdx.x & 63;
   bool in_bigs[2] = {false, false};
@@ -118,7 +120,7 @@ __device__ __forceinline__ void item_append2(const bool* take, const bool* dense
         const uint64_t at = side <= 0 ? k : (uint64_t)q.cap - 1 - k;
         uint4* it = (side < 0 ? q.bigs : q.items) + Q * at;
         it[0] = make_uint4(id[f], l[f], size[f], rec[f]);
-        it[1] = make_uint4(len, seed_i, 0u, 0u);
+        it[1] = make_uint4(len, seed_i, (tail != nullptr && tail[f]) ? 1u : 0u, 0u);
         uint32_t w[4 * (Q - 2)];
 #pragma unroll
         for (uint32_t t = 0; t < 4 * (Q - 2); ++t) w[t] = t < (uint32_t)NW ? rd[t] : (t < 2u * NW ? mk[t - NW] : 0u);
@@ -149,6 +151,71 @@ __device__ __forceinline__ T load_global(const T* p) {
 #endif
 }
 
+// Tail items (reads above 134 bases) arrive as key-equal RANGES: the candidates whose care
+// characters 44 .. seed_len - 1 equal the read's are a contiguous part of the range (a dense range is sorted on them),
+// on the benchmark genome half of it.  Before the verifier streams a range, one wavefront brackets that part: 64
+// evenly spaced records' tail characters (the 16-byte second half of a dense record holds them) are compared with the
+// read's, the samples below and above it are cut off, and the item's header is rewritten to the bracket -- at most
+// 1/32 of the range more than the region itself; the verifier still tests every candidate it streams and counts the
+// region for -b.  One wavefront per item; `n_items` dense items of q.items and `n_big` of q.bigs.
+// A range whose samples already prove more than `b` members (the samples that equal the read's characters are members,
+// and so is everything between them) is a region the reference skips (mapping.cpp:275-277): its item shrinks to one
+// candidate with tail = 2, which the verifier takes for an empty region -- satellite arrays put thousands of
+// candidates into such ranges, a third of all the candidates of the 150-base benchmark reads.
+template <int NW, class Sink>
+__device__ __forceinline__ void tail_items_narrow(const IndexView& iv, uint32_t strand_base, const ItemQueue& q, uint32_t n_items,
+                                                  uint32_t n_big, uint32_t b) {
+  static_assert(NW > 8 && NW <= 10 && kPat == 3, "seeds beyond the 44 key characters: reads of 135 to 160 bases, pattern 3");
+  constexpr uint32_t Q = item_quads<NW>();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_items + n_big; i += n_waves) {
+    uint4* const it = i < n_big ? q.bigs + (uint64_t)Q * i : q.items + (uint64_t)Q * (i - n_big);
+    const uint4 h = load_global(it + (lane < Q ? lane : 0u));
+    const uint32_t tail = bcast(h.z, 1);
+    if (!tail) continue;  // (uniform)
+    const uint32_t id = bcast(h.x, 0), l = bcast(h.y, 0), size = bcast(h.z, 0), rec0 = bcast(h.w, 0);
+    const uint32_t len = bcast(h.x, 1), seed_i = bcast(h.y, 1);
+    if (size <= 1 || rec0 == kItemDenseNone) continue;
+    const uint32_t seed_len = len >= kMinReadLen ? seed_len_of(seed_repeats(len)) : 0u;
+    // the read's words 8 and 9 (item words 8 + 8, 8 + 9: quads 4.x, 4.y)
+    const uint32_t r8 = bcast(h.x, 4), r9 = bcast(h.y, 4);
+    const unsigned long long rr = ((unsigned long long)r9 << 32) | r8;  // read offsets 128 .. 159
+    // tail key of the read and of this lane's sample: characters 44 .. 49, two bits each, the first one highest;
+    // characters at and beyond seed_len count as equal (0 on both sides)
+    const uint32_t s_at = (uint32_t)(((unsigned long long)lane * size) >> 6);  // sample positions rise with the lane
+    const StrandView& sv = iv.s[strand_base + Sink::strand(id)];
+    const uint4 e = load_global(reinterpret_cast<const uint4*>(sv.win2) + ((uint64_t)rec0 + s_at));
+    const unsigned long long g_lo = ((unsigned long long)e.y << 32) | e.x, g_hi = ((unsigned long long)e.w << 32) | e.z;  // bases 112..143, 144..175 of the record
+    uint32_t key_r = 0, key_g = 0;
+#pragma unroll
+    for (uint32_t p = kKeyWeight + kKeyChars; p < kMaxRepeats; ++p) {
+      const uint32_t o = seed_i + care_pos(p) - 128u;           // read offset - 128
+      const uint32_t b = care_pos(p) + kWinLead - 112u;          // record base index - 112: 23 .. 38
+      const uint32_t cr = (uint32_t)(rr >> (2u * o)) & 3u;
+      const uint32_t cg = b < 32u ? (uint32_t)(g_lo >> (2u * b)) & 3u : (uint32_t)(g_hi >> (2u * (b - 32u))) & 3u;
+      const bool on = p < seed_len;
+      key_r = (key_r << 2) | (on ? cr : 0u);
+      key_g = (key_g << 2) | (on ? cg : 0u);
+    }
+    const unsigned long long below = __ballot(key_g < key_r), not_above = __ballot(key_g <= key_r);
+    const uint32_t L = (uint32_t)__popcll(below), G = (uint32_t)__popcll(not_above);  // prefixes of the lanes: the range is sorted
+    // members lie behind sample L - 1 and in front of sample G
+    const uint32_t s_prev = (uint32_t)(((unsigned long long)(L ? L - 1 : 0u) * size) >> 6);
+    const uint32_t s_next = (uint32_t)(((unsigned long long)(G < 64u ? G : 63u) * size) >> 6);
+    uint32_t lo = L ? s_prev + 1 : 0u, hi = G < 64u ? s_next : size;
+    if (lo >= hi) { lo = lo < size ? lo : size - 1; hi = lo + 1; }  // no member: one candidate that is none stays (the region is empty)
+    // samples L .. G - 1 equal the read's characters: they and all candidates between them are members
+    const uint32_t s_first = (uint32_t)(((unsigned long long)L * size) >> 6), s_last = (uint32_t)(((unsigned long long)(G ? G - 1 : 0u) * size) >> 6);
+    const bool over_b = G > L && s_last - s_first + 1 > b;
+    if (over_b) hi = lo + 1;
+    if (lane == 0) {
+      it[0] = make_uint4(id, l + lo, hi - lo, rec0 + lo);
+      if (over_b) it[1] = make_uint4(len, seed_i, 2u, 0u);
+    }
+  }
+}
+
 // The item loop of a verifier kernel: one region per wavefront, everything about the item wave-uniform, so a lane
 // carries little besides the records it has in flight and the kernel runs at high occupancy.  Wavefronts take
 // items in batches from the queue's cursor (regions run from 17 to `-b` candidates: a static deal
@@ -161,9 +228,11 @@ __device__ __forceinline__ T load_global(const T* p) {
 //                  evaluation leaves exactly them in flight.
 //   DENSE = false: index entry, then the genome window (coop_verify_groups' gather route).
 //   FITS:          the chromosome starts are in LDS (s_start), else read from HBM.
-// Sink (all calls wave-uniform):  strand(id) -> 0 / 1;  begin(id, seed_i, position in the queue);  add(k, gp, mm) per lane and step
-// (k = slot offset in the region, mm = 0xFFFFFFFF when the slot is beyond the region or fails the edge filters of
-// mapping.cpp:280-286 / paired.cpp:166-171);  step() after every 64 candidates;  end().
+// Sink (all calls wave-uniform):  strand(id) -> 0 / 1;  begin(id, seed_i, position in the queue, tail);  add(k, gp, mm, in) per lane
+// and step (k = slot offset in the region, mm = 0xFFFFFFFF when the slot is beyond the region or fails the edge filters of
+// mapping.cpp:280-286 / paired.cpp:166-171; in = the slot belongs to the region: always inside [0, size) unless the item
+// is a `tail` item, whose candidates belong when their care characters >= 44 equal the read's -- the sink counts them
+// for the -b test, mapping.cpp:275-277);  step() after every 64 candidates;  end().
 template <int NW, bool DENSE, bool FITS, class Sink, int G = 1>
 __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand_base, const ItemQueue& q, uint32_t n_items,
                                             const uint32_t* s_start, Sink& sink, uint32_t n_big = 0) {
@@ -221,10 +290,22 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
   }
   uint4 hd = header(b0, true);
   // the current item, wave-uniform
-  uint32_t id = 0, l = 0, size = 1, rec0 = 0, len = 0, seed_i = 0, rd[NW], mk[NW];
+  // tail items (reads above 134 bases): the seed's care characters 44 .. seed_len - 1 sit at read offsets
+  // seed_i + 1 + 3 p = 133 .. 150, i.e. in words 8 and 9 of the read: a 64-bit mask over bases 128 .. 159
+  uint32_t id = 0, l = 0, size = 1, rec0 = 0, len = 0, seed_i = 0, tail = 0, rd[NW], mk[NW];
+  unsigned long long tm64 = 0;
   auto decode = [&](const uint4& h) {
     id = bcast(h.x, 0); l = bcast(h.y, 0); size = bcast(h.z, 0); rec0 = bcast(h.w, 0);
-    len = bcast(h.x, 1); seed_i = bcast(h.y, 1);
+    len = bcast(h.x, 1); seed_i = bcast(h.y, 1); tail = bcast(h.z, 1);
+    tm64 = 0;
+    if constexpr (NW > 8 && NW <= 10 && DENSE && kPat == 3) {  // only reads above 134 bases have seeds beyond the 44 characters of the keys
+      const uint32_t seed_len = (tail && len >= kMinReadLen) ? seed_len_of(seed_repeats(len)) : 0u;
+#pragma unroll
+      for (uint32_t p = kKeyWeight + kKeyChars; p < kMaxRepeats; ++p) {
+        const uint32_t o = seed_i + care_pos(p) - 128u;  // 5 .. 22 + seed shift: inside the 32 bases of words 8 and 9
+        tm64 |= p < seed_len ? 1ull << (2u * o) : 0ull;
+      }
+    }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const int a = 8 + w, c = 8 + NW + w;
@@ -259,7 +340,7 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
   };
   decode(hd);
   fetch_next();
-  sink.begin(id, seed_i, cur_i);
+  sink.begin(id, seed_i, cur_i, tail);
   if constexpr (DENSE && NW <= 10) {
     // G groups of 64 candidates per step (G = 4 for the queue of very large regions: a region of 5,000 candidates
     // taken 64 at a time is 79 dependent steps, and one such item set the duration of every launch)
@@ -308,7 +389,14 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
 #pragma unroll
         for (int w = 0; w <= NW; ++w) wv[w] = w < 11 ? first[w] : 0u;
         const uint32_t m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
-        sink.add(k, ok ? g : 0u, ok ? m : 0xFFFFFFFFu);
+        bool in = k < size;
+        if constexpr (NW > 8 && NW <= 10 && kPat == 3) {  // the candidate's care characters >= 44 against the read's (words 8, 9)
+          const uint32_t shv = 2 * (kWinLead - seed_i);
+          const uint32_t x8 = funnel_r(wv[8], wv[9], shv) ^ rd[8], x9 = funnel_r(wv[9], wv[10], shv) ^ rd[9];
+          const unsigned long long d = ((unsigned long long)(x9 | (x9 >> 1)) << 32) | (x8 | (x8 >> 1));
+          in = in && (d & tm64) == 0 && tail != 2u;  // (tail == 2: the region was proved larger than -b, tail_items_narrow)
+        }
+        sink.add(k, (ok && in) ? g : 0u, (ok && in) ? m : 0xFFFFFFFFu, in);
         sink.step();
       }
       if (last) {
@@ -317,7 +405,7 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
           decode(hdn);
           cur_i = ni;
           fetch_next();
-          sink.begin(id, seed_i, cur_i);
+          sink.begin(id, seed_i, cur_i, tail);
           base = 0;
         } else {
           done = true;
@@ -343,7 +431,7 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
       for (uint32_t base = 0; base < size; base += 64) {
         uint32_t gp[1], mm[1];
         coop_verify_groups<NW, 1>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, none, gp, mm);
-        sink.add(base + lane, gp[0], mm[0]);
+        sink.add(base + lane, gp[0], mm[0], base + lane < size);
         sink.step();
       }
       sink.end();
@@ -351,7 +439,7 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
       decode(hdn);
       cur_i = ni;
       fetch_next();
-      sink.begin(id, seed_i, cur_i);
+      sink.begin(id, seed_i, cur_i, tail);
     }
   }
 }

@@ -439,6 +439,7 @@ struct PeStage {
   uint32_t* flag;    // [j]: 1 = gone to the literal list, 2 = a probe outgrew its chunks or the pool
   ItemQueue q;       // 2 * ccap items (emptied after every seed); id = j | probe << 24, probe = 3 * strand + seed shift
   uint32_t ccap;     // staged reads per pass and mate
+  uint32_t defer_min;  // long seeds: key-equal ranges of more slots than this are narrowed by the verifier (0xFFFFFFFF: never)
 };
 
 template <int NW, bool LITERAL>
@@ -540,16 +541,22 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
     probe_entries(svm, pm);
     Lookup lp, lm;
     bool tail_p, tail_m;
-    probe_resolve_dual<(NW > 8)>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m);
+    bool defer_p = false, defer_m = false;  // long seeds: the verifier narrows the key-equal range (map_common.h DEFER)
+    if constexpr ((NW > 8) && (NW <= 10)) {
+      probe_resolve_dual<true, true>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m, &defer_p, &defer_m, ps.defer_min,
+                                     win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len));
+    } else {
+      probe_resolve_dual<(NW > 8)>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m);
+    }
     if constexpr (LITERAL) {  // LowerBound / UpperBound as the reference runs them (the lanes of a wave come sorted by iteration)
-      if (lit_p && need_p) { seed_lookup_ex(iv, svp, care, slot, span, seed_len_of(lr.repeats), lp, false); tail_p = false; }
-      if (lit_m && need_m) { seed_lookup_ex(iv, svm, care, slot, span, seed_len_of(lr.repeats), lm, false); tail_m = false; }
+      if (lit_p && need_p) { seed_lookup_ex(iv, svp, care, slot, span, seed_len_of(lr.repeats), lp, false); tail_p = false; defer_p = false; }
+      if (lit_m && need_m) { seed_lookup_ex(iv, svm, care, slot, span, seed_len_of(lr.repeats), lm, false); tail_m = false; defer_m = false; }
     }
     uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
     uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
     n_probe += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
-    if (size_p > b) size_p = 0;  // paired.cpp:161-163
-    if (size_m > b) size_m = 0;
+    if (size_p > b && !defer_p) size_p = 0;  // paired.cpp:161-163 (a deferred range: the verifier counts the region)
+    if (size_m > b && !defer_m) size_m = 0;
     uint32_t mk[NW];
     make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
     const uint32_t probe_p = seed_i, probe_m = 3 + seed_i;
@@ -581,8 +588,8 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
     }
     // mid regions (map_se.hip heavy stages): one pass for the lanes' '+' (or only '-') region, a second for the rest
     {
-      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kPeMidRegion) ? size_p : 0u;
-      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kPeMidRegion) ? size_m : 0u;
+      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kPeMidRegion && !defer_p) ? size_p : 0u;
+      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kPeMidRegion && !defer_m) ? size_m : 0u;
 #pragma unroll 1
       for (uint32_t pass = 0; pass < 2; ++pass) {
         const bool on_m = pass == 0 ? (nmid_p == 0 && nmid_m != 0) : (nmid_p != 0 && nmid_m != 0);
@@ -641,7 +648,7 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
       }
     }
     // larger regions: work items
-    const bool big_p = size_p > kPeMidRegion, big_m = size_m > kPeMidRegion;
+    const bool big_p = size_p > kPeMidRegion || defer_p, big_m = size_m > kPeMidRegion || defer_m;  // (a deferred range is an item whatever its size)
     const DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, big_p && win_usable<NW>(svp, lr.len));
     const DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, big_m && win_usable<NW>(svm, lr.len));
     {
@@ -649,7 +656,8 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
       const bool take2[2] = {big_p, big_m}, dense2[2] = {dn_p, dn_m};
       const uint32_t id2[2] = {j | (probe_p << 24), j | (probe_m << 24)}, l2[2] = {lp.reg.l, lm.reg.l}, size2[2] = {size_p, size_m};
       const uint32_t rec2[2] = {dn_p ? (uint32_t)dr_p.rec : kItemDenseNone, dn_m ? (uint32_t)dr_m.rec : kItemDenseNone};
-      item_append2<NW>(take2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, ps.q);  // one atomic for both strands' items
+      const bool tail2[2] = {defer_p, defer_m};
+      item_append2<NW>(take2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, ps.q, tail2);  // one atomic for both strands' items
       n_big += (big_p ? 1u : 0u) + (big_m ? 1u : 0u);
     }
     if (valid && !big_p) {  // an item's counts come from k_pe_verify
@@ -707,18 +715,21 @@ struct SurvivorSink {
   bool over;
   uint32_t gp_, mm_;
   uint32_t n_verified;
+  uint32_t b, tail, in_region;  // -b (paired.cpp:161-163) for tail items, whose region the lanes count here
   static __device__ __forceinline__ uint32_t strand(uint32_t id) { return ((id >> 24) & 7u) >= 3u ? 1u : 0u; }
-  __device__ __forceinline__ void begin(uint32_t id_, uint32_t seed_, uint32_t pos_) {
+  __device__ __forceinline__ void begin(uint32_t id_, uint32_t seed_, uint32_t pos_, uint32_t tail_) {
     id = id_;
     seed = seed_;
     pos = pos_;
+    tail = tail_;
+    in_region = 0;
     cnt = 0;
     bound = 0xFFFFFFFFu;
     cur = 0;
     over = false;
     hist[threadIdx.x & 63] = 0;
   }
-  __device__ __forceinline__ void add(uint32_t, uint32_t gp, uint32_t mm) { gp_ = gp; mm_ = mm; }
+  __device__ __forceinline__ void add(uint32_t, uint32_t gp, uint32_t mm, bool in) { gp_ = gp; mm_ = mm; in_region += in ? 1u : 0u; }
   // the c-th chunk of this probe: a number from the pool, noted in the probe's chunk table (wave-uniform result)
   __device__ __forceinline__ uint32_t take_chunk(uint32_t c) {
     const uint32_t j = id & 0xFFFFFFu, probe = (id >> 24) & 7u;
@@ -760,18 +771,32 @@ struct SurvivorSink {
   }
   __device__ __forceinline__ void end() {
     const uint32_t j = id & 0xFFFFFFu, probe = (id >> 24) & 7u;
+    const bool skip = tail && wave_sum_u32(in_region) > b;  // (uniform) the narrowed region exceeds -b: the probe pushes nothing
     if ((threadIdx.x & 63) == 0) {
-      ps.surv_n[(uint64_t)probe * ps.ccap + j] = cnt | 0x80000000u;
-      const uint32_t h0 = hist[0], h1 = h0 + hist[1];
+      ps.surv_n[(uint64_t)probe * ps.ccap + j] = (skip ? 0u : cnt) | 0x80000000u;
+      const uint32_t h0 = skip ? 0u : hist[0], h1 = skip ? 0u : h0 + hist[1];
       ps.cz[(uint64_t)probe * ps.ccap + j] = (h0 < 0xFFFFu ? h0 : 0xFFFFu) | ((h1 < 0xFFFFu ? h1 : 0xFFFFu) << 16);
       if (over) atomicOr(&ps.flag[j], 2u);
     }
   }
 };
 
+// the tail items of a stage bracketed before the verifier streams them (map_items.h tail_items_narrow)
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_pe_tail_narrow(IndexView iv, uint32_t strand_base, PeStage ps, uint32_t b) {
+  if constexpr (NW > 8 && NW <= 10) {
+    uint32_t n_big = *ps.q.big_n;
+    n_big = n_big < ps.q.big_cap ? n_big : ps.q.big_cap;
+    uint32_t n_items = ps.q.ctl[0];
+    n_items = n_items < ps.q.cap ? n_items : ps.q.cap;
+    tail_items_narrow<NW, SurvivorSink>(iv, strand_base, ps.q, n_items, n_big, b);
+  }
+}
+
 template <int NW, bool DENSE>
 __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_pe_verify(
-    IndexView iv, uint32_t strand_base, uint32_t max_mm, uint32_t top_k, unsigned long long* __restrict__ stats, PeStage ps) {
+    IndexView iv, uint32_t strand_base, uint32_t max_mm, uint32_t top_k, unsigned long long* __restrict__ stats, PeStage ps,
+    uint32_t b) {
   static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
   uint32_t n_big = DENSE ? *ps.q.big_n : 0u;
   n_big = n_big < ps.q.big_cap ? n_big : ps.q.big_cap;
@@ -785,7 +810,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
   __syncthreads();
   SurvivorSink sink;
   sink.ps = ps; sink.max_mm = max_mm; sink.top_k = top_k; sink.hist = s_hist[threadIdx.x >> 6]; sink.n_verified = 0;
-  sink.gp_ = 0; sink.mm_ = 0xFFFFFFFFu; sink.dense_kind = DENSE;
+  sink.gp_ = 0; sink.mm_ = 0xFFFFFFFFu; sink.dense_kind = DENSE; sink.b = b; sink.tail = 0; sink.in_region = 0;
   if (fits) item_stream<NW, DENSE, true>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
   else item_stream<NW, DENSE, false>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
   pe_flush(0u, 0u, sink.n_verified, 0u, stats);
@@ -1234,6 +1259,13 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 2 * w.ccap;
     ps.q.bigs = w.bigs[mate]; ps.q.big_n = ctl + 2; ps.q.big_cap = w.ccap / 8 + 64;
     ps.ccap = w.ccap;
+    static const uint32_t defer_min = [] {  // WALT_AMD_DEFER=0: never (A/B); =n: ranges of more than n slots (n >= the in-lane limit)
+      const char* e = getenv("WALT_AMD_DEFER");
+      if (!e) return (uint32_t)kSmallRegion;  // (measured: 4 / 8 / 16 -> 32.5 / 33.2 / 34.2 ms per 25 M 150-base reads)
+      const long v = atol(e);
+      return v <= 0 ? 0xFFFFFFFFu : (uint32_t)(v < (long)kSmallRegion ? (long)kSmallRegion : v);
+    }();
+    ps.defer_min = defer_min;
     uint32_t* fb_count = ctl + 26;
     uint32_t* fb_list = w.fb_list[mate];
     static const unsigned vg_dense = [] {
@@ -1248,9 +1280,11 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     }();
     const unsigned gs = grid_for(w.ccap) < kPersistentGrid ? grid_for(w.ccap) : kPersistentGrid;
     auto verify = [&]() {
+      if constexpr (NW > 8 && NW <= 10)
+        hipLaunchKernelGGL((k_pe_tail_narrow<NW>), dim3(256 * 4), dim3(kBlock), 0, stream, view, sb, ps, b);
       if constexpr (NW <= 10)
-        hipLaunchKernelGGL((k_pe_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps);
-      hipLaunchKernelGGL((k_pe_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps);
+        hipLaunchKernelGGL((k_pe_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps, b);
+      hipLaunchKernelGGL((k_pe_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps, b);
     };
     // the staged state holds ccap reads: a list is taken in rounds of ccap (the list's length is on the device: a
     // fixed number of rounds, the empty ones cost a few launches), the last round hands the rest to the list kernel

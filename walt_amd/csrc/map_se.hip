@@ -328,6 +328,7 @@ struct HeavyStage {
   uint32_t hcap;     // reads per chunk
   uint32_t first;    // heavy-list index of the chunk's first read
   uint32_t stage;    // 0..2: seed shift of the stage, 3: final fold
+  uint32_t defer_min;  // long seeds: key-equal ranges of more slots than this are narrowed by the verifier (0xFFFFFFFF: never)
 };
 template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
@@ -447,7 +448,11 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     probe_entries(svm, pm);
     Lookup lp, lm;
     bool tail_p, tail_m;
-    if constexpr (HEAVY) {
+    bool defer_p = false, defer_m = false;  // staged, long seeds: the verifier narrows the key-equal range (map_common.h DEFER)
+    if constexpr (HEAVY && STAGED && (NW > 8) && (NW <= 10)) {
+      probe_resolve_dual<true, true>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m, &defer_p, &defer_m, hs.defer_min,
+                                     win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len));
+    } else if constexpr (HEAVY) {
       probe_resolve_dual<(NW > 8)>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m);
     } else {
       probe_resolve<(NW > 8)>(svp, pp, care, lr.repeats, lp, tail_p);
@@ -458,8 +463,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
     uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
     ctr.probes += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
-    if (size_p > b) size_p = 0;  // mapping.cpp:275-277
-    if (size_m > b) size_m = 0;
+    if (size_p > b && !defer_p) size_p = 0;  // mapping.cpp:275-277 (a deferred range: the verifier counts the region)
+    if (size_m > b && !defer_m) size_m = 0;
     if (ablate & 1u) size_p = size_m = 0;
     if (!HEAVY && (size_p > kSmallRegion || size_m > kSmallRegion)) {  // a large region: the heavy pass verifies it
       heavy = true;
@@ -504,16 +509,17 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     //  * regions of up to kMidRegion candidates stay with their lane: all positions in one round of loads, then
     //    the genome windows four at a time -- five round trips for ALL such lanes of the wave;
     //  * only the larger ones take the whole wavefront.
-    DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, size_p > kMidRegion && win_usable<NW>(svp, lr.len));
-    DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, size_m > kMidRegion && win_usable<NW>(svm, lr.len));
+    // (a deferred range -- long seeds, map_common.h DEFER -- is an item whatever its size: only the verifier can narrow it)
+    DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, (size_p > kMidRegion || defer_p) && win_usable<NW>(svp, lr.len));
+    DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, (size_m > kMidRegion || defer_m) && win_usable<NW>(svm, lr.len));
     // mid regions: a lane usually has one, on either strand, so the strands are not taken in turn: in the first
     // pass every lane works on its '+' mid region, or on its '-' one if it has no '+'; the second pass (skipped
     // unless some lane has both) takes the remaining '-' ones.  All loads of a round are unconditional (idle
     // candidates read the first words of the genome): a load under `if (candidate ok)` is waited for at the end of
     // its branch, which made the four candidates of a round four round trips.
     {
-      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kMidRegion) ? size_p : 0u;
-      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kMidRegion) ? size_m : 0u;
+      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kMidRegion && !defer_p) ? size_p : 0u;
+      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kMidRegion && !defer_m) ? size_m : 0u;
 #pragma unroll 1
       for (uint32_t pass = 0; pass < 2; ++pass) {
         const bool on_m = pass == 0 ? (nmid_p == 0 && nmid_m != 0) : (nmid_p != 0 && nmid_m != 0);
@@ -574,14 +580,15 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       }
     }
     if constexpr (STAGED) {  // both strands' large regions become work items: one atomic for the two (map_items.h item_append2)
-      const bool big2[2] = {size_p > kMidRegion, size_m > kMidRegion};
+      const bool big2[2] = {size_p > kMidRegion || defer_p, size_m > kMidRegion || defer_m};
       const bool dense2[2] = {big2[0] && dr_p.hi > dr_p.lo, big2[1] && dr_m.hi > dr_m.lo};
       const uint32_t id2[2] = {j, j | (1u << 31)}, l2[2] = {lp.reg.l, lm.reg.l}, size2[2] = {size_p, size_m};
       const uint32_t rec2[2] = {dense2[0] ? (uint32_t)dr_p.rec : kItemDenseNone, dense2[1] ? (uint32_t)dr_m.rec : kItemDenseNone};
       ItemQueue q;
       q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
       q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
-      item_append2<NW>(big2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, q);
+      const bool tail2[2] = {defer_p, defer_m};
+      item_append2<NW>(big2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, q, tail2);
       if (big2[0]) { ++ctr.big; pend_p = true; }
       if (big2[1]) { ++ctr.big; pend_m = true; }
     }
@@ -865,28 +872,48 @@ __device__ __forceinline__ uint4 lane_best_reduce(const LaneBest& a) {
 struct SummarySink {
   uint4* sums;
   uint32_t hcap;
-  uint32_t id, seed_i;
+  uint32_t b;        // -b: a region of more candidates is skipped (mapping.cpp:275-277); tested here for tail items
+  uint32_t id, seed_i, tail;
   LaneBest acc;
+  uint32_t in_region;  // this lane's candidates that belong to the region (tail items: whose care characters >= 44 match)
   uint32_t n_verified;
   static __device__ __forceinline__ uint32_t strand(uint32_t id) { return id >> 31; }
-  __device__ __forceinline__ void begin(uint32_t id_, uint32_t seed_, uint32_t) {
-    id = id_; seed_i = seed_;
+  __device__ __forceinline__ void begin(uint32_t id_, uint32_t seed_, uint32_t, uint32_t tail_) {
+    id = id_; seed_i = seed_; tail = tail_;
     acc = {0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    in_region = 0;
   }
-  __device__ __forceinline__ void add(uint32_t k, uint32_t gp, uint32_t mm) {
+  __device__ __forceinline__ void add(uint32_t k, uint32_t gp, uint32_t mm, bool in) {
     n_verified += mm != 0xFFFFFFFFu ? 1u : 0u;
+    in_region += in ? 1u : 0u;
     lane_best_add(acc, k, gp, mm);
   }
   __device__ __forceinline__ void step() {}
   __device__ __forceinline__ void end() {
-    const uint4 res = lane_best_reduce(acc);
+    uint4 res = lane_best_reduce(acc);
+    if (tail && wave_sum_u32(in_region) > b) res = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // (uniform) the narrowed region exceeds -b
     if ((threadIdx.x & 63) == 0) sums[(uint64_t)(2 * seed_i + (id >> 31)) * hcap + (id & 0x7FFFFFFFu)] = res;
   }
 };
 
+// the tail items of a stage bracketed before the verifier streams them (map_items.h tail_items_narrow)
+template <int NW>
+__global__ __launch_bounds__(kBlock) void k_se_tail_narrow(IndexView iv, uint32_t strand_base, HeavyStage hs, uint32_t b) {
+  if constexpr (NW > 8 && NW <= 10) {
+    ItemQueue q;
+    q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
+    q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
+    uint32_t n_big = *q.big_n;
+    n_big = n_big < q.big_cap ? n_big : q.big_cap;
+    uint32_t n_items = q.ctl[0];
+    n_items = n_items < q.cap ? n_items : q.cap;
+    tail_items_narrow<NW, SummarySink>(iv, strand_base, q, n_items, n_big, b);
+  }
+}
+
 template <int NW, bool DENSE, int G = 1>
 __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
-    IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs) {
+    IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs, uint32_t b) {
   static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
   ItemQueue q;
   q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
@@ -901,7 +928,7 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
     for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
   __syncthreads();
   SummarySink sink;
-  sink.sums = hs.sums; sink.hcap = hs.hcap; sink.n_verified = 0;
+  sink.sums = hs.sums; sink.hcap = hs.hcap; sink.n_verified = 0; sink.b = b; sink.tail = 0; sink.in_region = 0;
   if (fits) item_stream<NW, DENSE, true, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big);
   else item_stream<NW, DENSE, false, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big);
   flush_counters({0u, sink.n_verified, 0u}, 0u, stats);
@@ -1053,6 +1080,13 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     hs.items = hs.sums + (uint64_t)6 * hcap;  // 2 * hcap items of item_quads<NW>() quads
     hs.giants = hs.items + (uint64_t)2 * hcap * item_quads<NW>();
     hs.hcap = hcap;
+    static const uint32_t defer_min = [] {  // WALT_AMD_DEFER=0: never (A/B); =n: ranges of more than n slots (n >= the in-lane limit)
+      const char* e = getenv("WALT_AMD_DEFER");
+      if (!e) return (uint32_t)kSmallRegion;  // (measured: 4 / 8 / 16 -> 32.5 / 33.2 / 34.2 ms per 25 M 150-base reads)
+      const long v = atol(e);
+      return v <= 0 ? 0xFFFFFFFFu : (uint32_t)(v < (long)kSmallRegion ? (long)kSmallRegion : v);
+    }();
+    hs.defer_min = defer_min;  // WALT_AMD_DEFER=0 (A/B): every range narrowed by lit_region in the stage kernel, as before round 3
     uint32_t* const ctl0 = heavy_area;
     static const unsigned vg_dense = [] {
       int nb = 0;
@@ -1089,10 +1123,12 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                              heavy_list, 0u, nullptr, hs);
         mark(1);
         if (stage == 3) break;
+        if constexpr (NW > 8 && NW <= 10)
+          hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(256 * 8), dim3(kBlock), 0, stream, view, strand_base, hs, b);
         if constexpr (NW <= 10) {
-          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
+          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, strand_base, stats, hs, b);
         }
-        hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, strand_base, stats, hs);
+        hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, strand_base, stats, hs, b);
         mark(2);
       }
     }
