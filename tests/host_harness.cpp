@@ -302,7 +302,19 @@ int hh_region_check(void* hp, const char* bases, const uint64_t* offsets, uint32
       for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
         const uint32_t* care = &rec[1 + NW + seed_i * kPerSeedWords];
         ++out4[0];
-        if (probe_is_dangerous(sv, care, seed_len)) { ++out4[2]; continue; }
+        if (probe_is_dangerous(sv, care, seed_len)) {
+          // the literal route: from the level the danger starts at (core.h probe_danger_level) against the whole bucket
+          ++out4[2];
+          Lookup from_level, whole;
+          literal_from_level_flag() = true;
+          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, from_level, false);
+          literal_from_level_flag() = false;
+          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, whole, false);
+          literal_from_level_flag() = true;
+          const bool e1 = from_level.reg.l > from_level.reg.u, e2 = whole.reg.l > whole.reg.u;
+          if (e1 != e2 || (!e1 && (from_level.reg.l != whole.reg.l || from_level.reg.u != whole.reg.u))) ++out4[1];
+          continue;
+        }
         Lookup fast;
         seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, fast, true);
         Region lit = empty_region();

@@ -470,16 +470,25 @@ WALT_HD uint32_t outl_dir_hash(uint32_t h) {
   uint32_t x = h * 0x9E3779B1u;
   return x ^ (x >> 15);
 }
-WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
+// 0: the probe is safe (directory / key search).  Otherwise the literal LowerBound / UpperBound search is needed, and
+// the value says from where: kKeyWeight (12) = over the whole bucket from the first character (a BAD bucket, or an
+// outlier of the probe's prefix group right behind the hash characters), or q_min > 12 = the smallest
+// first-missing-character index among ALL outliers that share the probe's characters 12..q-1.  Up to character
+// q_min - 1 the reference's bisection only ever compares entries on characters that are real AND in sorted order
+// (an outlier with q < q_min that the probe does not share differs from the probe before its q, where it is placed
+// correctly; one with q >= q_min is compared on real characters only), so after character q_min - 1 its range is the
+// equal range of the probe's first q_min - 12 key characters -- one masked-key search -- and only from q_min on does
+// the outcome depend on the outliers' real bytes (round 3; DESIGN.md section 4, "literal search from q_min").
+WALT_HD uint32_t probe_danger_level(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
   const uint32_t h = care[0] >> 8;
-  if (bucket_is_bad(sv, h)) return true;
+  if (bucket_is_bad(sv, h)) return kKeyWeight;
   uint32_t lo = 0, hi = sv.n_outl;  // first outlier of bucket h
   if (sv.outl_dir) {
     // one or two loads instead of log2(n_outl) dependent ones (this test runs for every probe of pass 2)
     uint32_t slot = outl_dir_hash(h) & sv.outl_dir_mask;
     for (;;) {
       const uint32_t tag = sv.outl_dir[2 * slot];
-      if (tag == 0) return false;  // no outlier in this bucket
+      if (tag == 0) return 0;  // no outlier in this bucket
       if (tag == h + 1) { lo = sv.outl_dir[2 * slot + 1]; break; }
       slot = (slot + 1) & sv.outl_dir_mask;
     }
@@ -491,11 +500,14 @@ WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint
   }
   const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
   const uint64_t T = target_key(care);
+  bool dangerous = false;
+  uint32_t q_min = 0xFFFFFFFFu;
   for (; lo < sv.n_outl && sv.outl[lo].h == h; ++lo) {
     const Outlier o = sv.outl[lo];
     if (o.q >= lim) continue;  // the search never compares a character this entry lacks
     const uint64_t k = ((uint64_t)o.key_hi << 32) | o.key_lo;
     if (((T ^ k) & key_mask(o.q - kKeyWeight)) == 0) {
+      q_min = o.q < q_min ? o.q : q_min;
       // The probe shares the outlier's characters 12..q-1.  The outlier sits at the START of that group
       // (makedb ranks its missing character q below every base) while the search reads a real byte x there.
       // If the probe's character q is GREATER than x, the outlier cannot matter: LowerBound's bisection
@@ -506,10 +518,13 @@ WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint
       // coincide in their first dir_bits, the outlier heads the slot as an entry smaller than the target,
       // which the key scan counts as such).  Anything else (c <= x) stays literal.  DESIGN.md section 4.
       const uint32_t sh = 2 * (kKeyWeight + kKeyChars - 1 - o.q);
-      if (!(((T >> sh) & 3u) > ((k >> sh) & 3u))) return true;
+      if (!(((T >> sh) & 3u) > ((k >> sh) & 3u))) dangerous = true;
     }
   }
-  return false;
+  return dangerous ? q_min : 0u;
+}
+WALT_HD bool probe_is_dangerous(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
+  return probe_danger_level(sv, care, seed_len) != 0;
 }
 
 // Full seed lookup for one (read, strand, seed shift): the region
@@ -879,6 +894,14 @@ WALT_HD void slot_scan_more(const StrandView& sv, uint32_t lo, uint32_t ne, uint
   pos[0] = p0; pos[1] = p1; pos[2] = p2; pos[3] = p3;
 }
 
+// (A/B and the harness's cross-check: 0 = every dangerous probe searched literally over its whole bucket, as before round 3)
+#if defined(__HIP_DEVICE_COMPILE__)
+WALT_HD bool literal_from_level() { return true; }
+#else
+inline bool& literal_from_level_flag() { static bool on = true; return on; }
+inline bool literal_from_level() { return literal_from_level_flag(); }
+#endif
+
 struct Lookup {
   Region reg;
   uint32_t npos;              // pos[0..npos) are the genome positions of slots reg.l, reg.l+1, ...
@@ -893,11 +916,25 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
   // care characters behind the 12 hashed ones; none for the shortest reads of patterns 5 / 7 (seed_len 10 / 8:
   // IndexRegion's loop over [F2SEEDKEYWEIGHT, seed_len) is empty there and the region is the whole bucket)
   uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0u;
-  if (!known_good && probe_is_dangerous(sv, care, seed_len)) {
-    uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
-    if (first == second) return;                         // mapping.cpp:271-272
-    out.reg = lit_region(sv, care, kKeyWeight, seed_len, first, second - 1);
-    return;
+  if (!known_good) {
+    const uint32_t level = probe_danger_level(sv, care, seed_len);
+    if (level) {
+      uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
+      if (first == second) return;                         // mapping.cpp:271-272
+      uint32_t l0 = first, u0 = second - 1, p0 = kKeyWeight;
+      if (level > kKeyWeight && literal_from_level()) {
+        // the reference's range after the characters in front of `level`: the equal range of the probe's first
+        // level - 12 key characters in the bucket (probe_danger_level); it holds the outliers that made the probe
+        // dangerous, so it is never empty
+        const uint64_t Mq = key_mask(level - kKeyWeight), Tq = target_key(care) & Mq;
+        uint32_t a0 = 0, b0 = 0;
+        const bool found = sv.fen[0] != nullptr ? slot_fence_search(sv, first, second, Tq, Mq, a0, b0)
+                                                : slot_kary_search(sv, first, second, Tq, Mq, a0, b0);
+        if (found) { l0 = a0; u0 = b0; p0 = level; }
+      }
+      out.reg = lit_region(sv, care, p0, seed_len, l0, u0);
+      return;
+    }
   }
   (void)iv;
   const uint32_t* dp = sv.dir + (uint32_t)(slot - 1u);  // slot S = 2^32 is held as 0 (dir_top)

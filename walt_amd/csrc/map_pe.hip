@@ -1175,13 +1175,22 @@ struct PeWorkspace {
 // reads of an hg19-like genome: four rounds; the state of a staged read is 2.2 KB and the paired-end index leaves
 // little room -- with rounds of an eighth the survivor pool had to shrink and a tenth of the staged reads fell
 // back to the list kernel: 359 ms against 315), all of it when the pass is small
+// rounds a pass takes its staged list in (WALT_AMD_PE_ROUNDS = 1, 2 or 4; the staged state grows accordingly)
+static uint32_t pe_rounds() {
+  static const uint32_t r = [] {
+    const char* e = getenv("WALT_AMD_PE_ROUNDS");
+    const long v = e ? atol(e) : 4;
+    return (uint32_t)(v == 1 || v == 2 ? v : 4);
+  }();
+  return r;
+}
 static uint32_t pe_stage_cap(uint32_t chunk) {
   if (const char* e = getenv("WALT_AMD_PE_STAGE_CAP")) {  // test hook: several rounds and the list-kernel fallback on a small batch
     const long v = atol(e);
     if (v > 0) return (uint32_t)align_up((uint64_t)v, 64);
   }
   if (chunk <= 65536) return chunk ? chunk : 1;
-  const uint32_t c = chunk / 16;
+  const uint32_t c = chunk / (4 * pe_rounds());  // the rounds together hold a quarter of the pass
   return (uint32_t)align_up(c > 65536 ? c : 65536, 64);
 }
 
@@ -1288,7 +1297,7 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     };
     // the staged state holds ccap reads: a list is taken in rounds of ccap (the list's length is on the device: a
     // fixed number of rounds, the empty ones cost a few launches), the last round hands the rest to the list kernel
-    constexpr uint32_t kRounds = 4;  // a quarter of the pass
+    const uint32_t kRounds = pe_rounds();  // together a quarter of the pass
     uint32_t* big_count = ctl + 1;  // reads of the round with more than kPushSmall survivors
     uint32_t* big_list = w.big_list[mate];
     auto clear_round = [&]() {  // pool + queue, the push kernels' list
