@@ -588,6 +588,7 @@ def calibration_leg(cx, local, cores, n=100_000, read_len=100, max_mm=6, b=5000)
 def pe_leg(cx, idx, d1, d2, d_off, n, read_len, max_mm, b, top_k, frag_range, steps, warmup, timed_barrier=True):
     torch, walt_amd = cx.torch, cx.walt_amd
     dev = cx.dev
+    torch.cuda.empty_cache()  # the read generator's cached blocks back to the device: the library sizes its passes by what is free
     d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
     d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
     d_ws = torch.empty(walt_amd.lib().walt_pe_workspace_bytes(n, read_len, top_k), dtype=torch.uint8, device=dev)

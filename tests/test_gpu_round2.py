@@ -142,6 +142,7 @@ def test_gpu_staged_paths_and_their_fallbacks_vs_oracle(wa, repeat_case, mode, m
     else:
         monkeypatch.setenv("WALT_AMD_HEAVY_CHUNK", "320")
         monkeypatch.setenv("WALT_AMD_PE_STAGE_CAP", "128")
+        monkeypatch.setenv("WALT_AMD_PE_ROUNDS", "4")  # (a small index leaves the device roomy: one round would be the default)
     idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_bits=-1)
     rng = random.Random(11)
     for conv, lens, m, b in (("CT", [100], 6, 5000), ("GA", [150], 10, 300), ("CT", [60, 100, 128, 150, 200], 6, 5000)):

@@ -260,7 +260,9 @@ int choose_dir_bits(uint64_t max_index_size, int requested, int n_strands, uint6
   if (B == 31 && max_index_size > (1ull << 31)) {
     const uint64_t strand = 12ull * max_index_size + (4ull << 32) + max_index_size / 3 + (80ull << 20) +
                             8ull * max_index_size / 15;  // entries, directory, genome and bitmaps, small tables, fence keys
-    const uint64_t resident = (uint64_t)n_strands * strand + (30ull << 30);
+    // (all four strands = paired-end use: the roomy paired-end workspace and its batch want ~80 GB, map_pe.hip pe_roomy;
+    // 2^31 slots cost the paired-end pass 1 a per cent, the larger passes and single rounds win ten)
+    const uint64_t resident = (uint64_t)n_strands * strand + (n_strands >= 4 ? 90ull << 30 : 30ull << 30);
     const uint64_t build_peak = (uint64_t)(n_strands - 1) * strand + 28ull * max_index_size;
     if (resident <= device_bytes && build_peak <= device_bytes) B = 32;
   }

@@ -40,10 +40,25 @@ namespace walt {
 // wavefront), so their cost per pass is nearly constant: large passes amortise it.  The ranked lists
 // (2 x top_k x 12 B per pair) bound the pass by a ~10 GB workspace budget.
 constexpr uint32_t kPeChunkMax = 1u << 23;
+// Larger passes taken in fewer rounds when the device has the room (decided ONCE per process, when the first
+// workspace is sized -- the launcher and walt_pe_workspace_bytes must agree): 0 = 8 M-pair passes, staged lists in four
+// rounds (24 GB of workspace at -k 50); 1 = 10 M-pair passes in one round (50 GB: every launch of the staged
+// kernels gets four times the items and the passes are a third fewer -- 273 -> 247 ms per 50 M pairs).  An hg19-scale
+// four-strand index with 2^31-slot directories leaves that room on a 288 GB device (device_index.hip choose_dir_bits).
+static int pe_roomy() {
+  if (const char* e = getenv("WALT_AMD_PE_ROOMY")) return atoi(e) != 0 ? 1 : 0;  // (tests / A/B: read at every call, like the other hooks)
+  static const int roomy = [] {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    return free_b >= (56ull << 30) ? 1 : 0;  // the workspace (~50 GB at -k 50), the pair records, some slack
+  }();
+  return roomy;
+}
 static inline uint32_t pe_chunk_pairs(uint32_t n, uint32_t top_k) {
-  const uint64_t budget = 10ull << 30;
+  const uint64_t budget = pe_roomy() ? 12ull << 30 : 10ull << 30;
   uint64_t c = budget / ((uint64_t)(top_k ? top_k : 1) * 2 * sizeof(Candidate));
-  if (c > kPeChunkMax) c = kPeChunkMax;
+  const uint64_t cmax = pe_roomy() ? 10000000ull : kPeChunkMax;
+  if (c > cmax) c = cmax;
   if (c < (1u << 16)) c = 1u << 16;
   if (const char* e = getenv("WALT_AMD_PE_CHUNK")) {  // test hook: force several passes on a small batch
     const long v = atol(e);
@@ -1177,12 +1192,9 @@ struct PeWorkspace {
 // back to the list kernel: 359 ms against 315), all of it when the pass is small
 // rounds a pass takes its staged list in (WALT_AMD_PE_ROUNDS = 1, 2 or 4; the staged state grows accordingly)
 static uint32_t pe_rounds() {
-  static const uint32_t r = [] {
-    const char* e = getenv("WALT_AMD_PE_ROUNDS");
-    const long v = e ? atol(e) : 4;
-    return (uint32_t)(v == 1 || v == 2 ? v : 4);
-  }();
-  return r;
+  const char* e = getenv("WALT_AMD_PE_ROUNDS");  // (read at every call, like WALT_AMD_PE_STAGE_CAP: a caller sizes and launches under one setting)
+  const long v = e ? atol(e) : (pe_roomy() ? 1 : 4);
+  return (uint32_t)(v == 1 || v == 2 ? v : 4);
 }
 static uint32_t pe_stage_cap(uint32_t chunk) {
   if (const char* e = getenv("WALT_AMD_PE_STAGE_CAP")) {  // test hook: several rounds and the list-kernel fallback on a small batch
@@ -1394,7 +1406,9 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   WALT_HIP(hipMemsetAsync(w.err + 64, 0, 128 * sizeof(uint32_t), stream));
   // The two mates are independent until the merge; mate 2 runs on a second stream so that its
   // throughput-bound pass 1 overlaps mate 1's list kernels (a few slow reads, mostly idle CUs) and vice versa.
-  hipStream_t stream_b = idx->pe_stream[slot][1];
+  // WALT_AMD_PE_SERIAL=1 (profiling): both mates and every pass on one stream, so that a kernel's duration is its own
+  static const bool serial = [] { const char* e = getenv("WALT_AMD_PE_SERIAL"); return e && atoi(e) != 0; }();
+  hipStream_t stream_b = serial ? stream : idx->pe_stream[slot][1];
   WALT_HIP(hipEventRecord(idx->pe_fork[slot], stream));
   WALT_HIP(hipStreamWaitEvent(stream_b, idx->pe_fork[slot], 0));
   hipStream_t user_stream = stream;
@@ -1481,7 +1495,8 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
   if ((rc = pe_streams(idx))) return rc;
   // Passes alternate between two pipeline slots (own workspace and streams), so the latency-bound list
   // kernels and the merge of one pass run beside the throughput-bound pass 1 of the next.
-  const bool two = n > chunk;
+  static const bool serial = [] { const char* e = getenv("WALT_AMD_PE_SERIAL"); return e && atoi(e) != 0; }();
+  const bool two = n > chunk && !serial;
   PeWorkspace w[2];
   w[0] = carve_pe(d_workspace, chunk, nw, top_k, max_read_len);
   w[1] = two ? carve_pe(static_cast<uint8_t*>(d_workspace) + w[0].total_bytes, chunk, nw, top_k, max_read_len) : w[0];
