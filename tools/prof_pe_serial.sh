@@ -15,8 +15,8 @@ import csv, glob, sys, collections
 out = sys.argv[1]
 ms = {}
 for ln in open(out + "/trace_sum.txt"):
-    p = ln.split()
-    ms[p[-1].split("<")[0] + ("<" + p[-1].split("<")[1] if "<" in p[-1] else "")] = (float(p[0]), float(p[2]))
+    p = ln.split(None, 4)
+    ms[p[4].strip()] = (float(p[0]), float(p[2]))
 def pmc(sub):
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(out + "/" + sub + "/*counter_collection.csv"):

@@ -353,7 +353,11 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
   }
   const uint32_t total = hsize + n_minus;
   const bool to_cplx = !deferred && valid && (cplx || total > kFastCands || total >= top_k);
-  wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, bloom_count, bloom_list);
+  if (bloom_list == cplx_list) {  // (uniform) the staged path: filter hits, tagged, share the complex reads' list and its buffer
+    wavelist_append(wl_cplx, deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, cplx_count, cplx_list);
+  } else {
+    wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, bloom_count, bloom_list);
+  }
   wavelist_append(wl_cplx, to_cplx, r, cplx_count, cplx_list);  // a fifth of the reads: buffered (map_common.h WaveList)
   if (!deferred && !to_cplx && valid) {
     // the heap never fills: plain pushes in the reference's order, then the drain of paired.cpp:685-692
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
 constexpr uint32_t kPeMidRegion = 16;  // regions up to this size are verified by their own lane
 constexpr uint32_t kPeChunkEnts = 64;  // survivors per chunk of the pool
 constexpr uint32_t kPeChunks = 8;      // chunks a probe may take (512 survivors); more: the list kernel maps the read
+constexpr uint32_t kPoolGrab = 8;      // pool chunks a wavefront of k_pe_verify takes per atomic (SurvivorSink::take_chunk)
 
 // Survivors {position, mismatches} of probe p of staged read j.  A region verified in place has at most
 // kPeMidRegion of them: inl[(p * kPeMidRegion + k) * ccap + j].  An item's survivors go to chunks of kPeChunkEnts
@@ -731,6 +736,7 @@ struct SurvivorSink {
   uint32_t gp_, mm_;
   uint32_t n_verified;
   uint32_t b, tail, in_region;  // -b (paired.cpp:161-163) for tail items, whose region the lanes count here
+  uint32_t grab_next, grab_end;  // this wavefront's stock of pool chunks (wave-uniform): kPoolGrab per visit to the pool's counter
   static __device__ __forceinline__ uint32_t strand(uint32_t id) { return ((id >> 24) & 7u) >= 3u ? 1u : 0u; }
   __device__ __forceinline__ void begin(uint32_t id_, uint32_t seed_, uint32_t pos_, uint32_t tail_) {
     id = id_;
@@ -750,11 +756,22 @@ struct SurvivorSink {
     const uint32_t j = id & 0xFFFFFFu, probe = (id >> 24) & 7u;
     uint32_t v = 0;
     const bool fixed = c == 0 && dense_kind && pos < ps.static_n;
+    // A chunk from the dynamic part: the pool's counter is ONE address, and the device serves ~10^8 atomics per second
+    // on one address -- twelve million chunks a step, one atomic each, were 120 ms of queueing and the whole duration
+    // of this kernel (round 3: 2.3 TB/s of records against the single-end verifier's 6.3).  A wavefront now takes
+    // kPoolGrab chunks per visit and hands them out itself; what it has left at the end is lost to the pass (the pool
+    // is sized with that: kPoolGrab - 1 chunks per wavefront at most).
+    if (!fixed && grab_next == grab_end) {  // (uniform)
+      uint32_t g = 0;
+      if ((threadIdx.x & 63) == 0) g = atomicAdd(ps.pool_next, kPoolGrab);
+      grab_next = bcast(g, 0);
+      grab_end = grab_next + kPoolGrab;
+    }
+    if (!fixed) v = 3 * ps.static_n + grab_next++;
+    else v = seed * ps.static_n + pos;
     if ((threadIdx.x & 63) == 0) {
-      v = fixed ? seed * ps.static_n + pos : 3 * ps.static_n + atomicAdd(ps.pool_next, 1u);
       if (c < kPeChunks && v < ps.pool_chunks) ps.chunk[((uint64_t)probe * kPeChunks + c) * ps.ccap + j] = v;
     }
-    v = fixed ? seed * ps.static_n + pos : bcast(v, 0);
     if (c >= kPeChunks || v >= ps.pool_chunks) { over = true; v = 0; }
     return v;
   }
@@ -826,6 +843,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
   SurvivorSink sink;
   sink.ps = ps; sink.max_mm = max_mm; sink.top_k = top_k; sink.hist = s_hist[threadIdx.x >> 6]; sink.n_verified = 0;
   sink.gp_ = 0; sink.mm_ = 0xFFFFFFFFu; sink.dense_kind = DENSE; sink.b = b; sink.tail = 0; sink.in_region = 0;
+  sink.grab_next = sink.grab_end = 0;
   if (fits) item_stream<NW, DENSE, true>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
   else item_stream<NW, DENSE, false>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
   pe_flush(0u, 0u, sink.n_verified, 0u, stats);
@@ -1055,13 +1073,23 @@ __global__ void k_pe_merge(IndexView iv, const Candidate* __restrict__ ranked1, 
     }
     out[r] = pr;
   }
+  // heavy pairs -> list: ONE atomic per block (6 % of the pairs of a repeat-rich genome are heavy, i.e. some lane of
+  // nearly every wavefront: an atomic per wavefront was 150,000 on one address per launch, most of its duration)
+  __shared__ uint32_t s_cnt[kBlock / 64], s_base;
   const unsigned long long hv = __ballot(heavy);
-  if (hv) {
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == (uint32_t)(__ffsll((long long)hv) - 1)) base = atomicAdd(heavy_count, (uint32_t)__popcll(hv));
-    base = bcast(base, __ffsll((long long)hv) - 1);
-    if (heavy) heavy_list[base + (uint32_t)__popcll(hv & ((1ull << lane) - 1ull))] = r;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(hv);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < blockDim.x / 64; ++k) tot += s_cnt[k];
+    s_base = tot ? atomicAdd(heavy_count, tot) : 0u;
+  }
+  __syncthreads();
+  if (heavy) {
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < wv; ++k) before += s_cnt[k];
+    heavy_list[s_base + before + (uint32_t)__popcll(hv & ((1ull << lane) - 1ull))] = r;
   }
 }
 
@@ -1225,7 +1253,10 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
   for (int m = 0; m < 2; ++m) w.codes2[m] = reinterpret_cast<uint32_t*>(take(codes2_words((uint64_t)chunk * max_read_len) * 4 + 64));
   for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
   w.ccap = pe_stage_cap(chunk);
-  w.pool_chunks = w.ccap * 2 > 4096 ? w.ccap * 2 : 4096;  // 128 survivors per staged read on average; three quarters static
+  // 128 survivors per staged read on average (192 when the device is roomy); three quarters static, the dynamic
+  // quarter handed out kPoolGrab chunks at a time
+  const uint32_t per_read = pe_roomy() ? 3u : 2u;
+  w.pool_chunks = w.ccap * per_read > 8192 ? w.ccap * per_read : 8192;
   const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
   for (int m = 0; m < 2; ++m) {
     w.fb_list[m] = reinterpret_cast<uint32_t*>(take(w.stride * 4 + 64));
