@@ -243,6 +243,7 @@ static void out_single_sam(const walt_best_match& bm, View name, View seq, View 
   }
 }
 
+static double g_t_main = 0;  // start of main (timeline under -v)
 static int host_threads(const Options& o) { return o.threads > 0 ? o.threads : hostio::effective_cpus(); }
 static double now_s() {
   struct timespec ts;
@@ -318,12 +319,22 @@ static void process_se(const Options& o, const string& reads_file, const string&
   const int T = host_threads(o);
   const int T_bg = std::max(1, T / 4);  // the loader's share while a batch is being formatted
   double t0 = now_s();
+  // the first batch is read WHILE the index is opened (seconds of file reads and kernels that leave most host cores
+  // idle); the loader's N draws are the only rand() calls of the process, as before
+  hostio::FastqReader rd;
+  Batch bt[2];
+  Prefetch first;
+  double t_open_reads = 0;
+  first.start([&]() {
+    const double t_o0 = now_s();
+    rd.open(reads_file, std::max(1, T / 2));
+    t_open_reads = now_s() - t_o0;
+    rd.load(o.batch_size, o.adaptor, bt[0]);
+  });
   DeviceSet dev;
   dev.open(o, o.ag ? WALT_STRANDS_GA : WALT_STRANDS_CT);
   double t_index = now_s() - t0, t_load = 0, t_map = 0, t_out = 0, t_write = 0;
   GenomeInfo g = genome_of(dev.idx[0]);
-  hostio::FastqReader rd;
-  rd.open(reads_file, T);
   OutFile fout;
   if (!fout.open_append(out_file)) die("cannot open input file " + out_file);
   SideFiles side;
@@ -331,7 +342,6 @@ static void process_se(const Options& o, const string& reads_file, const string&
   SeCounts st;
   if (o.verbose) std::cerr << "input_file: " << reads_file << std::endl << "output_file: " << out_file << std::endl;
   if (o.sam) { string h = sam_head(g); fout.write(h.data(), h.size()); }
-  Batch bt[2];
   walt_best_match* res = nullptr;
   size_t res_cap = 0;
   vector<Sink> sinks((size_t)T * kSinks);
@@ -341,7 +351,8 @@ static void process_se(const Options& o, const string& reads_file, const string&
   // waiting for the writer).
   Prefetch pre;
   t0 = now_s();
-  rd.load(o.batch_size, o.adaptor, bt[0]);
+  first.wait();  // what is still left of the first batch's ingest
+  rd.threads = T;
   t_load += now_s() - t0;
   for (int cur = 0;; cur ^= 1) {
     Batch& b = bt[cur];
@@ -413,10 +424,12 @@ static void process_se(const Options& o, const string& reads_file, const string&
     mf.write(ms.p, ms.n);
     mf.close();
   }
+  const double t_c0 = now_s();
   dev.close();
   if (o.verbose)
     fprintf(stderr, "[walt_amd: %d host threads, %zu GPU(s); index %.2f s, ingest not hidden behind the previous batch %.2f s, map %.2f s, "
-            "format %.2f s, write %.2f s]\n", T, dev.size(), t_index, t_load, t_map, t_out, t_write);
+            "format %.2f s, write %.2f s; opening the reads %.2f s, closing the index %.2f s, since main %.2f s]\n", T, dev.size(), t_index,
+            t_load, t_map, t_out, t_write, t_open_reads, now_s() - t_c0, now_s() - g_t_main);
 }
 
 // ---------------------------------------------------------------- paired-end writers
@@ -704,6 +717,7 @@ static void process_pe(const Options& o, const string& file1, const string& file
 }
 
 int main(int argc, const char** argv) {
+  g_t_main = now_s();
   try {
     if (argc == 1) {
       fprintf(stderr, "Usage: walt -i <index> -r <reads> | -1 <reads1> -2 <reads2> -o <out> [-m -N -a -u -C -A -P -b -k -L -sam -v -t -g <gpu>[,<gpu>...]]\n");
@@ -727,6 +741,7 @@ int main(int argc, const char** argv) {
     size_t k = 0;
     for (auto& f : se) process_se(o, f, outs[k++]);
     for (size_t i = 0; i < p1.size(); ++i) process_pe(o, p1[i], p2[i], outs[k++]);
+    if (o.verbose) fprintf(stderr, "[walt_amd: %.2f s in main]\n", now_s() - g_t_main);
   } catch (const std::exception& e) {
     std::cerr << e.what() << std::endl;
     return EXIT_FAILURE;
