@@ -45,14 +45,10 @@ constexpr uint32_t kPeChunkMax = 1u << 23;
 // rounds (24 GB of workspace at -k 50); 1 = 10 M-pair passes in one round (50 GB: every launch of the staged
 // kernels gets four times the items and the passes are a third fewer -- 273 -> 247 ms per 50 M pairs).  An hg19-scale
 // four-strand index with 2^31-slot directories leaves that room on a 288 GB device (device_index.hip choose_dir_bits).
+static int g_pe_roomy = -1;  // -1: not decided yet (pe_decide_roomy, at the first sizing or launch of the process)
 static int pe_roomy() {
   if (const char* e = getenv("WALT_AMD_PE_ROOMY")) return atoi(e) != 0 ? 1 : 0;  // (tests / A/B: read at every call, like the other hooks)
-  static const int roomy = [] {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
-    return free_b >= (56ull << 30) ? 1 : 0;  // the workspace (~50 GB at -k 50), the pair records, some slack
-  }();
-  return roomy;
+  return g_pe_roomy == 1 ? 1 : 0;
 }
 static inline uint32_t pe_chunk_pairs(uint32_t n, uint32_t top_k) {
   const uint64_t budget = pe_roomy() ? 12ull << 30 : 10ull << 30;
@@ -439,7 +435,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
 constexpr uint32_t kPeMidRegion = 16;  // regions up to this size are verified by their own lane
 constexpr uint32_t kPeChunkEnts = 64;  // survivors per chunk of the pool
 constexpr uint32_t kPeChunks = 8;      // chunks a probe may take (512 survivors); more: the list kernel maps the read
-constexpr uint32_t kPoolGrab = 8;      // pool chunks a wavefront of k_pe_verify takes per atomic (SurvivorSink::take_chunk)
+constexpr uint32_t kPoolGrab = 4;      // pool chunks a wavefront of k_pe_verify takes per atomic (SurvivorSink::take_chunk)
 
 // Survivors {position, mismatches} of probe p of staged read j.  A region verified in place has at most
 // kPeMidRegion of them: inl[(p * kPeMidRegion + k) * ccap + j].  An item's survivors go to chunks of kPeChunkEnts
@@ -1255,8 +1251,8 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
   w.ccap = pe_stage_cap(chunk);
   // 128 survivors per staged read on average (192 when the device is roomy); three quarters static, the dynamic
   // quarter handed out kPoolGrab chunks at a time
-  const uint32_t per_read = pe_roomy() ? 3u : 2u;
-  w.pool_chunks = w.ccap * per_read > 8192 ? w.ccap * per_read : 8192;
+  const uint32_t pool = pe_roomy() ? w.ccap * 3u : w.ccap * 2u + w.ccap / 2u;
+  w.pool_chunks = pool > 8192 ? pool : 8192;
   const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
   for (int m = 0; m < 2; ++m) {
     w.fb_list[m] = reinterpret_cast<uint32_t*>(take(w.stride * 4 + 64));
@@ -1504,7 +1500,22 @@ using namespace walt;
 
 extern "C" {
 
+// roomy when the device has room for this batch's roomy workspace and its pair records beside what is allocated already
+static void pe_decide_roomy(uint32_t n, uint32_t max_read_len, uint32_t top_k) {
+  if (g_pe_roomy >= 0 || getenv("WALT_AMD_PE_ROOMY")) return;
+  int nw = nw_for_len(max_read_len);
+  if (!nw) nw = 64;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { g_pe_roomy = 0; return; }
+  g_pe_roomy = 1;  // size it as if
+  const uint32_t chunk = pe_chunk_pairs(n, top_k);
+  const uint64_t want = (uint64_t)carve_pe(nullptr, chunk, nw, top_k, max_read_len).total_bytes * (n > chunk ? 2 : 1) + (uint64_t)n * sizeof(PairResult) +
+                        (2ull << 30);
+  g_pe_roomy = free_b >= want ? 1 : 0;
+}
+
 size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k) {
+  pe_decide_roomy(n, max_read_len, top_k);
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
   uint32_t chunk = pe_chunk_pairs(n, top_k);
@@ -1522,6 +1533,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
   if (n == 0) return WALT_OK;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WALT_HIP(hipSetDevice(idx->device));
+  pe_decide_roomy(n, max_read_len, top_k);  // (a caller that sized its workspace has decided it already)
   const uint32_t chunk = pe_chunk_pairs(n, top_k);
   if ((rc = pe_streams(idx))) return rc;
   // Passes alternate between two pipeline slots (own workspace and streams), so the latency-bound list
