@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""File the per-leg profiles that tools/prof_round2.sh left under gpurun_out/prof_<tag>_<leg>/ into profiles/:
+"""File the per-leg profiles that tools/prof_legs.sh left under gpurun_out/prof_<tag>_<leg>/ into profiles/:
    profiles/<tag>_<leg>_summary.md, profiles/<tag>_<leg>_kernel_stats.csv, profiles/traffic.json[<leg>].
    python3 tools/prof_collect.py <tag>"""
 import glob

@@ -4,9 +4,9 @@
 # and two PMC runs (read requests by size; WRITE_SIZE) -- separate passes, each with --kernel-trace only, as the
 # pool's rule and the TCC slot budget require.  tools/prof_traffic.py turns them into profiles/<tag>_<leg>_*.{csv,md}
 # and the entries of profiles/traffic.json that bench.py's roofline.traffic reads.
-#   bash tools/prof_round2.sh <tag> [legs...]      legs: se100 se150 se150ag pe100 pe150 (default: all)
+#   bash tools/prof_legs.sh <tag> [legs...]      legs: se100 se150 se150ag pe100 pe150 (default: all)
 set -u
-TAG=${1:-round2}; shift || true
+TAG=${1:-round3}; shift || true
 LEGS=${*:-se100 se150 se150ag pe100 pe150}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise one leg of tools/prof_round2.sh: per-kernel average duration (rocprofv3 --stats) and HBM traffic per
+"""Summarise one leg of tools/prof_legs.sh: per-kernel average duration (rocprofv3 --stats) and HBM traffic per
 step from the PMC passes, written as <dir>/summary.md, <dir>/kernel_stats.csv and <dir>/traffic_entry.json;
 tools/prof_collect.py files them under profiles/ (profiles/traffic.json[<leg>] is what bench.py's roofline.traffic
 reads).
@@ -38,7 +38,7 @@ if st:
         if is_ours(r["Name"]):
             nm = r["Name"].split("(")[0].replace("void ", "")
             kern_ms[nm] = float(r["TotalDurationNs"]) / 1e6 / steps
-            if float(r["TotalDurationNs"]) / 1e6 / steps < 0.05 and "k_map" not in nm and "k_pe" not in nm and "k_se_verify" not in nm:
+            if float(r["TotalDurationNs"]) / 1e6 / steps < 0.05 and "k_map" not in nm and "k_pe" not in nm and "k_se_" not in nm:
                 continue
             lines.append("| %s | %s | %.3f | %.3f | %.3f | %.3f |" % (nm, r["Calls"], float(r["AverageNs"]) / 1e6,
                                                                    float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6,
@@ -54,7 +54,7 @@ def pmc(sub):
             if not is_ours(k):
                 continue
             # index-building kernels run once, before the steps: not part of a step's traffic
-            if not any(x in k for x in ("k_map_se", "k_se_verify", "k_pe_", "k_ascii_to_2bit", "k_bin_", "k_reduce_stats")):
+            if not any(x in k for x in ("k_map_se", "k_se_verify", "k_se_tail", "k_pe_", "k_ascii_to_2bit", "k_bin_", "k_reduce_stats")):
                 continue
             tot[k.split("(")[0].replace("void ", "")][r["Counter_Name"]] += float(r["Counter_Value"])
     return tot
@@ -89,7 +89,10 @@ open(os.path.join(out, "summary.md"), "w").write(text)
 print(text)
 
 cfg = bench["config"]
+sys.path.insert(0, root)
+import bench as _bench  # csrc_sha(): the counters belong to these kernel sources (bench.py drops roofline.traffic when they change)
 entry = {"genome": cfg.get("genome"), "genome_bp": cfg.get("genome_bp"), "source": "profiles/%s_%s_summary.md" % (tag, leg),
+         "csrc_sha": _bench.csrc_sha(),
          "read_bytes": read_b, "write_bytes": write_b, "ms_per_step_under_profiler": bench["ms_per_step"]}
 if leg.startswith("se"):
     entry.update({"hbm_bytes_per_launch": total, "reads_per_launch": cfg.get("reads_per_gpu")})
