@@ -211,9 +211,19 @@ struct Outlier {
   uint32_t key_hi, key_lo;  // the entry's key (real bytes)
 };
 
+// Edge bitmap (DERIVED, round 3): bit b is set when some chromosome boundary lies within kEdgeMargin bases of the
+// genome positions [b << kEdgeBlockShift, (b + 1) << kEdgeBlockShift).  A candidate position in a block whose bit is
+// clear is at least kEdgeMargin bases from both ends of its chromosome, so that `offset in chromosome >= seed shift`
+// and `position - shift + read length < chromosome end` (mapping.cpp:280-286) hold for every seed shift (< 7) and read
+// length (<= 1024) without knowing the chromosome.  2^16 blocks at most: 8 KB.
+constexpr uint32_t kEdgeBlockShift = 16;
+constexpr uint32_t kEdgeMargin = 1024 + 16;
+constexpr uint32_t kEdgeWords = (1u << (32 - kEdgeBlockShift)) / 32;  // 2,048 words
+
 struct IndexView {
   StrandView s[4];               // CT00, CT01, GA10, GA11
   const uint32_t* start_index;   // n_chrom + 1 (Genome::start_index, reference.hpp:55)
+  const uint32_t* edge_bits;     // kEdgeWords words (see above); nullptr: none
   uint32_t n_chrom;
   uint32_t dir_bits;             // Bd: directory prefix length in code bits
   uint32_t dir_slots;            // S = 2^Bd modulo 2^32 (0 when Bd == 32; see dir_top)

@@ -684,6 +684,18 @@ int finish_index_device(walt_index* idx) {
   const std::vector<uint32_t>& mt = compare_mask_table();
   if ((rc = dev_alloc(idx, &idx->d_mask_table, mt.size()))) return rc;
   WALT_HIP(hipMemcpy(idx->d_mask_table, mt.data(), mt.size() * 4, hipMemcpyHostToDevice));
+  {  // edge bitmap (core.h kEdgeBlockShift): the blocks within kEdgeMargin of a chromosome boundary
+    std::vector<uint32_t> bits(kEdgeWords, 0u);
+    for (uint32_t b : idx->start_index) {
+      const uint64_t lo = b > kEdgeMargin ? (uint64_t)b - kEdgeMargin : 0ull, hi = (uint64_t)b + kEdgeMargin;
+      for (uint64_t blk = lo >> kEdgeBlockShift; blk <= (hi >> kEdgeBlockShift) && blk < 32ull * kEdgeWords; ++blk)
+        bits[blk >> 5] |= 1u << (blk & 31u);
+    }
+    uint32_t* d_edge = nullptr;
+    if ((rc = dev_alloc(idx, &d_edge, kEdgeWords))) return rc;
+    WALT_HIP(hipMemcpy(d_edge, bits.data(), kEdgeWords * 4, hipMemcpyHostToDevice));
+    idx->view.edge_bits = d_edge;
+  }
   return WALT_OK;
 }
 

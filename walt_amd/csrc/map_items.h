@@ -235,7 +235,8 @@ __device__ __forceinline__ void tail_items_narrow(const IndexView& iv, uint32_t 
 // for the -b test, mapping.cpp:275-277);  step() after every 64 candidates;  end().
 template <int NW, bool DENSE, bool FITS, class Sink, int G = 1>
 __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand_base, const ItemQueue& q, uint32_t n_items,
-                                            const uint32_t* s_start, Sink& sink, uint32_t n_big = 0) {
+                                            const uint32_t* s_start, Sink& sink, uint32_t n_big = 0,
+                                            const uint32_t* s_edge = nullptr /* LDS copy of iv.edge_bits, or none */) {
   // n_items counts the n_big items of q.bigs (taken first) and the dense (or gather) items of q.items
   constexpr uint32_t Q = item_quads<NW>();
   const uint32_t n_chrom = iv.n_chrom, top_step = top_step_of(n_chrom);
@@ -269,6 +270,13 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
     return v;
   };
   auto chrom_bounds = [&](uint32_t pos, uint32_t& c_lo, uint32_t& c_hi) {
+    // Far from every chromosome boundary (core.h kEdgeMargin) the edge filters of mapping.cpp:280-286 hold whatever the
+    // chromosome is: one bit per 64 K bases says so, and the search over the chromosome starts -- a quarter of the
+    // verifier's instructions -- is left to the few candidates near a boundary.
+    if (s_edge != nullptr && !((s_edge[pos >> (kEdgeBlockShift + 5)] >> ((pos >> kEdgeBlockShift) & 31u)) & 1u)) {
+      c_lo = 0; c_hi = 0xFFFFFFFFu;
+      return;
+    }
     if constexpr (FITS) {  // through the LDS array itself: through a pointer that may be either, the reads would be FLAT loads
       const uint32_t chr = chrom_id_steps(s_start, n_chrom, top_step, pos);
       c_lo = s_start[chr]; c_hi = s_start[chr + 1];

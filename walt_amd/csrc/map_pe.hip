@@ -832,16 +832,20 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
   if (n_items == 0) return;
   __shared__ uint32_t s_start[kLdsChroms + 1];
   __shared__ uint32_t s_hist[kBlock / 64][64];
+  __shared__ uint32_t s_edge[DENSE ? kEdgeWords : 1];  // (the dense verifier: core.h edge bitmap)
   const bool fits = iv.n_chrom <= kLdsChroms;
   if (fits)
     for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  if (DENSE && iv.edge_bits != nullptr)
+    for (uint32_t i = threadIdx.x; i < kEdgeWords; i += blockDim.x) s_edge[i] = iv.edge_bits[i];
   __syncthreads();
+  const uint32_t* const edge = (DENSE && iv.edge_bits != nullptr) ? s_edge : nullptr;
   SurvivorSink sink;
   sink.ps = ps; sink.max_mm = max_mm; sink.top_k = top_k; sink.hist = s_hist[threadIdx.x >> 6]; sink.n_verified = 0;
   sink.gp_ = 0; sink.mm_ = 0xFFFFFFFFu; sink.dense_kind = DENSE; sink.b = b; sink.tail = 0; sink.in_region = 0;
   sink.grab_next = sink.grab_end = 0;
-  if (fits) item_stream<NW, DENSE, true>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
-  else item_stream<NW, DENSE, false>(iv, strand_base, ps.q, n_items, s_start, sink, n_big);
+  if (fits) item_stream<NW, DENSE, true>(iv, strand_base, ps.q, n_items, s_start, sink, n_big, edge);
+  else item_stream<NW, DENSE, false>(iv, strand_base, ps.q, n_items, s_start, sink, n_big, edge);
   pe_flush(0u, 0u, sink.n_verified, 0u, stats);
 }
 

@@ -923,14 +923,18 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
   const uint32_t n_items = q.ctl[DENSE ? 0 : 1] + n_big;
   if (n_items == 0) return;
   __shared__ uint32_t s_start[kLdsChroms + 1];
+  __shared__ uint32_t s_edge[DENSE ? kEdgeWords : 1];  // (the dense verifier: core.h edge bitmap)
   const bool fits = iv.n_chrom <= kLdsChroms;
   if (fits)
     for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  if (DENSE && iv.edge_bits != nullptr)
+    for (uint32_t i = threadIdx.x; i < kEdgeWords; i += blockDim.x) s_edge[i] = iv.edge_bits[i];
   __syncthreads();
+  const uint32_t* const edge = (DENSE && iv.edge_bits != nullptr) ? s_edge : nullptr;
   SummarySink sink;
   sink.sums = hs.sums; sink.hcap = hs.hcap; sink.n_verified = 0; sink.b = b; sink.tail = 0; sink.in_region = 0;
-  if (fits) item_stream<NW, DENSE, true, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big);
-  else item_stream<NW, DENSE, false, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big);
+  if (fits) item_stream<NW, DENSE, true, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big, edge);
+  else item_stream<NW, DENSE, false, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big, edge);
   flush_counters({0u, sink.n_verified, 0u}, 0u, stats);
 }
 
