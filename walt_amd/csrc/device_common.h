@@ -45,6 +45,10 @@ struct walt_index {
   hipEvent_t ev_detail[kDetailEvents] = {};
   unsigned char ev_kind[kDetailEvents] = {};
   int n_detail = 0;
+  // single-end (created on first use): the side stream the literal pass runs on beside the last verifier launch and
+  // the final fold of the staged heavy pass
+  hipStream_t se_side = nullptr;
+  hipEvent_t se_fork = nullptr, se_join = nullptr;
   // paired-end (created on first use): two pipeline slots, each with a stream for mate 1 + merge (A, unused in
   // slot 0 of a single-pass call: the caller's stream plays that role) and one for mate 2 (B)
   hipStream_t pe_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};

@@ -1008,6 +1008,9 @@ void walt_index_close(walt_index* idx) {
       if (idx->pe_stream[k][j]) hipStreamDestroy(idx->pe_stream[k][j]);
   }
   if (idx->pe_start) hipEventDestroy(idx->pe_start);
+  if (idx->se_fork) hipEventDestroy(idx->se_fork);
+  if (idx->se_join) hipEventDestroy(idx->se_join);
+  if (idx->se_side) hipStreamDestroy(idx->se_side);
   delete idx;
 }
 

@@ -696,6 +696,12 @@ __device__ __forceinline__ void bin_slice(uint32_t count, uint32_t& lo, uint32_t
   lo = blockIdx.x * per < count ? blockIdx.x * per : count;
   hi = lo + per < count ? lo + per : count;
 }
+// ctl2[0] = the list's length now (the side launch's share), ctl2[8..23] = 0 (its bins); rng = {that length, 0}
+static __global__ void k_lit_snapshot(const uint32_t* __restrict__ count, uint32_t* __restrict__ ctl2, uint32_t* __restrict__ rng) {
+  if (threadIdx.x == 0) { ctl2[0] = *count; rng[0] = *count; }
+  if (threadIdx.x >= 8 && threadIdx.x < 24) ctl2[threadIdx.x] = 0;
+}
+static __global__ void k_lit_rest(const uint32_t* __restrict__ count, uint32_t* __restrict__ rng) { rng[1] = *count; }
 static __global__ void k_bin_count(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list) {
   __shared__ uint32_t bins[8];
   if (threadIdx.x < 8) bins[threadIdx.x] = 0;
@@ -951,13 +957,21 @@ __global__ __launch_bounds__(kBlock, NW <= 8 ? 5 : 1) void k_map_se_literal(Inde
                                                             unsigned long long* __restrict__ stats,
                                                             uint32_t* __restrict__ defer_count,
                                                             uint32_t* __restrict__ defer_list,
-                                                            uint32_t all_reads) {
+                                                            uint32_t all_reads, const uint32_t* __restrict__ range = nullptr) {
+  // range != nullptr: the list entries [range[0], range[1]) only (launch_map_se: what was deferred after the side launch)
+  uint32_t n_entries = 0;
+  if (range != nullptr) {
+    const uint32_t lo_entry = range[0];
+    n_entries = range[1] > lo_entry ? range[1] - lo_entry : 0u;
+    if (n_entries == 0) return;
+    defer_list += lo_entry;
+  }
   __shared__ BlockShared sh;
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   // all_reads != 0 (seed patterns 5 and 7, which have no seed-major pass 1): every read 0 .. all_reads-1 with
   // LITERAL = false (directory/key search; a Bloom hit appends the read to defer_list), then the list with
   // LITERAL = true
-  const uint32_t count = all_reads ? all_reads : *defer_count;
+  const uint32_t count = all_reads ? all_reads : (range != nullptr ? n_entries : *defer_count);
   MapCounters ctr = {0, 0, 0};
   uint32_t shortv = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
@@ -1065,6 +1079,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
   // lane) instead of the staged one (large regions streamed by k_se_verify); same results, kept for comparison
   const char* heavy_mode = getenv("WALT_AMD_HEAVY");
   const bool mono = heavy_mode && !strcmp(heavy_mode, "mono");
+  bool lit_side = false;
   if (diag2 && mono)
     hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
@@ -1103,6 +1118,23 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       return (unsigned)nb * 256u;
     }();
     static const int stage_occ = [] { const char* e = getenv("WALT_AMD_STAGE_OCC"); return e ? atoi(e) : 0; }();
+    // The literal pass beside the end of the heavy pass (round 3): after the first chunk's last look-up stage the list
+    // of reads with a truly dangerous probe is complete but for what later chunks add (nothing, when the heavy list fits
+    // one chunk); those reads are sorted and mapped on a side stream while the main stream runs the last verifier
+    // launch and the final fold.  The literal kernel is a chain of dependent loads with a few thousand wavefronts; the
+    // verifier is bound by HBM bandwidth, the fold is short.  What later chunks defer is mapped at the end as before.
+    // WALT_AMD_LIT_SIDE=0: the whole literal pass at the end.
+    static const bool lit_side_on = [] { const char* e = getenv("WALT_AMD_LIT_SIDE"); return !(e && atoi(e) == 0); }();
+    lit_side = lit_side_on && !diag && n <= kDeferMask;
+    uint32_t* const ctl2 = ctl0 + 200;  // [0] count of the side launch, [8..23] its bins
+    uint32_t* const rng = ctl0 + 232;   // {entries the side launch took, the list's final length}
+    if (lit_side && !idx->se_side) {
+      int lo_pri = 0, hi_pri = 0;
+      WALT_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+      WALT_HIP(hipStreamCreateWithPriority(&idx->se_side, hipStreamNonBlocking, lo_pri));
+      WALT_HIP(hipEventCreateWithFlags(&idx->se_fork, hipEventDisableTiming));
+      WALT_HIP(hipEventCreateWithFlags(&idx->se_join, hipEventDisableTiming));
+    }
     for (uint32_t c = 0; c < chunks; ++c) {
       hs.first = c * hcap;
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
@@ -1127,6 +1159,16 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                              heavy_list, 0u, nullptr, hs);
         mark(1);
         if (stage == 3) break;
+        if (lit_side && c == 0 && stage == 2) {
+          hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, stream, defer_count, ctl2, rng);
+          WALT_HIP(hipEventRecord(idx->se_fork, stream));
+          WALT_HIP(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
+          launch_bin_deferred(ctl2, defer_list, defer_list + stride, idx->se_side);
+          const unsigned g_lit = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+          hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g_lit), dim3(kBlock), 0, idx->se_side, view, codes2, offsets, err,
+                             strand_base, max_mm, b, idx->d_mask_table, out, stats, ctl2, defer_list + stride, 0u);
+          WALT_HIP(hipEventRecord(idx->se_join, idx->se_side));
+        }
         if constexpr (NW > 8 && NW <= 10)
           hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(256 * 8), dim3(kBlock), 0, stream, view, strand_base, hs, b);
         if constexpr (NW <= 10) {
@@ -1139,6 +1181,15 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
   }
   debug_sync("heavy pass", stream);
   mark(1);  // (the one-kernel heavy pass, when that is what ran)
+  if (lit_side) {  // what the chunks behind the first one deferred (usually nothing), then the side launch ends the call
+    hipLaunchKernelGGL(k_lit_rest, dim3(1), dim3(1), 0, stream, defer_count, heavy_area + 232);
+    unsigned g3 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+    hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g3), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, heavy_area + 232);
+    WALT_HIP(hipStreamWaitEvent(stream, idx->se_join, 0));
+    mark(3);
+    return WALT_OK;
+  }
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
