@@ -163,3 +163,33 @@ def test_bench_launches_its_own_ranks_dry_run():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, env=env, timeout=120)
     assert p.returncode != 0 and "--gpus 2" in p.stderr
+
+
+def _cross_check_worker(rank, world, port, out_dir, break_rank):
+    import torch.distributed as dist
+    from walt_amd import dist as wd
+    import walt_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == break_rank:  # this rank "cannot load librccl": the others must not be left waiting for it
+        walt_amd.comm_available = lambda: False
+    res = wd.c_abi_cross_check(0, np.array([1, 2, 3], dtype=np.uint64), [2, 4, 6])
+    open(os.path.join(out_dir, "xcheck%d.txt" % rank), "w").write(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("break_rank", [0, 1])
+def test_c_abi_cross_check_fails_collectively_not_by_hanging(scratch, break_rank):
+    """walt_amd.dist.c_abi_cross_check (bench.py's walt_stats_allreduce check at N > 1): when ONE rank cannot use
+    librccl -- or, on this GPU-less box, when rank 0 cannot make the id -- every rank gets "failed: ..." and goes on;
+    nobody enters ncclCommInitRank or a broadcast alone (the decision must be collective)."""
+    import torch.multiprocessing as mp
+    out_dir = os.path.join(scratch, "xcheck%d" % break_rank)
+    os.makedirs(out_dir, exist_ok=True)
+    world = 2
+    mp.spawn(_cross_check_worker, args=(world, _free_port(), out_dir, break_rank), nprocs=world, join=True)
+    texts = [open(os.path.join(out_dir, "xcheck%d.txt" % r)).read() for r in range(world)]
+    assert all(t.startswith("failed:") for t in texts), texts
