@@ -49,6 +49,10 @@ struct walt_index {
   // the final fold of the staged heavy pass
   hipStream_t se_side = nullptr;
   hipEvent_t se_fork = nullptr, se_join = nullptr;
+  // single-end staged heavy pass in two halves (map_se.hip launch_map_se): the second half's stream and the events
+  // that order the halves: [0] pass 1 done, [1] the first half's last look-up stage done, [2] second half done
+  hipStream_t se_pipe = nullptr;
+  hipEvent_t se_pipe_ev[3] = {nullptr, nullptr, nullptr};
   // paired-end (created on first use): two pipeline slots, each with a stream for mate 1 + merge (A, unused in
   // slot 0 of a single-pass call: the caller's stream plays that role) and one for mate 2 (B)
   hipStream_t pe_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};

@@ -1011,6 +1011,8 @@ void walt_index_close(walt_index* idx) {
   if (idx->se_fork) hipEventDestroy(idx->se_fork);
   if (idx->se_join) hipEventDestroy(idx->se_join);
   if (idx->se_side) hipStreamDestroy(idx->se_side);
+  for (hipEvent_t e : idx->se_pipe_ev) if (e) hipEventDestroy(e);
+  if (idx->se_pipe) hipStreamDestroy(idx->se_pipe);
   delete idx;
 }
 

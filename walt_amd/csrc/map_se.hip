@@ -326,10 +326,21 @@ struct HeavyStage {
   const uint32_t* count_in;
   uint32_t* list_out;       // stages 0, 1: positions that may need the next seed
   uint32_t hcap;     // reads per chunk
-  uint32_t first;    // heavy-list index of the chunk's first read
+  uint32_t first;    // heavy-list index of the chunk's first read (even == 0)
+  uint32_t chunk;    // even != 0: the heavy list is cut into an EVEN number of equal chunks of at most hcap reads, and
+  uint32_t even;     // this is chunk number `chunk` of them (heavy_chunk_span; the list's length is known on the device only)
   uint32_t stage;    // 0..2: seed shift of the stage, 3: final fold
   uint32_t defer_min;  // long seeds: key-equal ranges of more slots than this are narrowed by the verifier (0xFFFFFFFF: never)
 };
+// chunk c of the heavy list of H reads (HeavyStage::even): first read and number of reads
+__device__ __forceinline__ void heavy_chunk_span(uint32_t H, uint32_t hcap, uint32_t c, uint32_t& first, uint32_t& len) {
+  uint32_t k = (H + hcap - 1) / hcap;
+  k = (k + 1) & ~1u;                               // the two halves of the pipeline get the same number of chunks
+  const uint32_t per = k ? (((H + k - 1) / k + 63u) & ~63u) : 0u;  // <= hcap (a multiple of 64)
+  first = c * per;
+  len = first < H ? (H - first < per ? H - first : per) : 0u;
+}
+
 template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
                                                 const uint32_t* __restrict__ codes2, uint64_t o_first,
@@ -784,9 +795,15 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 
                                                     unsigned long long* __restrict__ stamps,
                                                     HeavyStage hs = HeavyStage()) {
   uint32_t n = HEAVY ? *heavy_count : n_all;
+  uint32_t h_first = 0;
   if constexpr (STAGED) {  // this chunk of the heavy list, or what the previous stage left of it
-    n = n > hs.first ? n - hs.first : 0u;
-    n = n < hs.hcap ? n : hs.hcap;
+    if (hs.even) {
+      heavy_chunk_span(n, hs.hcap, hs.chunk, h_first, n);
+    } else {
+      h_first = hs.first;
+      n = n > hs.first ? n - hs.first : 0u;
+      n = n < hs.hcap ? n : hs.hcap;
+    }
     if (hs.list_in) n = hs.count_in[4];
   }
   if (HEAVY && n == 0) return;
@@ -819,7 +836,7 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 
   auto fetch = [&](uint64_t i) {
     if constexpr (STAGED) {
       j_nx = hs.list_in ? hs.list_in[i] : (uint32_t)i;
-      r_nx = heavy_list[hs.first + j_nx];
+      r_nx = heavy_list[h_first + j_nx];
     } else {
       r_nx = HEAVY ? heavy_list[i] : (uint32_t)i;
     }
@@ -994,22 +1011,35 @@ __global__ __launch_bounds__(kBlock, NW <= 8 ? 5 : 1) void k_map_se_literal(Inde
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
-// staged heavy pass: reads per chunk of the heavy list (a quarter of the batch -- one chunk holds the heavy reads of
-// an hg19-like genome, a sixth of all: two chunks of an eighth cost 2.3 ms more -- the whole batch when it is small)
-// and the bytes of its state behind the dense read array: [128 control words][flag][6 summaries][2 x 2 item words]
+// staged heavy pass: reads per chunk of the heavy list and the bytes of its state behind the dense read array:
+// [256 control words] then per state slot [flag][two stage lists][6 summaries][2 x 2 item words][giants].
+// Round 3: the list is mapped in two halves on two streams (launch_map_se), each with its own state slot: chunks of an
+// eighth of the batch (the heavy reads of an hg19-like genome, a sixth of all, make one chunk per half), cut evenly on
+// the device (heavy_chunk_span).  WALT_AMD_SE_PIPE=0: one stream, one slot, chunks of a quarter (rounds 2's schedule).
 constexpr uint32_t kHeavyCtlWords = 256;  // 8 words per (chunk, stage): up to 8 chunks x 3 stages
+static int se_pipe_mode() {
+  static const int mode = [] { const char* e = getenv("WALT_AMD_SE_PIPE"); return e ? atoi(e) : 1; }();
+  return mode;
+}
 static uint32_t se_heavy_chunk(uint32_t n) {
-  const uint64_t share = ((uint64_t)n + 3) / 4;
+  const uint64_t share = ((uint64_t)n + (se_pipe_mode() ? 7 : 3)) / (se_pipe_mode() ? 8 : 4);
   if (const char* e = getenv("WALT_AMD_HEAVY_CHUNK")) {  // test hook: several chunks on a small batch (at most 8 are made)
     const uint64_t v = (uint64_t)atol(e);
     if (v * 8 >= n && v > 0) return (uint32_t)align_up(v, 64);
   }
   return (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (share > 65536 ? share : 65536), 64);
 }
-static uint64_t se_heavy_bytes(uint32_t n, int nw) {
-  const uint64_t hcap = se_heavy_chunk(n);
+static uint32_t se_heavy_chunks(uint32_t n) {  // <= 8
+  const uint32_t hcap = se_heavy_chunk(n);
+  return (uint32_t)(((uint64_t)n + hcap - 1) / hcap);
+}
+static bool se_heavy_piped(uint32_t n) { return se_pipe_mode() != 0 && se_heavy_chunks(n) > 1; }
+static uint64_t se_heavy_slot_bytes(uint64_t hcap, int nw) {
   const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
-  return 16 + kHeavyCtlWords * 4 + 3 * hcap * 4 + hcap * 6 * 16 + (2 * hcap + hcap / 8) * quads * 16;  // flag + two stage lists; items + giants
+  return 3 * hcap * 4 + hcap * 6 * 16 + (2 * hcap + hcap / 8) * quads * 16;  // flag + two stage lists; summaries; items + giants
+}
+static uint64_t se_heavy_bytes(uint32_t n, int nw) {
+  return 16 + kHeavyCtlWords * 4 + (se_heavy_piped(n) ? 2 : 1) * se_heavy_slot_bytes(se_heavy_chunk(n), nw);
 }
 
 // WALT_AMD_ABLATE (diagnostic builds of the measurement only; results are WRONG when
@@ -1090,15 +1120,25 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                        heavy_list, 0u, nullptr);
   else {
     const uint32_t hcap = se_heavy_chunk(n);
-    const uint32_t chunks = (uint32_t)(((uint64_t)n + hcap - 1) / hcap);  // <= 8
+    // two halves on two streams (se_heavy_chunk): odd chunks on idx->se_pipe with the second state slot.  Every launch
+    // is a set of persistent blocks that fill the device by their registers, so two launches do not share a SIMD for
+    // long; what the second stream buys is that one half's launch starts into the other's tail (41.3 against 42.3 ms
+    // per 50 M reads; holding the second half back by one stage to pair look-up stages with verifier launches: 42.7).
+    // Diagnostic runs (stamps, ablation) keep one stream.
+    const bool piped = se_heavy_piped(n) && !diag;
+    const uint32_t chunks = piped ? (se_heavy_chunks(n) + 1u) & ~1u : se_heavy_chunks(n);  // <= 8
     HeavyStage hs;
     hs.ctl = heavy_area;
-    hs.flag = heavy_area + kHeavyCtlWords;
-    uint32_t* const lists = hs.flag + hcap;  // [2][hcap]: what stage 0 hands to stage 1, stage 1 to stage 2
-    hs.sums = reinterpret_cast<uint4*>(lists + 2 * (uint64_t)hcap);
-    hs.items = hs.sums + (uint64_t)6 * hcap;  // 2 * hcap items of item_quads<NW>() quads
-    hs.giants = hs.items + (uint64_t)2 * hcap * item_quads<NW>();
     hs.hcap = hcap;
+    hs.even = piped ? 1u : 0u;
+    const uint64_t slot_words = se_heavy_slot_bytes(hcap, NW) / 4;
+    auto use_slot = [&](uint32_t k, uint32_t*& lists) {
+      hs.flag = heavy_area + kHeavyCtlWords + k * slot_words;
+      lists = hs.flag + hcap;  // [2][hcap]: what stage 0 hands to stage 1, stage 1 to stage 2
+      hs.sums = reinterpret_cast<uint4*>(lists + 2 * (uint64_t)hcap);
+      hs.items = hs.sums + (uint64_t)6 * hcap;  // 2 * hcap items of item_quads<NW>() quads
+      hs.giants = hs.items + (uint64_t)2 * hcap * item_quads<NW>();
+    };
     static const uint32_t defer_min = [] {  // WALT_AMD_DEFER=0: never (A/B); =n: ranges of more than n slots (n >= the in-lane limit)
       const char* e = getenv("WALT_AMD_DEFER");
       if (!e) return (uint32_t)kSmallRegion;  // (measured: 4 / 8 / 16 -> 32.5 / 33.2 / 34.2 ms per 25 M 150-base reads)
@@ -1118,12 +1158,12 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       return (unsigned)nb * 256u;
     }();
     static const int stage_occ = [] { const char* e = getenv("WALT_AMD_STAGE_OCC"); return e ? atoi(e) : 0; }();
-    // The literal pass beside the end of the heavy pass (round 3): after the first chunk's last look-up stage the list
-    // of reads with a truly dangerous probe is complete but for what later chunks add (nothing, when the heavy list fits
-    // one chunk); those reads are sorted and mapped on a side stream while the main stream runs the last verifier
-    // launch and the final fold.  The literal kernel is a chain of dependent loads with a few thousand wavefronts; the
-    // verifier is bound by HBM bandwidth, the fold is short.  What later chunks defer is mapped at the end as before.
-    // WALT_AMD_LIT_SIDE=0: the whole literal pass at the end.
+    // The literal pass beside the end of the heavy pass (round 3): after the last look-up stage of the first chunk (of
+    // each half) the list of reads with a truly dangerous probe is complete but for what later chunks add (nothing,
+    // when the heavy list fits these chunks); those reads are sorted and mapped on a side stream while the main streams
+    // run the last verifier launches and the final folds.  The literal kernel is a chain of dependent loads with a few
+    // thousand wavefronts; the verifier is bound by HBM bandwidth, the fold is short.  What later chunks defer is mapped
+    // at the end as before.  WALT_AMD_LIT_SIDE=0: the whole literal pass at the end.
     static const bool lit_side_on = [] { const char* e = getenv("WALT_AMD_LIT_SIDE"); return !(e && atoi(e) == 0); }();
     lit_side = lit_side_on && !diag && n <= kDeferMask;
     uint32_t* const ctl2 = ctl0 + 200;  // [0] count of the side launch, [8..23] its bins
@@ -1135,8 +1175,23 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       WALT_HIP(hipEventCreateWithFlags(&idx->se_fork, hipEventDisableTiming));
       WALT_HIP(hipEventCreateWithFlags(&idx->se_join, hipEventDisableTiming));
     }
+    if (piped && !idx->se_pipe) {
+      WALT_HIP(hipStreamCreateWithFlags(&idx->se_pipe, hipStreamNonBlocking));
+      for (hipEvent_t& e : idx->se_pipe_ev) WALT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (piped) {  // (pass 1 done)
+      WALT_HIP(hipEventRecord(idx->se_pipe_ev[0], stream));
+      WALT_HIP(hipStreamWaitEvent(idx->se_pipe, idx->se_pipe_ev[0], 0));
+    }
     for (uint32_t c = 0; c < chunks; ++c) {
+      const bool odd = piped && (c & 1u);
+      hipStream_t cs = odd ? idx->se_pipe : stream;
+      uint32_t* lists = nullptr;
+      use_slot(odd ? 1u : 0u, lists);
       hs.first = c * hcap;
+      hs.chunk = c;
+      // chunks behind the first pair append to the deferred list: not while the side launch's share is being fixed
+      if (piped && lit_side && c == 2) WALT_HIP(hipStreamWaitEvent(stream, idx->se_fork, 0));
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
       for (uint32_t stage = 0; stage < 4; ++stage) {
         hs.stage = stage;
@@ -1146,22 +1201,24 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
         hs.count_in = listed ? ctl0 + 8 * (3 * c + stage - 1) : nullptr;
         hs.list_out = stage < 2 ? lists + (uint64_t)stage * hcap : nullptr;
         if (diag2)
-          hipLaunchKernelGGL((k_map_se<NW, true, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+          hipLaunchKernelGGL((k_map_se<NW, true, true, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                              heavy_list, g_ablate, g_stamps, hs);
         else if (NW <= 10 && stage_occ == (NW <= 8 ? 3 : 2))  // A/B knob (WALT_AMD_STAGE_OCC): one wavefront per SIMD fewer, more registers
-          hipLaunchKernelGGL((k_map_se<NW, false, true, true, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+          hipLaunchKernelGGL((k_map_se<NW, false, true, true, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                              heavy_list, 0u, nullptr, hs);
         else
-          hipLaunchKernelGGL((k_map_se<NW, false, true, true>), dim3(gh), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+          hipLaunchKernelGGL((k_map_se<NW, false, true, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                              heavy_list, 0u, nullptr, hs);
-        mark(1);
+        if (!odd) mark(1);
         if (stage == 3) break;
-        if (lit_side && c == 0 && stage == 2) {
-          hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, stream, defer_count, ctl2, rng);
-          WALT_HIP(hipEventRecord(idx->se_fork, stream));
+        if (piped && c == 0 && stage == 2) WALT_HIP(hipEventRecord(idx->se_pipe_ev[1], stream));
+        if (lit_side && c == (piped ? 1u : 0u) && stage == 2) {
+          if (piped) WALT_HIP(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));  // both halves' first chunks have made their last deferrals
+          hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, cs, defer_count, ctl2, rng);
+          WALT_HIP(hipEventRecord(idx->se_fork, cs));
           WALT_HIP(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
           launch_bin_deferred(ctl2, defer_list, defer_list + stride, idx->se_side);
           const unsigned g_lit = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
@@ -1170,13 +1227,17 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
           WALT_HIP(hipEventRecord(idx->se_join, idx->se_side));
         }
         if constexpr (NW > 8 && NW <= 10)
-          hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(256 * 8), dim3(kBlock), 0, stream, view, strand_base, hs, b);
+          hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(256 * 8), dim3(kBlock), 0, cs, view, strand_base, hs, b);
         if constexpr (NW <= 10) {
-          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, strand_base, stats, hs, b);
+          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b);
         }
-        hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, strand_base, stats, hs, b);
-        mark(2);
+        hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b);
+        if (!odd) mark(2);
       }
+    }
+    if (piped) {  // the second half joins
+      WALT_HIP(hipEventRecord(idx->se_pipe_ev[2], idx->se_pipe));
+      WALT_HIP(hipStreamWaitEvent(stream, idx->se_pipe_ev[2], 0));
     }
   }
   debug_sync("heavy pass", stream);
