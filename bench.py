@@ -285,9 +285,10 @@ def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, tr
     # the 16-byte result.  SURVEY 8(d)'s formula prices the REFERENCE algorithm's binary-search steps and is
     # kept as `survey_8d`.
     table = bool(os.environ.get("WALT_AMD_TABLE", "0") not in ("", "0"))
-    dense_on = os.environ.get("WALT_AMD_WIN", "1") not in ("0",) and read_len <= 174 and args.pattern == 3
+    lead = args.pattern - 1  # bases a dense record holds in front of the entry's position (core.h kWinLead)
+    dense_on = os.environ.get("WALT_AMD_WIN", "1") not in ("0",) and read_len <= 176 - lead
     C_big = float(tu["cands_big"].sum()) / nu if dense_on else 0.0
-    rec_bytes = 32.0 if read_len <= 110 else 48.0
+    rec_bytes = 32.0 if read_len <= 112 - lead else 48.0
     lines = (1.0 if table else 2.0) * P + (C - C_big)
     bytes_per_read = 128.0 * lines + 12.0 * (C - C_big) + rec_bytes * C_big + read_len / 4.0 + 16
     useful = read_len / 4.0 + 16 + P * (8 + 12) + C * (12 + read_len / 4.0 + 8)

@@ -1045,6 +1045,31 @@ WALT_HD uint32_t funnel_r(uint32_t lo, uint32_t hi, uint32_t s) {  // (hi:lo >> 
 #endif
 }
 
+// The same mask without a table, for any pattern (patterns 5 / 7: seeds of more than 44 care characters start at 119 / 90
+// bases): the mask of seed shift 0 over ALL care characters >= 44 is a compile-time constant per word, a seed shift
+// moves it up by 2 seed_i bits, and the characters at and beyond seed_len -- their read offsets rise with p -- are cut
+// off at read offset `cut` = seed_i + care_pos(seed_len) (anything >= 16 kMaskWords... when seed_len == kNumCare).
+constexpr uint32_t tail_care_base_word(uint32_t w) {
+  uint32_t m = 0;
+  for (uint32_t p = kKeyWeight + kKeyChars; p < kNumCare; ++p) {
+    const uint32_t o = care_pos(p);
+    if ((o >> 4) == w) m |= 1u << (2 * (o & 15u));
+  }
+  return m;
+}
+WALT_HD uint32_t tail_mask_word(uint32_t w, uint32_t lo, uint32_t hi);
+template <int W>
+WALT_HD uint32_t tail_care_mask_word(uint32_t seed_i, uint32_t cut) {
+  constexpr uint32_t b1 = tail_care_base_word(W), b0 = W ? tail_care_base_word(W ? W - 1 : 0) : 0u;
+  const uint32_t s = 2 * seed_i;  // <= 12
+  const uint32_t m = (b1 << s) | (s ? b0 >> (32 - s) : 0u);
+  return m & tail_mask_word(W, 0, cut);
+}
+// read offset from which the care characters of a seed of seed_len characters at shift seed_i stop
+WALT_HD uint32_t tail_care_cut(uint32_t seed_i, uint32_t seed_len) {
+  return seed_len < kNumCare ? seed_i + care_pos(seed_len) : 0xFFFFu;
+}
+
 template <int NW>
 WALT_HD uint32_t count_mismatch(const uint32_t* g2, uint32_t gpos, const uint32_t* rd, const uint32_t* mask) {
   const uint32_t* g = g2 + (gpos >> 4);
@@ -1058,6 +1083,30 @@ WALT_HD uint32_t count_mismatch(const uint32_t* g2, uint32_t gpos, const uint32_
     mm += popc32((x | (x >> 1)) & mask[w]);
     cur = nxt;
   }
+  return mm;
+}
+
+// the same count, and beside it the mismatches at the seed's care characters >= 44 (tail_care_mask_word): a single
+// key-equal candidate survives IndexRegion iff that count is zero (mapping.cpp:206-211; patterns 5 / 7)
+template <int NW, int W = 0>
+WALT_HD void count_mismatch_tail_words(const uint32_t* g, uint32_t sh, const uint32_t* rd, const uint32_t* mask,
+                                       uint32_t seed_i, uint32_t cut, uint32_t cur, uint32_t& mm, uint32_t& tmm) {
+  if constexpr (W < NW) {
+    const uint32_t nxt = g[W + 1];
+    const uint32_t x = funnel_r(cur, nxt, sh) ^ rd[W];
+    const uint32_t d = x | (x >> 1);
+    mm += popc32(d & mask[W]);
+    tmm += popc32(d & tail_care_mask_word<W>(seed_i, cut));
+    count_mismatch_tail_words<NW, W + 1>(g, sh, rd, mask, seed_i, cut, nxt, mm, tmm);
+  }
+}
+template <int NW>
+WALT_HD uint32_t count_mismatch_tail(const uint32_t* g2, uint32_t gpos, const uint32_t* rd, const uint32_t* mask,
+                                     uint32_t seed_i, uint32_t cut, uint32_t& tmm) {
+  const uint32_t* g = g2 + (gpos >> 4);
+  uint32_t mm = 0;
+  tmm = 0;
+  count_mismatch_tail_words<NW>(g, 2 * (gpos & 15), rd, mask, seed_i, cut, g[0], mm, tmm);
   return mm;
 }
 

@@ -349,14 +349,28 @@ __device__ __forceinline__ void probe_entries(const StrandView& sv, SlotProbe& p
     if (j < p.ne) p.e[j] = sv.ent[p.lo + j];
   }
 }
+// kernel instances for reads of up to 16 NW bases: can a seed exceed the 44 care characters of hash + key?
+// (pattern 3: NW > 8, reads above 134 bases; pattern 5: NW >= 8, from 119 bases; pattern 7: every instance, from 90)
+template <int NW>
+constexpr bool long_seed_nw() {
+  uint32_t len = 16u * NW < kMaxReadLen ? 16u * NW : kMaxReadLen;
+  uint32_t r = (len - kPat + 1) / kPat;
+  r = r < kMaxRepeats ? r : kMaxRepeats;
+  return r * kCareW > kKeyWeight + kKeyChars;
+}
+
 // region + leading candidate positions from a probed slot (core.h seed_lookup_ex, scan branch)
-// LONG_SEED: instances for reads above 128 bp, whose seeds can exceed the 32 key characters
+// LONG_SEED: instances for reads whose seeds can exceed the 32 key characters (long_seed_nw)
 // tail_check: set when a single key-equal candidate still has to pass the care characters behind the key
 // (>= 44); the caller tests them on the genome words its verification loads anyway (tail_care_ok).
+// unresolved (patterns 5 / 7, whose tail characters span more than the two-word window of lit_region_small): a
+// key-equal range of several slots is returned as it is and flagged -- pass 1 hands such a read to the heavy pass
+// instead of running lit_region's chain of dependent loads beside 63 reads that have none
 template <bool LONG_SEED>
 __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotProbe& p, const uint32_t* care,
-                                              uint32_t seed_len, Lookup& out, bool& tail_check) {
+                                              uint32_t seed_len, Lookup& out, bool& tail_check, bool* unresolved = nullptr) {
   tail_check = false;
+  if (unresolved) *unresolved = false;
   out.npos = 0;
   out.reg = empty_region();
   if (p.ne == 0) return;
@@ -395,8 +409,12 @@ __device__ __forceinline__ void probe_resolve(const StrandView& sv, const SlotPr
       // IndexRegion on one slot (mapping.cpp:206-211): it survives iff every remaining care char matches
       tail_check = true;
       out.reg.l = a; out.reg.u = a;
-    } else if (LONG_SEED && size <= kLookupPos && out.npos == size) {
+    } else if (kPat == 3 && LONG_SEED && size <= kLookupPos && out.npos == size) {
       out.reg = lit_region_small(sv, care, seed_len, a, size, out.pos, out.npos);
+    } else if (kPat != 3 && unresolved != nullptr) {
+      *unresolved = true;
+      out.npos = 0;
+      out.reg.l = a; out.reg.u = u;
     } else {
       out.npos = 0;
       out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a, u);
@@ -594,7 +612,7 @@ __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const 
       } else if (LONG_SEED && size == 1 && out.npos == 1) {
         tail_check = true;  // IndexRegion on one slot (mapping.cpp:206-211)
         out.reg.l = a[f]; out.reg.u = a[f];
-      } else if (LONG_SEED && size <= kLookupPos && out.npos == size) {
+      } else if (kPat == 3 && LONG_SEED && size <= kLookupPos && out.npos == size) {
         out.reg = lit_region_small(sv, care, seed_len, a[f], size, out.pos, out.npos);
       } else {
         out.npos = 0;
@@ -646,6 +664,31 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const Bloc
   // only lanes with a candidate touch memory: the mapping kernels are bound by the number of per-lane
   // accesses the L1 (TCP) processes, not by instruction issue, so an idle lane's dummy load is not free
   if (ok) mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
+}
+
+// the same with the seed's care characters >= 44 tested on the window the count loads (patterns 5 / 7; pattern 3 has
+// tail_care_ok's two words): tail_ok = they all equal the read's
+template <int NW>
+__device__ __forceinline__ void verify_nobranch_tail(const StrandView& sv, const BlockShared& sh, const uint32_t* si,
+                                                     uint32_t n_chrom, uint32_t top_step, bool active, uint32_t slot_pos,
+                                                     uint32_t seed_i, uint32_t len, const uint32_t* rd,
+                                                     const uint32_t* mk, uint32_t cut, bool& ok, uint32_t& gp, uint32_t& mm,
+                                                     bool& tail_ok) {
+  uint32_t c_lo, c_hi;
+  if (n_chrom <= kLdsChroms) {
+    const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, slot_pos);
+    c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
+  } else {
+    const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, slot_pos);
+    c_lo = si[chr]; c_hi = si[chr + 1];
+  }
+  const uint32_t g = slot_pos - seed_i;
+  ok = active && (slot_pos - c_lo >= seed_i) && (g + len < c_hi);
+  gp = ok ? g : 0u;
+  mm = 0;
+  uint32_t tmm = 0;
+  if (ok) mm = count_mismatch_tail<NW>(sv.g2, gp, rd, mk, seed_i, cut, tmm);  // (a candidate inside its chromosome: every care character lies in the genome)
+  tail_ok = tmm == 0;
 }
 
 // ---- candidates of a wave-cooperative region: G groups of 64 consecutive index slots per step ----

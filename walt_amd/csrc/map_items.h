@@ -216,6 +216,81 @@ __device__ __forceinline__ void tail_items_narrow(const IndexView& iv, uint32_t 
   }
 }
 
+// The same for patterns 5 / 7, whose tail characters (up to 36 of them) span several words of read and record: the
+// samples are compared with the read character by character (lexicographic state instead of a packed key); the
+// record's words and the read shifted by the seed shift make every character's place a compile-time constant.
+template <int NW, class Sink>
+__device__ __forceinline__ void tail_items_narrow_wide(const IndexView& iv, uint32_t strand_base, const ItemQueue& q,
+                                                       uint32_t n_items, uint32_t n_big, uint32_t b) {
+  static_assert(NW <= 10 && kPat != 3 && long_seed_nw<NW>(), "seeds beyond the 44 key characters, patterns 5 and 7");
+  constexpr uint32_t Q = item_quads<NW>();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_items + n_big; i += n_waves) {
+    uint4* const it = i < n_big ? q.bigs + (uint64_t)Q * i : q.items + (uint64_t)Q * (i - n_big);
+    const uint4 h = load_global(it + (lane < Q ? lane : 0u));
+    const uint32_t tail = bcast(h.z, 1);
+    if (!tail) continue;  // (uniform)
+    const uint32_t id = bcast(h.x, 0), l = bcast(h.y, 0), size = bcast(h.z, 0), rec0 = bcast(h.w, 0);
+    const uint32_t len = bcast(h.x, 1), seed_i = bcast(h.y, 1);
+    if (size <= 1 || rec0 == kItemDenseNone) continue;
+    const uint32_t seed_len = len >= kMinReadLen ? seed_len_of(seed_repeats(len)) : 0u;
+    uint32_t rd[NW + 1];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int a = 8 + w;
+      const uint32_t va = (a & 3) == 0 ? h.x : (a & 3) == 1 ? h.y : (a & 3) == 2 ? h.z : h.w;
+      rd[w] = bcast(va, a >> 2);
+    }
+    rd[NW] = 0;
+    uint32_t rs[NW];  // the read from its seed shift on
+#pragma unroll
+    for (int w = 0; w < NW; ++w) rs[w] = funnel_r(rd[w], rd[w + 1], 2 * seed_i);
+    const uint32_t s_at = (uint32_t)(((unsigned long long)lane * size) >> 6);  // sample positions rise with the lane
+    const StrandView& sv = iv.s[strand_base + Sink::strand(id)];
+    const uint4* rp = reinterpret_cast<const uint4*>(sv.win) + 2 * ((uint64_t)rec0 + s_at);
+    const uint4 ra = load_global(rp), rc = load_global(rp + 1);
+    uint4 re = make_uint4(0, 0, 0, 0);
+    if constexpr (NW > 7) re = load_global(reinterpret_cast<const uint4*>(sv.win2) + ((uint64_t)rec0 + s_at));
+    const uint32_t gw[11] = {ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w, re.x, re.y, re.z, re.w};  // bases from pos - kWinLead
+    bool lt = false, gt = false;  // the sample's tail characters against the read's, first difference decides
+#pragma unroll
+    for (uint32_t p = kKeyWeight + kKeyChars; p < kNumCare; ++p) {
+      constexpr uint32_t kLimit = 16u * (NW < 10 ? NW : 10);
+      const uint32_t o = care_pos(p);              // read offset behind the seed shift
+      const uint32_t g = care_pos(p) + kWinLead;   // base index in the record
+      if (o < kLimit && g < 176u) {
+        const uint32_t cr = (rs[o >> 4] >> (2u * (o & 15u))) & 3u;
+        const uint32_t cg = (gw[g >> 4] >> (2u * (g & 15u))) & 3u;
+        const bool on = p < seed_len && !lt && !gt;
+        lt = lt || (on && cg < cr);
+        gt = gt || (on && cg > cr);
+      }
+    }
+    const unsigned long long below = __ballot(lt), not_above = __ballot(!gt);
+    const uint32_t L = (uint32_t)__popcll(below), G = (uint32_t)__popcll(not_above);  // prefixes of the lanes: the range is sorted
+    const uint32_t s_prev = (uint32_t)(((unsigned long long)(L ? L - 1 : 0u) * size) >> 6);
+    const uint32_t s_next = (uint32_t)(((unsigned long long)(G < 64u ? G : 63u) * size) >> 6);
+    uint32_t lo = L ? s_prev + 1 : 0u, hi = G < 64u ? s_next : size;
+    if (lo >= hi) { lo = lo < size ? lo : size - 1; hi = lo + 1; }  // no member: one candidate that is none stays (the region is empty)
+    const uint32_t s_first = (uint32_t)(((unsigned long long)L * size) >> 6), s_last = (uint32_t)(((unsigned long long)(G ? G - 1 : 0u) * size) >> 6);
+    const bool over_b = G > L && s_last - s_first + 1 > b;
+    if (over_b) hi = lo + 1;
+    if (lane == 0) {
+      it[0] = make_uint4(id, l + lo, hi - lo, rec0 + lo);
+      if (over_b) it[1] = make_uint4(len, seed_i, 2u, 0u);
+    }
+  }
+}
+
+template <int W, int N>
+__device__ __forceinline__ void tail_words(uint32_t (&t)[N], uint32_t seed_i, uint32_t cut) {
+  if constexpr (W < N) {
+    t[W] = tail_care_mask_word<W>(seed_i, cut);
+    tail_words<W + 1>(t, seed_i, cut);
+  }
+}
+
 // The item loop of a verifier kernel: one region per wavefront, everything about the item wave-uniform, so a lane
 // carries little besides the records it has in flight and the kernel runs at high occupancy.  Wavefronts take
 // items in batches from the queue's cursor (regions run from 17 to `-b` candidates: a static deal
@@ -302,10 +377,19 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
   // seed_i + 1 + 3 p = 133 .. 150, i.e. in words 8 and 9 of the read: a 64-bit mask over bases 128 .. 159
   uint32_t id = 0, l = 0, size = 1, rec0 = 0, len = 0, seed_i = 0, tail = 0, rd[NW], mk[NW];
   unsigned long long tm64 = 0;
+  // patterns 5 / 7: the tail characters span several words; their mask per word (core.h tail_care_mask_word), all zero
+  // for an item that is no tail item
+  constexpr bool kTailWide = kPat != 3 && DENSE && NW <= 10 && long_seed_nw<NW>();
+  uint32_t tmw[kTailWide ? NW : 1];
   auto decode = [&](const uint4& h) {
     id = bcast(h.x, 0); l = bcast(h.y, 0); size = bcast(h.z, 0); rec0 = bcast(h.w, 0);
     len = bcast(h.x, 1); seed_i = bcast(h.y, 1); tail = bcast(h.z, 1);
     tm64 = 0;
+    if constexpr (kTailWide) {
+      const uint32_t seed_len = len >= kMinReadLen ? seed_len_of(seed_repeats(len)) : 0u;
+      const uint32_t cut = tail ? tail_care_cut(seed_i, seed_len) : 0u;
+      tail_words<0>(tmw, seed_i, cut);
+    }
     if constexpr (NW > 8 && NW <= 10 && DENSE && kPat == 3) {  // only reads above 134 bases have seeds beyond the 44 characters of the keys
       const uint32_t seed_len = (tail && len >= kMinReadLen) ? seed_len_of(seed_repeats(len)) : 0u;
 #pragma unroll
@@ -396,8 +480,15 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
                                     NW > 7 ? x.e[u].x : 0u, NW > 7 ? x.e[u].y : 0u, NW > 7 ? x.e[u].z : 0u, NW > 7 ? x.e[u].w : 0u};
 #pragma unroll
         for (int w = 0; w <= NW; ++w) wv[w] = w < 11 ? first[w] : 0u;
-        const uint32_t m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
+        uint32_t m;
         bool in = k < size;
+        if constexpr (kTailWide) {  // the candidate's care characters >= 44 against the read's
+          uint32_t tmm;
+          m = count_mismatch_regs2<NW>(wv, 2 * (kWinLead - seed_i), rd, mk, tmw, tmm);
+          in = in && tmm == 0 && tail != 2u;  // (tail == 2: the region was proved larger than -b, tail_items_narrow_wide)
+        } else {
+          m = count_mismatch_regs<NW>(wv, 2 * (kWinLead - seed_i), rd, mk);
+        }
         if constexpr (NW > 8 && NW <= 10 && kPat == 3) {  // the candidate's care characters >= 44 against the read's (words 8, 9)
           const uint32_t shv = 2 * (kWinLead - seed_i);
           const uint32_t x8 = funnel_r(wv[8], wv[9], shv) ^ rd[8], x9 = funnel_r(wv[9], wv[10], shv) ^ rd[9];

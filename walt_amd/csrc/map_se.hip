@@ -286,19 +286,19 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
   stamp(st, 7);
 }
 
-#if WALT_SEEDPATTERN == 3  // the seed-major pass-1 kernel is built for the default pattern (core.h probe_is_dangerous)
 // ---------------------------------------------------------------------------
 // Pass 1, seed-major: for each seed shift the '+' and '-' strand probes of a read
 // are issued TOGETHER (directory loads of both strands, then both slots' entries,
 // then both genome windows), because the kernel is bound by dependent round trips
 // (Little's law: ~330 k lanes in flight / ~19 dependent trips per read), not by
 // instruction issue.  The reference order is strand-major (+s0 +s1 +s2 -s0 -s1 -s2,
-// mapping.cpp:491-499, 248-263) and its early exits depend on the running best, so:
+// mapping.cpp:491-499, 248-263; written for pattern 3 and its three seed shifts, the same for the five / seven of
+// patterns 5 / 7 since round 3) and its early exits depend on the running best, so:
 //   * '+' summaries are folded immediately (their need is known exactly);
 //   * a '-' probe is computed when it MIGHT be needed (best so far, including the
 //     '-' summaries already seen, has not reached the exit value) -- a superset of
 //     the reference's probes -- and its RegionSummary is kept;
-//   * after seed 2 the '-' summaries are folded in order under the exact exit
+//   * after the last seed the '-' summaries are folded in order under the exact exit
 //     conditions.  A RegionSummary does not depend on the running best (the
 //     reference's mismatch-loop cut-off only truncates counts that lose anyway),
 //     so the result is identical; unused speculative probes are only extra work.
@@ -309,29 +309,36 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 constexpr uint32_t kMidRegion = 16;  // heavy pass: regions up to this size are verified by their own lane, in batches
 
 // ---- staged heavy pass --------------------------------------------------------------------------------------
-// The heavy list is mapped in four stages per chunk of `hcap` reads: stage k = 0, 1, 2 does what the monolithic
+// The heavy list is mapped in kPat + 1 stages per chunk of `hcap` reads: stage k = 0 .. kPat - 1 does what the monolithic
 // heavy kernel does for seed shift k (both strands' lookups, the regions of up to kMidRegion candidates) but turns
 // every larger region into a work ITEM instead of borrowing the wavefront for it; k_se_verify streams the items
 // with one wavefront per region and writes their RegionSummary; stage k + 1 starts by reading the summaries of
-// the seeds before it (they decide which probes the reference makes next, mapping.cpp:250-257); stage 3 only
-// folds and writes the record.  State per read of the chunk: six summaries (seed x strand) and a flag.
+// the seeds before it (they decide which probes the reference makes next, mapping.cpp:250-257); stage kPat only
+// folds and writes the record.  State per read of the chunk: 2 kPat summaries (seed x strand) and a flag.
 struct HeavyStage {
-  uint4* sums;       // [6][hcap]: RegionSummary of (seed, strand) = sums[(2 * seed + strand) * hcap + j]
+  uint4* sums;       // [2 kPat][hcap]: RegionSummary of (seed, strand) = sums[(2 * seed + strand) * hcap + j]
   uint32_t* flag;    // [hcap]: 1 = the read went to the literal list at an earlier stage
   uint4* items;      // 2 * hcap items of item_quads<NW>() 16-byte words; dense items from the front, gather items from the back
   uint4* giants;     // hcap / 8 items: the dense regions of more than kBigFirst candidates, verified first (count: ctl[5])
   uint32_t* ctl;     // this (chunk, stage)'s counters: [0] dense items, [1] gather items, [2] [3] the verifiers' cursors,
                      // [4] reads that go on to the next stage
-  const uint32_t* list_in;  // stages 1, 2: the chunk positions j this stage visits (count in count_in[4]); else every j
+  const uint32_t* list_in;  // stages 1 .. kPat - 1: the chunk positions j this stage visits (count in count_in[4]); else every j
   const uint32_t* count_in;
-  uint32_t* list_out;       // stages 0, 1: positions that may need the next seed
+  uint32_t* list_out;       // stages 0 .. kPat - 2: positions that may need the next seed
   uint32_t hcap;     // reads per chunk
   uint32_t first;    // heavy-list index of the chunk's first read (even == 0)
   uint32_t chunk;    // even != 0: the heavy list is cut into an EVEN number of equal chunks of at most hcap reads, and
   uint32_t even;     // this is chunk number `chunk` of them (heavy_chunk_span; the list's length is known on the device only)
-  uint32_t stage;    // 0..2: seed shift of the stage, 3: final fold
+  uint32_t stage;    // 0 .. kPat - 1: seed shift of the stage, kPat: final fold
   uint32_t defer_min;  // long seeds: key-equal ranges of more slots than this are narrowed by the verifier (0xFFFFFFFF: never)
 };
+// does the reference probe seed shift seed_i when the best mismatch count so far is mm?  (mapping.cpp:248-263: never
+// again after an exact match; after a one-mismatch match only the first kExitOneMismatch shifts.)  Monotone: a larger
+// mm never needs fewer seeds, a later seed is never needed when an earlier one is not.
+__device__ __forceinline__ bool seed_needed(uint32_t mm, uint32_t seed_i) {
+  return seed_i == 0 || (mm != 0 && !(mm == 1 && seed_i >= kExitOneMismatch));
+}
+
 // chunk c of the heavy list of H reads (HeavyStage::even): first read and number of reads
 __device__ __forceinline__ void heavy_chunk_span(uint32_t H, uint32_t hcap, uint32_t c, uint32_t& first, uint32_t& len) {
   uint32_t k = (H + hcap - 1) / hcap;
@@ -374,11 +381,15 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
 
   BestMatch best;  // mapping.cpp:486
   best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
-  RegionSummary m0 = summary_empty(), m1 = summary_empty(), m2 = summary_empty();  // '-' strand, per seed
+  RegionSummary mneg[kPat];  // '-' strand, per seed
+#pragma unroll
+  for (uint32_t k = 0; k < kPat; ++k) mneg[k] = summary_empty();
   uint32_t minus_lb = 0xFFFFFFFFu;  // smallest mismatch count any kept '-' summary holds
+  constexpr bool kLong = long_seed_nw<NW>();  // seeds of more than the 44 characters of hash + key exist
+  const uint32_t seed_len = seed_len_of(lr.repeats);
 
 #pragma unroll 1
-  for (uint32_t seed_i = 0; seed_i < 3; ++seed_i) {
+  for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
     RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
     bool replay = false;
     if constexpr (STAGED) {
@@ -386,10 +397,10 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       replay = seed_i < hs.stage;  // a seed of an earlier stage: its summaries are in the state arrays
     }
     // '+': exact (mapping.cpp:250-257 with the state after the '+' folds so far)
-    bool need_p = mappable && (seed_i == 0 || (seed_i == 1 ? best.mismatch != 0 : best.mismatch > 1));
+    bool need_p = mappable && seed_needed(best.mismatch, seed_i);
     // '-': superset of the reference's decision (see header comment)
     const uint32_t lb = best.mismatch < minus_lb ? best.mismatch : minus_lb;
-    bool need_m = mappable && (seed_i == 0 || (seed_i == 1 ? lb != 0 : lb > 1));
+    bool need_m = mappable && seed_needed(lb, seed_i);
     if (replay) {
       // only what the stage of this seed computed: a read that left the stage lists early (its need was already
       // decided by part of the summaries; more of them only lower the best) has nothing valid stored for later seeds
@@ -407,7 +418,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
 
     uint32_t care[kCareWords] = {0, 0, 0, 0};
     uint32_t slot = 0, span = 0;
-    if (need_p || need_m) seed_query<NW>(lr.rd, lr.repeats, seed_i, ga, Bd, sh.pcode4, care, slot, span);
+    if (need_p || need_m) seed_query<NW>(lr.rd, seed_len, seed_i, ga, Bd, sh.pcode4, care, slot, span);
     stamp(st, 1);
     // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
     const uint32_t bkey = bloom_key_of_care(care);
@@ -441,7 +452,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
           deferred = true;
           mappable = false;
           need_p = need_m = false;
-          defer_iter = seed_i + (dng_p ? 0u : 3u);
+          defer_iter = seed_i + (dng_p ? 0u : kPat);  // (grouping only: map_common.h kDeferShift)
+          defer_iter = defer_iter < 7u ? defer_iter : 7u;
         }
       }
     }
@@ -460,14 +472,21 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     Lookup lp, lm;
     bool tail_p, tail_m;
     bool defer_p = false, defer_m = false;  // staged, long seeds: the verifier narrows the key-equal range (map_common.h DEFER)
-    if constexpr (HEAVY && STAGED && (NW > 8) && (NW <= 10)) {
-      probe_resolve_dual<true, true>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m, &defer_p, &defer_m, hs.defer_min,
+    if constexpr (HEAVY && STAGED && kLong && (NW <= 10)) {
+      probe_resolve_dual<true, true>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m, &defer_p, &defer_m, hs.defer_min,
                                      win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len));
     } else if constexpr (HEAVY) {
-      probe_resolve_dual<(NW > 8)>(svp, svm, pp, pm, care, lr.repeats, lp, lm, tail_p, tail_m);
+      probe_resolve_dual<kLong>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m);
     } else {
-      probe_resolve<(NW > 8)>(svp, pp, care, lr.repeats, lp, tail_p);
-      probe_resolve<(NW > 8)>(svm, pm, care, lr.repeats, lm, tail_m);
+      bool unres_p = false, unres_m = false;  // patterns 5 / 7: a key-equal range of several slots still owes its tail characters
+      probe_resolve<kLong>(svp, pp, care, seed_len, lp, tail_p, &unres_p);
+      probe_resolve<kLong>(svm, pm, care, seed_len, lm, tail_m, &unres_m);
+      if (unres_p || unres_m) {  // the heavy pass narrows it
+        heavy = true;
+        mappable = false;
+        lp.reg = empty_region(); lm.reg = empty_region();
+        lp.npos = lm.npos = 0;
+      }
     }
     stamp(st, 3);
 
@@ -499,13 +518,22 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
         bool ok_p, ok_m;
         uint32_t gp_p, gp_m, mm_p, mm_m;
-        verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
-        verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
-        if (NW > 8) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
-          // inactive lanes carry no valid position: read from 0 like verify_nobranch does
-          const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, lr.repeats), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, lr.repeats);
+        if constexpr (kLong && kPat != 3) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
+          bool t_p, t_m;
+          const uint32_t cut = tail_care_cut(seed_i, seed_len);
+          verify_nobranch_tail<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, cut, ok_p, gp_p, mm_p, t_p);
+          verify_nobranch_tail<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, cut, ok_m, gp_m, mm_m, t_m);
           ok_p = ok_p && (!tail_p || t_p);
           ok_m = ok_m && (!tail_m || t_m);
+        } else {
+        verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+        verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+        if (kLong) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
+          // inactive lanes carry no valid position: read from 0 like verify_nobranch does
+          const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, seed_len), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, seed_len);
+          ok_p = ok_p && (!tail_p || t_p);
+          ok_m = ok_m && (!tail_m || t_m);
+        }
         }
         if (ok_p) { sum_p = summary_merge(sum_p, summary_one(mm_p, gp_p)); ++ctr.verified; }
         if (ok_m) { sum_m = summary_merge(sum_m, summary_one(mm_m, gp_m)); ++ctr.verified; }
@@ -639,30 +667,35 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
       // this stage's summaries: what the lane worked out itself now, the items' when k_se_verify has run
       if (valid && !pend_p) hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j] = make_uint4(sum_p.min_mm, sum_p.count, sum_p.first, sum_p.last);
       if (valid && !pend_m) hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j] = make_uint4(sum_m.min_mm, sum_m.count, sum_m.first, sum_m.last);
-      if (seed_i < 2) {
-        // the next seed is probed on '+' while the best of the '+' strand is above seed_i (mapping.cpp:250-257), and
-        // never on '-' otherwise (the '-' bound is at most the '+' best); pending summaries can only lower it
+      if (seed_i + 1 < kPat) {
+        // the next seed is probed on '+' while the best of the '+' strand asks for it (seed_needed, mapping.cpp:250-257),
+        // and never on '-' otherwise (the '-' bound is at most the '+' best); pending summaries can only lower it
         const uint32_t known = (!pend_p && sum_p.count && sum_p.min_mm < best.mismatch) ? sum_p.min_mm : best.mismatch;
-        wavelist_append(*wl_heavy, mappable && known > seed_i, j, &hs.ctl[4], hs.list_out);  // (the staged kernels' use of the buffer)
+        wavelist_append(*wl_heavy, mappable && seed_needed(known, seed_i + 1), j, &hs.ctl[4], hs.list_out);  // (the staged kernels' use of the buffer)
       }
       break;
     }
     }  // !replay
     fold_region(best, sum_p, '+');  // empty when the '+' probe was not needed
-    if (seed_i == 0) m0 = sum_m; else if (seed_i == 1) m1 = sum_m; else m2 = sum_m;
+#pragma unroll
+    for (uint32_t k = 0; k < kPat; ++k)  // (selects: an index into the array would send it to scratch)
+      if (seed_i == k) mneg[k] = sum_m;
     if (sum_m.count && sum_m.min_mm < minus_lb) minus_lb = sum_m.min_mm;
   }
   // '-' strand folds in reference order under the exact exit conditions
-  fold_region(best, m0, '-');
-  if (best.mismatch != 0) {
-    fold_region(best, m1, '-');
-    if (best.mismatch > 1) fold_region(best, m2, '-');
+  {
+    bool go = true;
+#pragma unroll
+    for (uint32_t k = 0; k < kPat; ++k) {
+      go = go && seed_needed(best.mismatch, k);
+      if (go) fold_region(best, mneg[k], '-');
+    }
   }
   wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, defer_count, defer_list);
   if constexpr (!HEAVY) wavelist_append(*wl_heavy, heavy && !deferred, r, heavy_count, heavy_list);  // (buffered: map_common.h WaveList)
   if constexpr (STAGED) {
     if (hs.stage == 0 ? valid || deferred : deferred) hs.flag[j] = deferred ? 1u : 0u;
-    if (hs.stage == 3 && valid) out[r] = best;
+    if (hs.stage == kPat && valid) out[r] = best;
     // the stage's own work (the literal pass counts a deferred read's again: these counters are diagnostic)
     ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big;
   } else {
@@ -671,8 +704,6 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
   }
   stamp(st, 7);
 }
-
-#endif  // WALT_SEEDPATTERN == 3
 
 __device__ __forceinline__ void flush_counters(const MapCounters& ctr, uint32_t shortv,
                                                unsigned long long* __restrict__ shards) {
@@ -777,7 +808,6 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
   hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(kStatShards), 0, stream, d_shards, d_stats);
 }
 
-#if WALT_SEEDPATTERN == 3
 // pass 1: every read of the batch, one per lane (HEAVY = false); pass 1b: the reads of the heavy list (HEAVY = true)
 template <int NW, bool DIAG, bool HEAVY, bool STAGED = false, int OCC = 0>  // OCC: wavefronts per SIMD the registers are capped for (0: the default below)
 __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 : 3) : (NW <= 10 ? (STAGED ? 3 : 2) : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
@@ -922,7 +952,7 @@ struct SummarySink {
 // the tail items of a stage bracketed before the verifier streams them (map_items.h tail_items_narrow)
 template <int NW>
 __global__ __launch_bounds__(kBlock) void k_se_tail_narrow(IndexView iv, uint32_t strand_base, HeavyStage hs, uint32_t b) {
-  if constexpr (NW > 8 && NW <= 10) {
+  if constexpr (NW <= 10 && long_seed_nw<NW>()) {
     ItemQueue q;
     q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
     q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
@@ -930,7 +960,8 @@ __global__ __launch_bounds__(kBlock) void k_se_tail_narrow(IndexView iv, uint32_
     n_big = n_big < q.big_cap ? n_big : q.big_cap;
     uint32_t n_items = q.ctl[0];
     n_items = n_items < q.cap ? n_items : q.cap;
-    tail_items_narrow<NW, SummarySink>(iv, strand_base, q, n_items, n_big, b);
+    if constexpr (kPat == 3) tail_items_narrow<NW, SummarySink>(iv, strand_base, q, n_items, n_big, b);
+    else tail_items_narrow_wide<NW, SummarySink>(iv, strand_base, q, n_items, n_big, b);
   }
 }
 
@@ -960,8 +991,6 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
   else item_stream<NW, DENSE, false, SummarySink, G>(iv, strand_base, q, n_items, s_start, sink, n_big, edge);
   flush_counters({0u, sink.n_verified, 0u}, 0u, stats);
 }
-
-#endif  // WALT_SEEDPATTERN == 3
 
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
 template <int NW, bool LITERAL = true>
@@ -1012,11 +1041,11 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 // staged heavy pass: reads per chunk of the heavy list and the bytes of its state behind the dense read array:
-// [256 control words] then per state slot [flag][two stage lists][6 summaries][2 x 2 item words][giants].
+// [control words] then per state slot [flag][kPat - 1 stage lists][2 kPat summaries][2 x 2 item words][giants].
 // Round 3: the list is mapped in two halves on two streams (launch_map_se), each with its own state slot: chunks of an
 // eighth of the batch (the heavy reads of an hg19-like genome, a sixth of all, make one chunk per half), cut evenly on
 // the device (heavy_chunk_span).  WALT_AMD_SE_PIPE=0: one stream, one slot, chunks of a quarter (rounds 2's schedule).
-constexpr uint32_t kHeavyCtlWords = 256;  // 8 words per (chunk, stage): up to 8 chunks x 3 stages
+constexpr uint32_t kHeavyCtlWords = 64 * kPat + 64;  // 8 words per (chunk, stage): up to 8 chunks x kPat stages; then the literal side launch's 64
 static int se_pipe_mode() {
   static const int mode = [] { const char* e = getenv("WALT_AMD_SE_PIPE"); return e ? atoi(e) : 1; }();
   return mode;
@@ -1036,7 +1065,7 @@ static uint32_t se_heavy_chunks(uint32_t n) {  // <= 8
 static bool se_heavy_piped(uint32_t n) { return se_pipe_mode() != 0 && se_heavy_chunks(n) > 1; }
 static uint64_t se_heavy_slot_bytes(uint64_t hcap, int nw) {
   const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
-  return 3 * hcap * 4 + hcap * 6 * 16 + (2 * hcap + hcap / 8) * quads * 16;  // flag + two stage lists; summaries; items + giants
+  return kPat * hcap * 4 + hcap * 2 * kPat * 16 + (2 * hcap + hcap / 8) * quads * 16;  // flag + kPat - 1 stage lists; summaries; items + giants
 }
 static uint64_t se_heavy_bytes(uint32_t n, int nw) {
   return 16 + kHeavyCtlWords * 4 + (se_heavy_piped(n) ? 2 : 1) * se_heavy_slot_bytes(se_heavy_chunk(n), nw);
@@ -1062,19 +1091,6 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                          uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
                          uint32_t* heavy_area, hipStream_t stream) {
-#if WALT_SEEDPATTERN != 3
-  (void)stride;
-  (void)heavy_area;
-  // patterns 5 / 7: strand-major kernel over every read with the directory/key search, Bloom hits deferred
-  // (untagged order) to the literal pass
-  const unsigned g1 = grid_for(n) < 4 * kLiteralGrid ? grid_for(n) : 4 * kLiteralGrid;
-  hipLaunchKernelGGL((k_map_se_literal<NW, false>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, n);
-  const unsigned g2 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
-  hipLaunchKernelGGL((k_map_se_literal<NW, true>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err,
-                     strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u);
-  return WALT_OK;
-#else
   unsigned pg = kPersistentGrid;
   if (const char* e = getenv("WALT_AMD_GRID")) pg = atoi(e) > 0 ? (unsigned)atoi(e) : grid_for(n);  // diagnostic knob
   const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
@@ -1134,9 +1150,9 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     const uint64_t slot_words = se_heavy_slot_bytes(hcap, NW) / 4;
     auto use_slot = [&](uint32_t k, uint32_t*& lists) {
       hs.flag = heavy_area + kHeavyCtlWords + k * slot_words;
-      lists = hs.flag + hcap;  // [2][hcap]: what stage 0 hands to stage 1, stage 1 to stage 2
-      hs.sums = reinterpret_cast<uint4*>(lists + 2 * (uint64_t)hcap);
-      hs.items = hs.sums + (uint64_t)6 * hcap;  // 2 * hcap items of item_quads<NW>() quads
+      lists = hs.flag + hcap;  // [kPat - 1][hcap]: what stage k hands to stage k + 1
+      hs.sums = reinterpret_cast<uint4*>(lists + (kPat - 1) * (uint64_t)hcap);
+      hs.items = hs.sums + (uint64_t)(2 * kPat) * hcap;  // 2 * hcap items of item_quads<NW>() quads
       hs.giants = hs.items + (uint64_t)2 * hcap * item_quads<NW>();
     };
     static const uint32_t defer_min = [] {  // WALT_AMD_DEFER=0: never (A/B); =n: ranges of more than n slots (n >= the in-lane limit)
@@ -1166,8 +1182,8 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     // at the end as before.  WALT_AMD_LIT_SIDE=0: the whole literal pass at the end.
     static const bool lit_side_on = [] { const char* e = getenv("WALT_AMD_LIT_SIDE"); return !(e && atoi(e) == 0); }();
     lit_side = lit_side_on && !diag && n <= kDeferMask;
-    uint32_t* const ctl2 = ctl0 + 200;  // [0] count of the side launch, [8..23] its bins
-    uint32_t* const rng = ctl0 + 232;   // {entries the side launch took, the list's final length}
+    uint32_t* const ctl2 = ctl0 + 64 * kPat + 8;  // [0] count of the side launch, [8..23] its bins
+    uint32_t* const rng = ctl2 + 32;              // {entries the side launch took, the list's final length}
     if (lit_side && !idx->se_side) {
       int lo_pri = 0, hi_pri = 0;
       WALT_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
@@ -1193,13 +1209,13 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       // chunks behind the first pair append to the deferred list: not while the side launch's share is being fixed
       if (piped && lit_side && c == 2) WALT_HIP(hipStreamWaitEvent(stream, idx->se_fork, 0));
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
-      for (uint32_t stage = 0; stage < 4; ++stage) {
+      for (uint32_t stage = 0; stage <= kPat; ++stage) {
         hs.stage = stage;
-        hs.ctl = ctl0 + 8 * (3 * c + (stage < 3 ? stage : 0));
-        const bool listed = stage == 1 || stage == 2;
+        hs.ctl = ctl0 + 8 * (kPat * c + (stage < kPat ? stage : 0));
+        const bool listed = stage >= 1 && stage < kPat;
         hs.list_in = listed ? lists + (uint64_t)(stage - 1) * hcap : nullptr;
-        hs.count_in = listed ? ctl0 + 8 * (3 * c + stage - 1) : nullptr;
-        hs.list_out = stage < 2 ? lists + (uint64_t)stage * hcap : nullptr;
+        hs.count_in = listed ? ctl0 + 8 * (kPat * c + stage - 1) : nullptr;
+        hs.list_out = stage + 1 < kPat ? lists + (uint64_t)stage * hcap : nullptr;
         if (diag2)
           hipLaunchKernelGGL((k_map_se<NW, true, true, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
@@ -1213,9 +1229,9 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                              n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
                              heavy_list, 0u, nullptr, hs);
         if (!odd) mark(1);
-        if (stage == 3) break;
-        if (piped && c == 0 && stage == 2) WALT_HIP(hipEventRecord(idx->se_pipe_ev[1], stream));
-        if (lit_side && c == (piped ? 1u : 0u) && stage == 2) {
+        if (stage == kPat) break;
+        if (piped && c == 0 && stage == kPat - 1) WALT_HIP(hipEventRecord(idx->se_pipe_ev[1], stream));
+        if (lit_side && c == (piped ? 1u : 0u) && stage == kPat - 1) {
           if (piped) WALT_HIP(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));  // both halves' first chunks have made their last deferrals
           hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, cs, defer_count, ctl2, rng);
           WALT_HIP(hipEventRecord(idx->se_fork, cs));
@@ -1226,7 +1242,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                              strand_base, max_mm, b, idx->d_mask_table, out, stats, ctl2, defer_list + stride, 0u);
           WALT_HIP(hipEventRecord(idx->se_join, idx->se_side));
         }
-        if constexpr (NW > 8 && NW <= 10)
+        if constexpr (NW <= 10 && long_seed_nw<NW>())
           hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(256 * 8), dim3(kBlock), 0, cs, view, strand_base, hs, b);
         if constexpr (NW <= 10) {
           hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b);
@@ -1243,10 +1259,11 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
   debug_sync("heavy pass", stream);
   mark(1);  // (the one-kernel heavy pass, when that is what ran)
   if (lit_side) {  // what the chunks behind the first one deferred (usually nothing), then the side launch ends the call
-    hipLaunchKernelGGL(k_lit_rest, dim3(1), dim3(1), 0, stream, defer_count, heavy_area + 232);
+    uint32_t* const rng = heavy_area + 64 * kPat + 40;
+    hipLaunchKernelGGL(k_lit_rest, dim3(1), dim3(1), 0, stream, defer_count, rng);
     unsigned g3 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
     hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g3), dim3(kBlock), 0, stream, view, codes2, offsets, err,
-                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, heavy_area + 232);
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, rng);
     WALT_HIP(hipStreamWaitEvent(stream, idx->se_join, 0));
     mark(3);
     return WALT_OK;
@@ -1261,7 +1278,6 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
   debug_sync("literal pass", stream);
   mark(3);
   return WALT_OK;
-#endif
 }
 
 int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n, uint32_t max_read_len,
