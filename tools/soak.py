@@ -116,6 +116,13 @@ def run_soak(seconds, seed0=1, pattern=3, max_genomes=None):
                 os.environ.pop("WALT_AMD_TABLE", None)
             idx = walt_amd.Index.open(path, device=0, dir_bits=D)
             lengths = [lo + 2, lo + 3, 40, 45, 60, 100, 100, 100, 131, 140, min(150, hi), min(200, hi), hi]
+            # the kernels are instantiated per read-length class (up to 112, 128, 160 ... bases: the batch's longest read
+            # selects the instance): some genomes get batches that stop at 112 or 128 bases
+            cls = rng.choice(["all", "all", "le112", "le128"])
+            if cls == "le112":
+                lengths = [x for x in lengths if x <= 112] + [90, 96, 104, 110, 112]
+            elif cls == "le128":
+                lengths = [x for x in lengths if x <= 128] + [100, 113, 119, 120, 125, 128]
             m, b, k = rng.choice([0, 2, 6, 10]), rng.choice([2, 30, 5000]), rng.choice([2, 5, 50, 300])
             for conv, ag in (("CT", False), ("GA", True)):
                 reads = sample(rng, seqs, 1500, conv, lengths, refio)

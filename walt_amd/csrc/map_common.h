@@ -508,7 +508,7 @@ __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const 
                                                    const SlotProbe& pm, const uint32_t* care, uint32_t seed_len,
                                                    Lookup& lp, Lookup& lm, bool& tail_p, bool& tail_m,
                                                    bool* defer_p = nullptr, bool* defer_m = nullptr, uint32_t defer_min = 0,
-                                                   bool win_ok = false) {
+                                                   bool win_ok = false, uint32_t multi_max = 0) {
   const uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0u;
   const uint32_t nk = n < kKeyChars ? n : kKeyChars;
   const uint64_t M = key_mask(nk);
@@ -614,6 +614,14 @@ __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const 
         out.reg.l = a[f]; out.reg.u = a[f];
       } else if (kPat == 3 && LONG_SEED && size <= kLookupPos && out.npos == size) {
         out.reg = lit_region_small(sv, care, seed_len, a[f], size, out.pos, out.npos);
+      } else if (kPat != 3 && LONG_SEED && size <= multi_max) {
+        // patterns 5 / 7: a short key-equal range goes to the caller as it is, every candidate owing its tail characters
+        // (tail_check with a region of several slots).  The caller verifies all of them side by side and keeps those
+        // whose tail characters equal the read's -- IndexRegion's result when the range is sorted on them, which holds
+        // when every candidate passes the edge filters of mapping.cpp:280-286 (its tail characters then lie inside its
+        // chromosome, where makedb compared real characters); otherwise the caller falls back to lit_region.
+        tail_check = true;
+        out.reg.l = a[f]; out.reg.u = u[f];
       } else {
         out.npos = 0;
         out.reg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, a[f], u[f]);
@@ -664,6 +672,19 @@ __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const Bloc
   // only lanes with a candidate touch memory: the mapping kernels are bound by the number of per-lane
   // accesses the L1 (TCP) processes, not by instruction issue, so an idle lane's dummy load is not free
   if (ok) mm = count_mismatch<NW>(sv.g2, gp, rd, mk);
+}
+
+// mismatches under the compare masks and at the seed's care characters >= 44 on NW + 1 window words in registers
+template <int NW, int W = 0>
+__device__ __forceinline__ void count_mismatch_regs_tail(const uint32_t* g, uint32_t sh, const uint32_t* rd, const uint32_t* mask,
+                                                         uint32_t seed_i, uint32_t cut, uint32_t& mm, uint32_t& tmm) {
+  if constexpr (W < NW) {
+    const uint32_t x = funnel_r(g[W], g[W + 1], sh) ^ rd[W];
+    const uint32_t d = x | (x >> 1);
+    mm += __popc(d & mask[W]);
+    tmm += __popc(d & tail_care_mask_word<W>(seed_i, cut));
+    count_mismatch_regs_tail<NW, W + 1>(g, sh, rd, mask, seed_i, cut, mm, tmm);
+  }
 }
 
 // the same with the seed's care characters >= 44 tested on the window the count loads (patterns 5 / 7; pattern 3 has

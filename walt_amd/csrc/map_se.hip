@@ -474,7 +474,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     bool defer_p = false, defer_m = false;  // staged, long seeds: the verifier narrows the key-equal range (map_common.h DEFER)
     if constexpr (HEAVY && STAGED && kLong && (NW <= 10)) {
       probe_resolve_dual<true, true>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m, &defer_p, &defer_m, hs.defer_min,
-                                     win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len));
+                                     win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len), kPat != 3 ? kMidRegion : 0u);
     } else if constexpr (HEAVY) {
       probe_resolve_dual<kLong>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m);
     } else {
@@ -493,8 +493,13 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
     uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
     ctr.probes += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
-    if (size_p > b && !defer_p) size_p = 0;  // mapping.cpp:275-277 (a deferred range: the verifier counts the region)
-    if (size_m > b && !defer_m) size_m = 0;
+    // patterns 5 / 7, staged: a key-equal range of several slots whose candidates owe their tail characters (probe_resolve_dual)
+    constexpr bool kMulti = HEAVY && STAGED && kLong && kPat != 3 && NW <= 10;
+    const bool multi_p = kMulti && tail_p && size_p > 1, multi_m = kMulti && tail_m && size_m > 1;
+    bool fb_p = false, fb_m = false;    // ... one of them fails an edge filter: the range may be unsorted there, lit_region decides
+    uint32_t nin_p = 0, nin_m = 0;      // ... those whose tail characters match: the region's size for -b
+    if (size_p > b && !defer_p && !multi_p) size_p = 0;  // mapping.cpp:275-277 (a deferred range: the verifier counts the region)
+    if (size_m > b && !defer_m && !multi_m) size_m = 0;
     if (ablate & 1u) size_p = size_m = 0;
     if (!HEAVY && (size_p > kSmallRegion || size_m > kSmallRegion)) {  // a large region: the heavy pass verifies it
       heavy = true;
@@ -523,6 +528,10 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
           const uint32_t cut = tail_care_cut(seed_i, seed_len);
           verify_nobranch_tail<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, cut, ok_p, gp_p, mm_p, t_p);
           verify_nobranch_tail<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, cut, ok_m, gp_m, mm_m, t_m);
+          fb_p = fb_p || (multi_p && act_p && !ok_p);
+          fb_m = fb_m || (multi_m && act_m && !ok_m);
+          nin_p += (multi_p && ok_p && t_p) ? 1u : 0u;
+          nin_m += (multi_m && ok_m && t_m) ? 1u : 0u;
           ok_p = ok_p && (!tail_p || t_p);
           ok_m = ok_m && (!tail_m || t_m);
         } else {
@@ -593,6 +602,9 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
             }
             const uint32_t g = pos - seed_i;
             ok[jj] = k0 + jj < nmid && (pos - c_lo >= seed_i) && (g + lr.len < c_hi);  // mapping.cpp:280-286
+            if constexpr (kMulti) {
+              if (k0 + jj < nmid && !ok[jj]) { fb_p = fb_p || (on_p && multi_p); fb_m = fb_m || (on_m && multi_m); }
+            }
             gpv[jj] = ok[jj] ? g : 0u;
             const uint32_t* gw = g2 + (gpv[jj] >> 4);
 #pragma unroll
@@ -607,8 +619,18 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
           }
 #pragma unroll
           for (uint32_t jj = 0; jj < 4; ++jj) {
-            const uint32_t mm = count_mismatch_regs<NW>(win[jj], 2 * (gpv[jj] & 15u), lr.rd, mk);
-            if (ok[jj]) {
+            uint32_t mm = 0;
+            bool keep = ok[jj];
+            if constexpr (kMulti) {
+              uint32_t tmm = 0;
+              count_mismatch_regs_tail<NW>(win[jj], 2 * (gpv[jj] & 15u), lr.rd, mk, seed_i, tail_care_cut(seed_i, seed_len), mm, tmm);
+              const bool mine = on_p ? multi_p : (on_m && multi_m);
+              keep = keep && (!mine || tmm == 0);
+              if (mine && keep) { if (on_p) ++nin_p; else ++nin_m; }
+            } else {
+              mm = count_mismatch_regs<NW>(win[jj], 2 * (gpv[jj] & 15u), lr.rd, mk);
+            }
+            if (keep) {
               acc = summary_merge(acc, summary_one(mm, gpv[jj]));
               ++ctr.verified;
             }
@@ -616,6 +638,30 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         }
         if (on_p) sum_p = acc;
         if (on_m) sum_m = acc;
+      }
+    }
+    if constexpr (kMulti) {
+      // the region's size is the number of candidates whose tail characters match (mapping.cpp:275-277); a range with a
+      // candidate at a chromosome's edge is narrowed the reference's way and verified one candidate after the other (rare)
+      if (multi_p && !fb_p && nin_p > b) sum_p = summary_empty();
+      if (multi_m && !fb_m && nin_m > b) sum_m = summary_empty();
+      if (__ballot(fb_p || fb_m)) {
+#pragma unroll 1
+        for (uint32_t fi = 0; fi < 2; ++fi) {
+          const bool mine = fi ? fb_m : fb_p;
+          if (!mine) continue;
+          const StrandView& sv = fi ? svm : svp;
+          const Region rg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, fi ? lm.reg.l : lp.reg.l, fi ? lm.reg.u : lp.reg.u);
+          RegionSummary acc = summary_empty();
+          if (rg.l <= rg.u && rg.u - rg.l + 1 <= b) {
+            for (uint32_t sl = rg.l; sl <= rg.u; ++sl) {
+              uint32_t gp_c, mm_c;
+              if (verify_candidate<NW>(sv, si, n_chrom, sv.ent[sl].pos, seed_i, lr.len, lr.rd, mk, gp_c, mm_c))
+                acc = summary_merge(acc, summary_one(mm_c, gp_c));
+            }
+          }
+          if (fi) sum_m = acc; else sum_p = acc;
+        }
       }
     }
     if constexpr (STAGED) {  // both strands' large regions become work items: one atomic for the two (map_items.h item_append2)
