@@ -915,13 +915,35 @@ __global__ __launch_bounds__(kBlock) void k_pe_topk_list(IndexView iv, const uin
 // kPushSmall slots do and all 64 lanes of a wavefront work -- and lists the others; SMALL = false maps the listed
 // ones with top_k slots each (kListHeapSlots / top_k reads per wavefront).
 constexpr uint32_t kPushSmall = 12;
+// The heaps of the second launch hold 4-byte entries -- mismatches (bits 0..10), the survivor's place = probe and
+// number in the probe's survivor list (bits 11..19 number, 20..22 probe) -- instead of (position, mismatches): the
+// comparator looks at the mismatches only (paired.hpp:39-41), the strand follows from the probe, and the position is
+// fetched for the entries that are left when the heap is emptied.  Twice the reads per wavefront for the same LDS
+// (30 at -k 50): the kernel is bound by instruction issue with a quarter of its lanes at work.
+static_assert(kPeChunks * kPeChunkEnts <= 512 && kPeMidRegion <= 512, "a survivor's number takes 9 bits");
+struct Heap4 {
+  uint32_t* w;
+  struct Ref {
+    uint32_t* p;
+    __device__ __forceinline__ operator HeapEnt() const {
+      const uint32_t v = *p;
+      HeapEnt e;
+      e.pos = v >> 11;                                            // place: probe << 9 | number
+      e.mms = (v & 0x7FFu) | ((v >> 20) >= 3u ? 0x80000000u : 0u);  // probes 3..5 are the '-' strand's
+      return e;
+    }
+    __device__ __forceinline__ Ref& operator=(const HeapEnt& e) { *p = (e.mms & 0x7FFu) | (e.pos << 11); return *this; }
+    __device__ __forceinline__ Ref& operator=(const Ref& o) { *p = *o.p; return *this; }
+  };
+  __device__ __forceinline__ Ref operator[](uint32_t i) const { return Ref{w + i}; }
+};
 template <bool SMALL>
 __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ list,
                                                     PeStage ps, uint32_t top_k, Candidate* __restrict__ ranked,
                                                     uint32_t* __restrict__ heap_n, uint32_t* __restrict__ fb_count,
                                                     uint32_t* __restrict__ fb_list, uint32_t first,
                                                     uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
-  __shared__ HeapEnt s_heap[kBlock / 64][kListHeapSlots];
+  __shared__ HeapEnt s_heap[kBlock / 64][kListHeapSlots];  // (second launch: 2 x kListHeapSlots 4-byte entries)
   uint32_t count;
   if (SMALL) {
     count = *list_count;
@@ -937,10 +959,13 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
   const uint32_t total_waves = gridDim.x * waves_per_block;
   const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
   const uint32_t cap = SMALL ? kPushSmall : top_k;
-  const uint32_t rpw_max = kListHeapSlots / cap < 64 ? kListHeapSlots / cap : 64;  // top_k <= 300: at least 2
+  constexpr uint32_t kSlots = SMALL ? kListHeapSlots : 2 * kListHeapSlots;
+  const uint32_t rpw_max = kSlots / cap < 64 ? kSlots / cap : 64;  // top_k <= 300: at least 2
   uint32_t rpw = (count + total_waves - 1) / total_waves;
   rpw = rpw < 1 ? 1 : (rpw > rpw_max ? rpw_max : rpw);
-  HeapEnt* heap = &s_heap[threadIdx.x >> 6][(lane < rpw ? lane : 0) * cap];
+  HeapEnt* heap = &s_heap[threadIdx.x >> 6][(lane < rpw ? lane : 0) * (SMALL ? cap : 0u)];
+  Heap4 heap4;
+  heap4.w = reinterpret_cast<uint32_t*>(&s_heap[threadIdx.x >> 6][0]) + (lane < rpw ? lane : 0) * cap;
   const uint64_t ccap = ps.ccap;
   for (uint64_t base = (uint64_t)wave * rpw; base < count; base += (uint64_t)total_waves * rpw) {
     const uint64_t i = base + lane;
@@ -965,7 +990,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
       for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
         // paired.cpp:133-149 (top only decreases: per-seed predicates equal the reference's `break`)
         const bool full = hsize >= top_k;
-        const uint32_t top_mm = hsize ? heap_mm(heap[0]) : 0xFFFFFFFFu;
+        const uint32_t top_mm = hsize ? (SMALL ? heap_mm(heap[0]) : (heap4.w[0] & 0x7FFu)) : 0xFFFFFFFFu;
         if ((full && top_mm == 0 && seed_i) || (full && top_mm == 1 && seed_i >= kExitOneMismatch)) continue;
         const uint32_t probe = 3 * fi + seed_i;
         const uint32_t sn = ps.surv_n[(uint64_t)probe * ccap + j];
@@ -986,7 +1011,12 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
           for (uint32_t t = 0; t < 8; ++t) {
             if (k0 + t < n) {
               HeapEnt e; e.pos = c[t].x; e.mms = c[t].y | (fi << 31);
-              topk_push(heap, hsize, top_k, e);  // paired.cpp:195
+              if constexpr (SMALL) {
+                topk_push(heap, hsize, top_k, e);  // paired.cpp:195
+              } else {
+                e.pos = (probe << 9) | (k0 + t);
+                topk_push(heap4, hsize, top_k, e);
+              }
             }
           }
         }
@@ -995,11 +1025,45 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
     // paired.cpp:685-692: pop everything; ranked[r][i] = i-th popped (descending mismatch)
     heap_n[r] = hsize;
     Candidate* out = ranked + (uint64_t)r * top_k;
-    uint32_t i2 = 0;
-    while (hsize) {
-      const HeapEnt e = heap_pop(heap, hsize);
-      Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
-      out[i2++] = c;
+    if constexpr (SMALL) {
+      uint32_t i2 = 0;
+      while (hsize) {
+        const HeapEnt e = heap_pop(heap, hsize);
+        Candidate c; c.genome_pos = e.pos; c.strand = (e.mms >> 31) ? '-' : '+'; c.mismatch = heap_mm(e);
+        out[i2++] = c;
+      }
+    } else {
+      // emptied in place: every pop moves the top to the end of the shrinking heap (__pop_heap), so afterwards entry
+      // n - 1 - i is the i-th popped; then the positions, eight entries per round of loads
+      const uint32_t n_ent = hsize;
+      while (hsize) heap_pop(heap4, hsize);
+      for (uint32_t i0 = 0; i0 < n_ent; i0 += 8) {
+        uint32_t v[8], sn[8], ch[8];
+        uint2 c[8];
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+          v[t] = heap4.w[n_ent - 1 - (i0 + t < n_ent ? i0 + t : n_ent - 1)];
+          sn[t] = ps.surv_n[(uint64_t)(v[t] >> 20) * ccap + j];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+          const uint32_t probe = v[t] >> 20, k = (v[t] >> 11) & 511u;
+          ch[t] = (sn[t] >> 31) ? ps.chunk[((uint64_t)probe * kPeChunks + k / kPeChunkEnts) * ccap + j] : 0u;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+          const uint32_t probe = v[t] >> 20, k = (v[t] >> 11) & 511u;
+          c[t] = (sn[t] >> 31) ? ps.pool[(uint64_t)ch[t] * kPeChunkEnts + k % kPeChunkEnts]
+                               : ps.inl[((uint64_t)probe * kPeMidRegion + k) * ccap + j];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+          if (i0 + t < n_ent) {
+            Candidate cd; cd.genome_pos = c[t].x; cd.strand = (v[t] >> 20) >= 3u ? '-' : '+'; cd.mismatch = v[t] & 0x7FFu;
+            out[i0 + t] = cd;
+          }
+        }
+      }
     }
   }
 }
