@@ -921,6 +921,10 @@ constexpr uint32_t kPushSmall = 12;
 // fetched for the entries that are left when the heap is emptied.  Twice the reads per wavefront for the same LDS
 // (30 at -k 50): the kernel is bound by instruction issue with a quarter of its lanes at work.
 static_assert(kPeChunks * kPeChunkEnts <= 512 && kPeMidRegion <= 512, "a survivor's number takes 9 bits");
+#ifndef WALT_PUSH_BIG_SLOTS
+#define WALT_PUSH_BIG_SLOTS 1536
+#endif
+constexpr uint32_t kPushBigSlots = WALT_PUSH_BIG_SLOTS;  // 4-byte heap slots per wavefront of the second launch
 struct Heap4 {
   uint32_t* w;
   struct Ref {
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ heap_n, uint32_t* __restrict__ fb_count,
                                                     uint32_t* __restrict__ fb_list, uint32_t first,
                                                     uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
-  __shared__ HeapEnt s_heap[kBlock / 64][kListHeapSlots];  // (second launch: 2 x kListHeapSlots 4-byte entries)
+  __shared__ HeapEnt s_heap[kBlock / 64][SMALL ? kListHeapSlots : kPushBigSlots / 2];  // (second launch: kPushBigSlots 4-byte entries)
   uint32_t count;
   if (SMALL) {
     count = *list_count;
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
   const uint32_t total_waves = gridDim.x * waves_per_block;
   const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
   const uint32_t cap = SMALL ? kPushSmall : top_k;
-  constexpr uint32_t kSlots = SMALL ? kListHeapSlots : 2 * kListHeapSlots;
+  constexpr uint32_t kSlots = SMALL ? kListHeapSlots : kPushBigSlots;
   const uint32_t rpw_max = kSlots / cap < 64 ? kSlots / cap : 64;  // top_k <= 300: at least 2
   uint32_t rpw = (count + total_waves - 1) / total_waves;
   rpw = rpw < 1 ? 1 : (rpw > rpw_max ? rpw_max : rpw);
