@@ -48,6 +48,17 @@ static void verify_region(const IndexView& iv, const StrandView& sv, const Looku
   }
 }
 
+template <int W>
+static long tail_mask_words_differ(uint32_t seed_i, uint32_t seed_len) {
+  if constexpr (W < 10) {
+    const uint32_t want = care_mask_word((uint32_t)W, seed_i, kKeyWeight + kKeyChars, seed_len);
+    const uint32_t got = tail_care_mask_word<W>(seed_i, tail_care_cut(seed_i, seed_len));
+    return (want != got ? 1 : 0) + tail_mask_words_differ<W + 1>(seed_i, seed_len);
+  } else {
+    return 0;
+  }
+}
+
 extern "C" {
 
 void* hh_index_new(uint32_t n_chrom, const uint32_t* chrom_len, int dir_bits) {
@@ -492,6 +503,48 @@ long hh_fence_check(uint32_t seed, uint32_t n_cases) {
       const bool f2 = u2 > a2;
       if (f1 != f2 || (f1 && (a1 != a2 || u1 != u2 - 1))) ++bad;
     }
+  }
+  return bad;
+}
+
+// core.h tail_care_mask_word / count_mismatch_tail (round 3: the seed's care characters >= 44 tested on the window the
+// mismatch count loads -- patterns 5 / 7 -- and on the dense records): the mask built without a table must be the
+// straightforward one (care_mask_word over [44, seed_len)) for every word, seed shift and seed length, and the tail
+// count on random windows must be the number of those characters that differ.  Returns the number of differences.
+long hh_tail_mask_check(uint32_t seed) {
+  long bad = 0;
+  for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i)
+    for (uint32_t seed_len = kKeyWeight + kKeyChars; seed_len <= kNumCare; ++seed_len) {
+      if (care_pos(seed_len - 1) + seed_i >= 160) continue;  // beyond the ten words the long-seed kernels hold
+      bad += tail_mask_words_differ<0>(seed_i, seed_len);
+    }
+  uint64_t x = 0x9E3779B97F4A7C15ull * (seed + 1);
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  constexpr int NW = 10;
+  for (int c = 0; c < 2000; ++c) {
+    uint32_t g2[NW + 4], rd[NW], mk[NW];
+    for (auto& v : g2) v = (uint32_t)rnd();
+    const uint32_t gpos = (uint32_t)(rnd() % 16), seed_i = (uint32_t)(rnd() % kPat);
+    const uint32_t seed_len = kKeyWeight + kKeyChars + (uint32_t)(rnd() % (kNumCare - kKeyWeight - kKeyChars + 1));
+    if (seed_len > kKeyWeight + kKeyChars && care_pos(seed_len - 1) + seed_i >= 16 * NW) continue;
+    for (int w = 0; w < NW; ++w) {  // the read: the window itself with a few characters changed
+      rd[w] = funnel_r(g2[w], g2[w + 1], 2 * gpos);
+      if (rnd() % 2) rd[w] ^= (uint32_t)(1 + rnd() % 3) << (2 * (rnd() % 16));
+      mk[w] = (uint32_t)rnd() & 0x55555555u;
+    }
+    uint32_t want_mm = 0, want_t = 0;
+    for (int w = 0; w < NW; ++w)
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t a = (rd[w] >> (2 * k)) & 3u, b = g2_code(g2, gpos + 16 * w + k);
+        if ((mk[w] >> (2 * k)) & 1u) want_mm += a != b;
+      }
+    for (uint32_t p = kKeyWeight + kKeyChars; p < seed_len; ++p) {
+      const uint32_t o = seed_i + care_pos(p);
+      want_t += ((rd[o >> 4] >> (2 * (o & 15))) & 3u) != g2_code(g2, gpos + o);
+    }
+    uint32_t got_t = 0;
+    const uint32_t got_mm = count_mismatch_tail<NW>(g2, gpos, rd, mk, seed_i, tail_care_cut(seed_i, seed_len), got_t);
+    if (got_mm != want_mm || got_t != want_t) ++bad;
   }
   return bad;
 }
