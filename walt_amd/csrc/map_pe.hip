@@ -1180,6 +1180,10 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
                                                             const uint32_t* __restrict__ heavy_count,
                                                             const uint32_t* __restrict__ heavy_list) {
   __shared__ uint32_t s_start[kLdsChroms + 1];
+  // per wavefront: the pair's two candidate lists with what every combination needs of a candidate -- position,
+  // mismatches | strand, chromosome, forward start -- worked out ONCE per candidate (the chromosome search per
+  // combination was 2 x 2,500 searches for a pair with two full lists of 50)
+  extern __shared__ uint4 s_cand[];  // [waves][2][top_k]
   const bool fits = iv.n_chrom <= kLdsChroms;
   if (fits)
     for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
@@ -1188,6 +1192,8 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t waves_per_block = blockDim.x >> 6;
   const uint32_t count = *heavy_count;
+  uint4* const ca = s_cand + (uint64_t)(threadIdx.x >> 6) * 2 * top_k;
+  uint4* const cb = ca + top_k;
   for (uint32_t h = blockIdx.x * waves_per_block + (threadIdx.x >> 6); h < count; h += gridDim.x * waves_per_block) {
     const uint32_t r = heavy_list[h];
     const Candidate* r1 = ranked1 + (uint64_t)r * top_k;
@@ -1195,6 +1201,17 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
     const uint32_t na = n1[r], nb = n2[r];
     const uint32_t len1 = (uint32_t)(off1[r + 1] - off1[r]), len2 = (uint32_t)(off2[r + 1] - off2[r]);
     const uint32_t total = na * nb;
+    __builtin_amdgcn_wave_barrier();  // (the previous pair's combinations have been read)
+    for (uint32_t t = lane; t < na + nb; t += 64) {
+      const bool first = t < na;
+      const Candidate c = first ? r1[t] : r2[t - na];
+      const uint32_t chr = chrom_id(starts, iv.n_chrom, c.genome_pos);
+      uint32_t sf, ef;
+      forward_pos(c.genome_pos, c.strand, chr, first ? len1 : len2, starts, sf, ef);
+      (first ? ca : cb)[first ? t : t - na] = make_uint4(c.genome_pos, c.mismatch | ((c.strand & 0xFFu) == '-' ? 0x80000000u : 0u), chr, sf);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     uint32_t min_mm = max_mm, best_times = 0;
     uint32_t best_hi = 0, best_lo = 0;  // best_pos = (pos1 << 32) + pos2
     int bi = -1, bj = -1;
@@ -1206,19 +1223,13 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
       if (c < total) {
         i = (int)(na - 1 - c / nb);
         j = (int)(nb - 1 - c % nb);
-        const Candidate A = r1[i], B = r2[j];
-        p1 = A.genome_pos; p2 = B.genome_pos;
-        if (A.strand != B.strand) {
-          mm = A.mismatch + B.mismatch;
-          if (mm <= min_mm) {
-            const uint32_t c1 = chrom_id(starts, iv.n_chrom, p1), c2 = chrom_id(starts, iv.n_chrom, p2);
-            if (c1 == c2) {
-              uint32_t s1, e1, s2, e2;
-              forward_pos(p1, A.strand, c1, len1, starts, s1, e1);
-              forward_pos(p2, B.strand, c2, len2, starts, s2, e2);
-              const int frag = A.strand == '+' ? (int)(e2 - s1) : (int)(e1 - s2);
-              ok = frag > 0 && frag <= frag_range;
-            }
+        const uint4 A = ca[i], B = cb[j];
+        p1 = A.x; p2 = B.x;
+        if ((A.y ^ B.y) >> 31) {  // opposite strands
+          mm = (A.y & 0x7FFFFFFFu) + (B.y & 0x7FFFFFFFu);
+          if (mm <= min_mm && A.z == B.z) {
+            const int frag = (A.y >> 31) ? (int)(A.w + len1 - B.w) : (int)(B.w + len2 - A.w);
+            ok = frag > 0 && frag <= frag_range;
           }
         }
       }
@@ -1546,7 +1557,8 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   hipLaunchKernelGGL(k_pe_merge, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, w.ranked[0], w.heap_n[0],
                      w.ranked[1], w.heap_n[1], d_off1, d_off2, n, top_k, frag_range, max_mm, d_out, heavy_count,
                      heavy_list);
-  hipLaunchKernelGGL(k_pe_merge_heavy, dim3(grid_for(n) < 2048u ? grid_for(n) : 2048u), dim3(kBlock), 0, stream,
+  hipLaunchKernelGGL(k_pe_merge_heavy, dim3(grid_for(n) < 2048u ? grid_for(n) : 2048u), dim3(kBlock),
+                     (size_t)(kBlock / 64) * 2 * top_k * sizeof(uint4), stream,
                      idx->view, w.ranked[0], w.heap_n[0], w.ranked[1], w.heap_n[1], d_off1, d_off2, top_k, frag_range,
                      max_mm, d_out, heavy_count, heavy_list);
   WALT_HIP(hipGetLastError());
