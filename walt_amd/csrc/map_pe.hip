@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
 // Pairs whose candidate lists span more than kLightCombos (i, j) combinations are
 // left to k_pe_merge_heavy: one such lane would otherwise hold its whole wave for
 // thousands of iterations (repeat families fill both lists to top_k).
-constexpr uint32_t kLightCombos = 64;
+constexpr uint32_t kLightCombos = 16;  // (64 until the heavy kernel worked the candidates out once per pair: 202 -> 199 ms)
 
 __global__ void k_pe_merge(IndexView iv, const Candidate* __restrict__ ranked1, const uint32_t* __restrict__ n1,
                            const Candidate* __restrict__ ranked2, const uint32_t* __restrict__ n2,
