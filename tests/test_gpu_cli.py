@@ -52,6 +52,29 @@ def test_cli_output_files_identical_to_reference(cli_index, scratch, case):
             assert False, "%s/%s differs" % (case, fn)
 
 
+@pytest.mark.parametrize("env", [{"WALT_AMD_SE_PIPE": "0"}, {"WALT_AMD_SE_PIPE": "0", "WALT_AMD_HEAVY_CHUNK": "64"},
+                                 {"WALT_AMD_HEAVY_CHUNK": "64"}, {"WALT_AMD_LIT_SIDE": "0"}])
+@pytest.mark.parametrize("case", ["se_sam_au", "se150_ag_sam_au_m10"])
+def test_cli_single_end_schedules_give_the_same_files(cli_index, scratch, case, env):
+    """The staged heavy pass has two schedules -- two halves of the heavy list on two streams, each with its own state
+    slot and the list cut evenly on the device (default, round 3), or one stream in chunks (WALT_AMD_SE_PIPE=0) -- and the
+    literal pass runs beside its end or after it (WALT_AMD_LIT_SIDE=0).  The switches are read once per process, so each
+    combination runs in a process of its own (the command line), with chunks of 64 reads so that several chunks, both
+    slots and the later chunks' wait for the literal snapshot are all exercised; the files must be the reference's."""
+    if case not in META["cases"]:
+        pytest.skip("no golden case " + case)
+    info = META["cases"][case]
+    wd = os.path.join(scratch, "cli_sched_%s_%s" % (case, "_".join(sorted(env)) + "".join(env.values())))
+    os.makedirs(wd, exist_ok=True)
+    out = os.path.join(wd, "out.sam" if "-sam" in info["args"] else "out.mr")
+    cmd = [WALT_BIN, "-i", cli_index, "-o", out] + list(info["args"]) + ["-r", os.path.join(refio.GOLDEN, info["kind"] + ".fastq")]
+    subprocess.run(cmd, check=True, cwd=wd, stderr=subprocess.DEVNULL, env=dict(os.environ, **env))
+    assert sorted(os.listdir(wd)) == sorted(info["files"])
+    for fn in info["files"]:
+        with open(os.path.join(wd, fn)) as f:
+            assert f.read() == refio.golden_file(case, fn), "%s/%s differs under %s" % (case, fn, env)
+
+
 @pytest.mark.parametrize("case", ["se_sam_au_N100", "se_ag_mr_au", "se_clip_mr_au_N100", "pe_sam_au_N250", "pe_mr_au", "pe150_sam_au_m10"])
 def test_cli_several_gpus_share_each_batch(cli_index, scratch, case):
     """-g 0,0: two index replicas (here on the one GPU of the box), every -N batch cut into two contiguous shares
