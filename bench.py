@@ -112,9 +112,18 @@ def parse_args(argv):
                     help="build the opt-in direct-mapped slot table (WALT_AMD_TABLE=1: +51.5 GB per strand at hg19 scale)")
     ap.add_argument("--seed-offset", type=int, default=0,
                     help="added to the rank in the read seeds (tests: rank r of an N-rank run == a 1-rank run at offset r)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="an option of the mapping library on every index the run opens (walt_index_set_option; A/B runs)")
     ap.add_argument("--pattern", type=int, choices=[3, 5, 7], default=3,
                     help="seed pattern (the reference's -D SEEDPATTERN3/5/7); 5 and 7 use libwalt_amd_sp5/_sp7.so")
     return ap.parse_args(argv)
+
+
+def apply_opts(idx, args):
+    """--opt NAME=VALUE: options of the mapping library (schedule only, never results), for A/B runs"""
+    for kv in args.opt:
+        name, _, value = kv.partition("=")
+        idx.set_option(name, int(value))
 
 
 def launch_ranks(args, argv):
@@ -153,7 +162,7 @@ def se_leg(cx, idx, d_bases, d_off, n, read_len, max_mm, b, ag, steps, warmup, t
 
     def step():
         idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, read_len, d_out.data_ptr(),
-                                d_stats.data_ptr(), d_ws.data_ptr(), stream=stream, ag_wildcard=ag,
+                                d_stats.data_ptr(), d_ws.data_ptr(), d_ws.numel(), stream=stream, ag_wildcard=ag,
                                 max_mismatches=max_mm, b=b)
 
     for _ in range(warmup):
@@ -179,8 +188,17 @@ def se_leg(cx, idx, d_bases, d_off, n, read_len, max_mm, b, ag, steps, warmup, t
     if n_def and cx.pattern == 3:
         off = 64 * 4 + 256 * 16 * 8
         deferred = (d_ws[off:off + 4 * n_def].view(torch.int32) & 0x0FFFFFFF).long()
+    # the staged heavy pass's control words (map_se.hip: 8 per (chunk, round), behind the dense 2-bit reads): per chunk
+    # and round [reads blocked -> next round, dense items, gather items, giants]
+    stride = (n + 63) // 64 * 64
+    h_off = (64 * 4 + 256 * 16 * 8 + 3 * stride * 4 + ((n * read_len) // 16 + 10) * 4 + 15) // 16 * 16
+    kpat = cx.pattern
+    hctl = d_ws[h_off:h_off + 4 * 64 * kpat].view(torch.int32).cpu().numpy().reshape(8, kpat, 8)
+    rounds = [[[int(hctl[c, r, 4]), int(hctl[c, r, 0]), int(hctl[c, r, 1]), int(hctl[c, r, 5])] for r in range(kpat)]
+              for c in range(8) if hctl[c].any()]
     return {"elapsed": elapsed, "pack_ms": pack_ms, "map_ms": map_ms, "d_out": d_out, "stats": st, "deferred": deferred,
-            "n_deferred": n_def, "n_heavy": n_heavy, "d_ws": d_ws, "detail_ms": np.median(np.array(detail), axis=0).tolist()}
+            "n_deferred": n_def, "n_heavy": n_heavy, "d_ws": d_ws, "detail_ms": np.median(np.array(detail), axis=0).tolist(),
+            "rounds": rounds}
 
 
 def se_sample(cx, leg, n, n_uniform, n_hard):
@@ -510,7 +528,7 @@ def calibration_leg(cx, local, cores, n=100_000, read_len=100, max_mm=6, b=5000)
         d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
         d_ws = torch.empty(walt_amd.lib().walt_se_workspace_bytes(n, read_len), dtype=torch.uint8, device=dev)
         idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, read_len, d_out.data_ptr(), d_stats.data_ptr(),
-                                d_ws.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, ag_wildcard=False,
+                                d_ws.data_ptr(), d_ws.numel(), stream=torch.cuda.current_stream().cuda_stream, ag_wildcard=False,
                                 max_mismatches=max_mm, b=b)
         torch.cuda.synchronize()
         gpu = d_out.cpu().numpy().view(walt_amd.best_match_dtype).reshape(-1)
@@ -592,12 +610,13 @@ def pe_leg(cx, idx, d1, d2, d_off, n, read_len, max_mm, b, top_k, frag_range, st
     torch.cuda.empty_cache()  # the read generator's cached blocks back to the device: the library sizes its passes by what is free
     d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
     d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
-    d_ws = torch.empty(walt_amd.lib().walt_pe_workspace_bytes(n, read_len, top_k), dtype=torch.uint8, device=dev)
+    # what the call uses best on this device now: the larger passes when it has the room (walt_pe_workspace_bytes_best)
+    d_ws = torch.empty(idx.pe_workspace_bytes(n, read_len, top_k), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         idx.map_pe_batch_device(d1.data_ptr(), d_off.data_ptr(), d2.data_ptr(), d_off.data_ptr(), n, read_len,
-                                d_out.data_ptr(), d_stats.data_ptr(), d_ws.data_ptr(), stream=stream,
+                                d_out.data_ptr(), d_stats.data_ptr(), d_ws.data_ptr(), d_ws.numel(), stream=stream,
                                 max_mismatches=max_mm, b=b, top_k=top_k, frag_range=frag_range)
 
     for _ in range(warmup):
@@ -845,6 +864,7 @@ def worker(args):
         t0 = time.perf_counter()
         idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local, strands=strands,
                                           dir_bits=args.dir_bits)
+        apply_opts(idx, args)
         t_index = time.perf_counter() - t0
         s0 = 2 if args.ag else 0
         log("index: %d + %d entries, dir_bits %d, %.1f GB in HBM, outliers %d/%d, bad buckets %d/%d (%.1f s)" % (
@@ -883,6 +903,7 @@ def worker(args):
                         "(must be 0)" % (buf[14], buf[15]))
         log("heavy pass: %d reads, literal pass: %d reads; kernel ms/step: pack %.2f map %.2f (median)" % (
             leg["n_heavy"], leg["n_deferred"], float(np.median(leg["pack_ms"])), float(np.median(leg["map_ms"]))))
+        log("staged rounds per chunk [blocked -> next round, dense items, gather items, giants]: %s" % leg["rounds"])
         log("device counters per step: probes %.2f, candidates %.2f per read, %d wave-cooperative regions" % (
             leg["stats"][1] / n, leg["stats"][2] / n, leg["stats"][3]))
         if rank == 0:
@@ -1007,6 +1028,7 @@ def worker(args):
         t0 = time.perf_counter()
         idx = walt_amd.Index.build_device(genome_ascii.data_ptr(), lens, names, device=local,
                                           strands=walt_amd.STRANDS_ALL, dir_bits=args.dir_bits)
+        apply_opts(idx, args)
         t_index4 = time.perf_counter() - t0
         log("index (4 strands): %.1f GB in HBM, dir_bits %d (%.1f s)" % (idx.device_bytes / 1e9, idx.dir_bits, t_index4))
         jobs = []

@@ -158,18 +158,24 @@ int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offset
 /* Device-resident form (pointers are HBM addresses on idx's device; stream is a
  * hipStream_t or NULL).  Asynchronous: returns after enqueueing; d_stats
  * (walt_batch_stats, device memory) is accumulated into, not cleared.
- * d_workspace must hold walt_se_workspace_bytes(n, max_read_len) bytes. */
+ * d_workspace must hold walt_se_workspace_bytes(n, max_read_len) bytes; the call is told how many it holds
+ * (workspace_bytes) and refuses a smaller one with WALT_EINVAL instead of writing beyond it.  No option of the
+ * index (walt_index_set_option) makes a call need more than that.
+ * One single-end call at a time per index (its side streams and events belong to the index): a second call that
+ * arrives while one is being enqueued is refused with WALT_EINVAL; different indexes are independent. */
 size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len);
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
                              uint32_t max_read_len, int ag_wildcard, uint32_t max_mismatches,
-                             uint32_t b, void* d_out, void* d_stats, void* d_workspace, void* stream);
+                             uint32_t b, void* d_out, void* d_stats, void* d_workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* The device-resident calls are asynchronous, so invalid input cannot come back as their status.
  * walt_batch_check waits for `stream` and reports what the last call on `d_workspace` found:
  * WALT_EBASE (a read holds a non-ACGT base: the reference's getBits exits, util.hpp:117-119; its
  * record is left as initialised), WALT_EINVAL (a read longer than max_read_len, or a batch of more than
  * n x max_read_len bases -- the workspace is sized by that product: such reads are refused in the kernels, never
- * converted or read beyond the workspace, their records left as initialised), else WALT_OK.
+ * converted or read beyond the workspace, their records left as initialised), WALT_EHIP (internal: a work-item
+ * queue overflowed -- never with a workspace of the promised size), else WALT_OK.
  * The host-buffer calls do this themselves. */
 int walt_batch_check(const void* d_workspace, void* stream);
 
@@ -186,13 +192,43 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
                       walt_candidate* ranked2, uint32_t* ranked_n2, walt_batch_stats* stats /*[2]*/);
 
 /* One paired-end call at a time per walt_index: the call's internal streams and events (mate 2 runs beside mate 1,
- * passes alternate between two pipeline slots) belong to the index.  Different indexes (devices) are independent. */
+ * passes alternate between two pipeline slots) belong to the index.  Different indexes (devices) are independent.
+ * Workspace: walt_pe_workspace_bytes is the LEAST a call needs (8 M-pair passes, staged lists in four rounds);
+ * walt_pe_workspace_bytes_best is what it uses best on idx's device as it stands now -- 10 M-pair passes in one round
+ * when the device has that much free memory -- and never less than the former.  The call takes the geometry the
+ * workspace it is given has room for (workspace_bytes), so sizing and mapping cannot disagree, and nothing about the
+ * choice is kept in the process: two indexes on two devices decide independently. */
 size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k);
+size_t walt_pe_workspace_bytes_best(walt_index* idx, uint32_t n, uint32_t max_read_len, uint32_t top_k);
 int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* d_offsets1,
                              const void* d_bases2, const void* d_offsets2, uint32_t n,
                              uint32_t max_read_len, uint32_t max_mismatches, uint32_t b,
                              uint32_t top_k, int frag_range, void* d_out, void* d_stats /*[2]*/,
-                             void* d_workspace, void* stream);
+                             void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- options ---------------------------------------------------------------------------------
+ * Tuning values and test hooks of the mapping calls, per index.  The mapping calls read NO environment
+ * variable: an index maps the same way whatever the process environment holds (the library's only
+ * environment inputs are read once, when an index is opened or built: WALT_AMD_WIN / _WIN_GB /
+ * _WIN_RESERVE_GB (dense candidate windows: on/off, memory cap, memory left free), WALT_AMD_FENCE,
+ * WALT_AMD_TABLE, WALT_AMD_VERBOSE; and WALT_AMD_RCCL, the library walt_comm_* binds).  Every option
+ * changes the schedule of a call, never its results.  Names (value 0 / 1 unless said otherwise):
+ *   se_pipe        1  staged heavy pass in two halves on two streams
+ *   se_heavy_chunk 0  reads per chunk of the heavy list (0: default; a test hook for several chunks on a small batch)
+ *   se_lit_side    1  literal pass on a side stream beside the end of the heavy pass
+ *   se_defer_min  -1  long seeds: key-equal ranges of more slots than this go to the verifier unnarrowed (-1: default 4, 0: never)
+ *   se_stage_occ   0  wavefronts per SIMD the stage kernel is built for (0: default, 3)
+ *   se_carry       1  pass 1 hands its state to the staged rounds (0: they start over at seed 0)
+ *   se_heavy_mono  0  the one-kernel heavy pass instead of the staged rounds
+ *   grid           0  blocks of the persistent kernels (0: 8 per compute unit)
+ *   pe_mode        0  0: staged path, 1: list kernels only
+ *   pe_chunk       0  pairs per pass (0: default)          pe_rounds    0  rounds of a staged list (0: default, 1, 2, 4)
+ *   pe_stage_cap   0  staged reads per round (0: default)  pe_small_heaps 0  force the 8-slot heaps of long literal lists
+ *   pe_serial      0  mates and passes on one stream (profiling)
+ *   pe_defer_min  -1  as se_defer_min                      pe_roomy    -1  -1: by the workspace's size, 0 / 1: forced
+ * Set between calls, not during one.  WALT_EINVAL for an unknown name. */
+int walt_index_set_option(walt_index* idx, const char* name, long long value);
+int walt_index_get_option(const walt_index* idx, const char* name, long long* value);
 
 /* ---- makedb-compatible index builders (reference.cpp:79-322,
  *      makedb.cpp:46-159) ---------------------------------------------------- */
@@ -271,8 +307,9 @@ int walt_profile_last(walt_index* idx, float* pack_ms, float* map_ms);
 /* The last single-end call's mapping time by kernel group, from events between the groups: out4 = milliseconds of
  * {pass 1, heavy stages, region verifier, literal pass incl. its sort}. */
 int walt_profile_detail(walt_index* idx, float* out4);
-/* Diagnostic (environment WALT_AMD_STAMPS=1): in-kernel s_memtime sums per phase of
- * the single-end mapping kernel, cycles summed over waves; reading clears them. */
+/* Diagnostic BUILD only (make -C walt_amd/csrc diag: libwalt_amd_diag.so, environment WALT_AMD_STAMPS=1):
+ * in-kernel s_memtime sums per phase of the single-end mapping kernel, cycles summed over waves; reading
+ * clears them.  The product library returns WALT_EINVAL. */
 int walt_profile_stamps(unsigned long long* out16);
 
 #ifdef __cplusplus

@@ -44,3 +44,28 @@ def g1_index_path(scratch):
 def g1_db(g1_index_path):
     import refio
     return refio.DbIndex(g1_index_path)
+
+
+@pytest.fixture
+def index_options():
+    """index_options(idx, name=value, ...): sets options of a (shared) index for this test and puts the old values back
+    afterwards (walt_index_set_option: tuning values and test hooks; they change a call's schedule, never its results)."""
+    undo = []
+
+    def setter(idx, **kv):
+        for name, value in kv.items():
+            undo.append((idx, name, idx.get_option(name)))
+            idx.set_option(name, value)
+
+    yield setter
+    for idx, name, old in reversed(undo):
+        idx.set_option(name, old)
+
+
+@pytest.fixture(scope="module")
+def wa_diag():
+    """walt_amd with its diagnostic library loaded as well (walt_amd.diag_lib(): libwalt_amd_diag.so)."""
+    import walt_amd
+    assert walt_amd.device_count() >= 1, "no HIP device: the walt_amd hot path has no CPU fallback"
+    walt_amd.diag_lib()
+    return walt_amd

@@ -52,15 +52,16 @@ def test_cli_output_files_identical_to_reference(cli_index, scratch, case):
             assert False, "%s/%s differs" % (case, fn)
 
 
-@pytest.mark.parametrize("env", [{"WALT_AMD_SE_PIPE": "0"}, {"WALT_AMD_SE_PIPE": "0", "WALT_AMD_HEAVY_CHUNK": "64"},
-                                 {"WALT_AMD_HEAVY_CHUNK": "64"}, {"WALT_AMD_LIT_SIDE": "0"}])
+@pytest.mark.parametrize("env", [{"se_pipe": "0"}, {"se_pipe": "0", "se_heavy_chunk": "64"},
+                                 {"se_heavy_chunk": "64"}, {"se_lit_side": "0"}, {"se_carry": "0", "se_heavy_chunk": "64"}])
 @pytest.mark.parametrize("case", ["se_sam_au", "se150_ag_sam_au_m10"])
 def test_cli_single_end_schedules_give_the_same_files(cli_index, scratch, case, env):
     """The staged heavy pass has two schedules -- two halves of the heavy list on two streams, each with its own state
-    slot and the list cut evenly on the device (default, round 3), or one stream in chunks (WALT_AMD_SE_PIPE=0) -- and the
-    literal pass runs beside its end or after it (WALT_AMD_LIT_SIDE=0).  The switches are read once per process, so each
-    combination runs in a process of its own (the command line), with chunks of 64 reads so that several chunks, both
-    slots and the later chunks' wait for the literal snapshot are all exercised; the files must be the reference's."""
+    slot and the list cut evenly on the device (default), or one stream in chunks (option se_pipe = 0) -- the literal
+    pass runs beside its end or after it (se_lit_side = 0), and the staged rounds go on from pass 1's state or start over
+    (se_carry = 0).  Each combination through the command line (-X name=value), with chunks of 64 reads so that several
+    chunks, both slots and the later chunks' wait for the literal snapshot are all exercised; the files must be the
+    reference's."""
     if case not in META["cases"]:
         pytest.skip("no golden case " + case)
     info = META["cases"][case]
@@ -68,7 +69,9 @@ def test_cli_single_end_schedules_give_the_same_files(cli_index, scratch, case, 
     os.makedirs(wd, exist_ok=True)
     out = os.path.join(wd, "out.sam" if "-sam" in info["args"] else "out.mr")
     cmd = [WALT_BIN, "-i", cli_index, "-o", out] + list(info["args"]) + ["-r", os.path.join(refio.GOLDEN, info["kind"] + ".fastq")]
-    subprocess.run(cmd, check=True, cwd=wd, stderr=subprocess.DEVNULL, env=dict(os.environ, **env))
+    for k, v in sorted(env.items()):
+        cmd += ["-X", "%s=%s" % (k, v)]
+    subprocess.run(cmd, check=True, cwd=wd, stderr=subprocess.DEVNULL)
     assert sorted(os.listdir(wd)) == sorted(info["files"])
     for fn in info["files"]:
         with open(os.path.join(wd, fn)) as f:

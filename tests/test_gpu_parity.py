@@ -74,11 +74,10 @@ def test_gpu_se_records_equal_oracle_exact_times(wa, g1_db, g1_dev):
                 assert int(stats["candidates"]) >= 0
 
 
-@pytest.mark.parametrize("pe_chunk", [None, "333"])
-def test_gpu_pe_ranked_lists_and_pairs_equal_oracle(wa, g1_db, g1_dev, pe_chunk, monkeypatch):
+@pytest.mark.parametrize("pe_chunk", [0, 333])
+def test_gpu_pe_ranked_lists_and_pairs_equal_oracle(wa, g1_db, g1_dev, pe_chunk, index_options):
     """pe_chunk forces the batch through several workspace passes (two-stream fork/join per pass)."""
-    if pe_chunk:
-        monkeypatch.setenv("WALT_AMD_PE_CHUNK", pe_chunk)
+    index_options(g1_dev[-1], pe_chunk=pe_chunk)
     _, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 10 ** 7))
     _, s2, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_2.fastq"), 10 ** 7))
     b1, o1 = wa.pack_reads(s1)
@@ -194,8 +193,13 @@ def test_gpu_device_pointer_api_with_torch(wa, g1_db, g1_dev):
     d_stats = torch.zeros(4, dtype=torch.int64, device=dev)
     d_ws = torch.empty(wa.lib().walt_se_workspace_bytes(n, max_len), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    # a workspace smaller than the call needs is refused, not overrun
+    with pytest.raises(wa.WaltError) as ei:
+        idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, max_len, d_out.data_ptr(), d_stats.data_ptr(),
+                                d_ws.data_ptr(), d_ws.numel() - 1, stream=stream)
+    assert ei.value.code == wa.WALT_EINVAL
     idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, max_len, d_out.data_ptr(), d_stats.data_ptr(),
-                            d_ws.data_ptr(), stream=stream)
+                            d_ws.data_ptr(), d_ws.numel(), stream=stream)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy().view(wa.best_match_dtype)
     want, work = refio.oracle_se(g1_db, seqs)
@@ -207,18 +211,18 @@ def test_gpu_device_pointer_api_with_torch(wa, g1_db, g1_dev):
     bad[offsets[5] + 3] = ord("N")
     d_bad = torch.from_numpy(bad).to(dev)
     idx.map_se_batch_device(d_bad.data_ptr(), d_off.data_ptr(), n, max_len, d_out.data_ptr(), d_stats.data_ptr(),
-                            d_ws.data_ptr(), stream=stream)
+                            d_ws.data_ptr(), d_ws.numel(), stream=stream)
     with pytest.raises(wa.WaltError) as ei:
         idx.check_batch(d_ws.data_ptr(), stream)
     assert ei.value.code == wa.WALT_EBASE
 
 
-def test_gpu_pe_device_api_pipelined_passes(wa, g1_db, g1_dev, monkeypatch):
+def test_gpu_pe_device_api_pipelined_passes(wa, g1_db, g1_dev, index_options):
     """Device-resident paired-end call forced through many passes: they alternate between the two pipeline
     slots (own workspace and streams) and must give the oracle's pair records."""
     import torch
-    monkeypatch.setenv("WALT_AMD_PE_CHUNK", "257")
     idx = g1_dev[-1]
+    index_options(idx, pe_chunk=257)
     _, s1, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_1.fastq"), 10 ** 7))
     _, s2, _ = next(refio.load_fastq_batches(os.path.join(refio.GOLDEN, "pe_2.fastq"), 10 ** 7))
     b1, o1 = wa.pack_reads(s1)
@@ -233,11 +237,17 @@ def test_gpu_pe_device_api_pipelined_passes(wa, g1_db, g1_dev, monkeypatch):
         want, _, _ = refio.oracle_pe(g1_db, s1, s2, max_mm=m, b=5000, top_k=k, frag_range=1000)
         d_out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
         d_stats = torch.zeros(8, dtype=torch.int64, device=dev)
-        d_ws = torch.empty(wa.lib().walt_pe_workspace_bytes(n, max_len, k), dtype=torch.uint8, device=dev)
+        d_ws = torch.empty(idx.pe_workspace_bytes(n, max_len, k), dtype=torch.uint8, device=dev)
+        assert d_ws.numel() >= wa.lib().walt_pe_workspace_bytes(n, max_len, k) or idx.get_option("pe_chunk")
         stream = torch.cuda.current_stream().cuda_stream
+        with pytest.raises(wa.WaltError) as ei:  # a workspace smaller than the call needs is refused, not overrun
+            idx.map_pe_batch_device(d1.data_ptr(), do1.data_ptr(), d2.data_ptr(), do2.data_ptr(), n, max_len,
+                                    d_out.data_ptr(), d_stats.data_ptr(), d_ws.data_ptr(), 4096, stream=stream,
+                                    max_mismatches=m, top_k=k)
+        assert ei.value.code == wa.WALT_EINVAL
         for _ in range(2):  # twice: slot state (events, streams) is reused across calls
             idx.map_pe_batch_device(d1.data_ptr(), do1.data_ptr(), d2.data_ptr(), do2.data_ptr(), n, max_len,
-                                    d_out.data_ptr(), d_stats.data_ptr(), d_ws.data_ptr(), stream=stream,
+                                    d_out.data_ptr(), d_stats.data_ptr(), d_ws.data_ptr(), d_ws.numel(), stream=stream,
                                     max_mismatches=m, top_k=k)
             idx.check_batch(d_ws.data_ptr(), stream)
             got = d_out.cpu().numpy().view(wa.pair_result_dtype)
@@ -355,12 +365,14 @@ def test_gpu_slot_table(wa, g1_db, scratch, monkeypatch):
         idx.close()
 
 
-def test_gpu_filter_covers_every_dangerous_probe(wa, scratch, monkeypatch):
-    """In-kernel self-check (WALT_AMD_STAMPS=1 WALT_AMD_ABLATE=8): for every probe pass 1 issues, the exact test
+def test_gpu_filter_covers_every_dangerous_probe(wa_diag, scratch, monkeypatch):
+    """In-kernel self-check of the DIAGNOSTIC build (libwalt_amd_diag.so: WALT_AMD_STAMPS=1 WALT_AMD_ABLATE=8 -- the
+    product library reads neither): for every probe pass 1 issues, the exact test
     (core.h probe_is_dangerous) is evaluated beside the prefilter/Bloom decision; a probe that is dangerous but
     not flagged would silently take the key search.  Genomes with hundreds of chromosome ends; the count of
     such probes must be zero while thousands of probes are checked."""
     import ctypes
+    wa = wa_diag
     monkeypatch.setenv("WALT_AMD_STAMPS", "1")
     monkeypatch.setenv("WALT_AMD_ABLATE", "8")
     checked = 0
@@ -368,12 +380,12 @@ def test_gpu_filter_covers_every_dangerous_probe(wa, scratch, monkeypatch):
         seqs, db = make_random_case(seed, n_chrom, scratch)
         rng = random.Random(seed)
         reads = [r for r in sample_reads(rng, seqs, 4000, "CT") if len(r) <= 112]  # the 7-word pass-1 instance
-        idx = wa.Index.from_host(db.lengths, db.genome, db.counter, db.index, chrom_names=db.names, device=0)
+        idx = wa.Index.from_host(db.lengths, db.genome, db.counter, db.index, chrom_names=db.names, device=0, diag=True)
         want, _ = refio.oracle_se(db, reads)
         got, _ = idx.map_se_batch(*wa.pack_reads(reads))
         assert_best_equal(got, want, "self-check run")  # results stay valid in this mode
         buf = (ctypes.c_ulonglong * 16)()
-        assert wa.lib().walt_profile_stamps(buf) == 0
+        assert wa.diag_lib().walt_profile_stamps(buf) == 0
         assert buf[15] == 0, "%d dangerous probes were not flagged by the filter" % buf[15]
         checked += buf[14]
         idx.close()
@@ -387,7 +399,6 @@ def test_gpu_pe_small_heaps_with_overflow_list(wa, scratch, monkeypatch):
     that most reads are deferred to the literal list (chromosome ends everywhere) AND collect dozens of
     candidates (every read occurs in many chromosomes): the overflow path carries most of the load.  Pair
     records and ranked lists must equal the oracle's."""
-    monkeypatch.setenv("WALT_AMD_SMALL_HEAPS", "1")
     rng = random.Random(4242)
     unit = "".join(rng.choice("ACGT") for _ in range(600))
     seqs = []
@@ -419,6 +430,8 @@ def test_gpu_pe_small_heaps_with_overflow_list(wa, scratch, monkeypatch):
         s1.append(frag[:L])
         s2.append(refio.revcomp(frag)[:L])
     idx = wa.Index.open(path, device=0)
+    idx.set_option("pe_small_heaps", 1)
+    idx.set_option("pe_mode", 1)  # the list kernels (the staged path maps long literal lists itself)
     deferred_any = False
     for k in (50, 5, 300):
         res, stats, ranked = idx.map_pe_batch(*wa.pack_reads(s1), *wa.pack_reads(s2), top_k=k, want_ranked=True)

@@ -136,14 +136,14 @@ def test_gpu_staged_paths_and_their_fallbacks_vs_oracle(wa, repeat_case, mode, m
                  and the fallback are all exercised on a batch of a few thousand reads.
     Same records as the oracle in every mode."""
     seqs, db = repeat_case
-    if mode == "mono_list":
-        monkeypatch.setenv("WALT_AMD_HEAVY", "mono")
-        monkeypatch.setenv("WALT_AMD_PE", "list")
-    else:
-        monkeypatch.setenv("WALT_AMD_HEAVY_CHUNK", "320")
-        monkeypatch.setenv("WALT_AMD_PE_STAGE_CAP", "128")
-        monkeypatch.setenv("WALT_AMD_PE_ROUNDS", "4")  # (a small index leaves the device roomy: one round would be the default)
     idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_bits=-1)
+    if mode == "mono_list":
+        idx.set_option("se_heavy_mono", 1)
+        idx.set_option("pe_mode", 1)
+    else:
+        idx.set_option("se_heavy_chunk", 320)
+        idx.set_option("pe_stage_cap", 128)
+        idx.set_option("pe_rounds", 4)  # (a small index leaves the device roomy: one round would be the default)
     rng = random.Random(11)
     for conv, lens, m, b in (("CT", [100], 6, 5000), ("GA", [150], 10, 300), ("CT", [60, 100, 128, 150, 200], 6, 5000)):
         reads = _reads(rng, seqs, 2500, conv, lens)
@@ -203,7 +203,7 @@ def test_gpu_device_api_refuses_reads_beyond_max_read_len(wa, g1_index_path, g1_
         d_ws = torch.full((ws_bytes + guard,), 0xA5, dtype=torch.uint8, device=dev)  # guard bytes behind the workspace
         stream = torch.cuda.current_stream().cuda_stream
         idx.map_se_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n, n_claim_len, d_out.data_ptr(), d_stats.data_ptr(),
-                                d_ws.data_ptr(), stream=stream)
+                                d_ws.data_ptr(), ws_bytes, stream=stream)
         torch.cuda.synchronize()
         assert bool((d_ws[ws_bytes:] == 0xA5).all()), "the call wrote behind its workspace"
         return d_out.cpu().numpy().view(wa.best_match_dtype), d_ws, stream

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of single-end kernel variants on one GPU box: each variant is one bench.py run (own genome + index build) with
-# its environment; the JSON lines land in gpurun_out/ab_<tag>/<name>.json, stderr beside them.
+# its options; the JSON lines land in gpurun_out/ab_<tag>/<name>.json, stderr beside them.
 #   bash tools/ab_se.sh <tag> "<name>|<env assignments>|<extra bench args>" ...
 set -u
 TAG=$1; shift
@@ -11,7 +11,7 @@ mkdir -p $OUT
 for SPEC in "$@"; do
   NAME=${SPEC%%|*}; REST=${SPEC#*|}; ENVS=${REST%%|*}; ARGS=${REST#*|}
   echo "== $NAME: env [$ENVS] args [$ARGS]"
-  ( export $ENVS; timeout -k 10 900 python3 bench.py $ARGS > $OUT/$NAME.json 2> $OUT/$NAME.log ) || { echo "$NAME failed"; tail -n 5 $OUT/$NAME.log; exit 1; }
+  ( [ -n "$ENVS" ] && export $ENVS; timeout -k 10 900 python3 bench.py $ARGS > $OUT/$NAME.json 2> $OUT/$NAME.log ) || { echo "$NAME failed"; tail -n 5 $OUT/$NAME.log; exit 1; }
   python3 - "$OUT/$NAME.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -116,12 +116,21 @@ def _preload_hip_runtime():
         ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
 
 
+def diag_lib():
+    """libwalt_amd_diag.so (make -C walt_amd/csrc diag): the pattern-3 library with the in-kernel phase stamps and
+    the WALT_AMD_ABLATE / WALT_AMD_STAMPS / WALT_AMD_SYNC_DEBUG switches, which the product library does not have."""
+    return lib("diag")
+
+
 def lib(pattern=None):
     """Load libwalt_amd.so / its _sp5 / _sp7 variant (fails loudly when it has not been built)."""
     pattern = PATTERN if pattern is None else pattern
     if pattern in _libs:
         return _libs[pattern]
-    path = lib_path(pattern)
+    diag = pattern == "diag"
+    path = os.path.join(_HERE, "lib", "libwalt_amd_diag.so") if diag else lib_path(pattern)
+    if diag:
+        pattern = 3
     if not os.path.exists(path):
         raise ImportError(
             "walt_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -163,12 +172,16 @@ def lib(pattern=None):
     L.walt_map_se_batch.argtypes = [vp, vp, vp, u32, ci, u32, u32, vp, vp]
     L.walt_se_workspace_bytes.argtypes = [u32, u32]
     L.walt_se_workspace_bytes.restype = c.c_size_t
-    L.walt_map_se_batch_device.argtypes = [vp, vp, vp, u32, u32, ci, u32, u32, vp, vp, vp, vp]
+    L.walt_map_se_batch_device.argtypes = [vp, vp, vp, u32, u32, ci, u32, u32, vp, vp, vp, c.c_size_t, vp]
     L.walt_batch_check.argtypes = [vp, vp]
     L.walt_map_pe_batch.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, ci, vp, vp, vp, vp, vp, vp]
     L.walt_pe_workspace_bytes.argtypes = [u32, u32, u32]
     L.walt_pe_workspace_bytes.restype = c.c_size_t
-    L.walt_map_pe_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, ci, vp, vp, vp, vp]
+    L.walt_pe_workspace_bytes_best.argtypes = [vp, u32, u32, u32]
+    L.walt_pe_workspace_bytes_best.restype = c.c_size_t
+    L.walt_map_pe_batch_device.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, u32, u32, ci, vp, vp, vp, c.c_size_t, vp]
+    L.walt_index_set_option.argtypes = [vp, c.c_char_p, c.c_longlong]
+    L.walt_index_get_option.argtypes = [vp, c.c_char_p, c.POINTER(c.c_longlong)]
     L.walt_makedb.argtypes = [c.c_char_p, c.c_char_p, ci]
     L.walt_index_build_device.argtypes = [vp, u32, vp, vp, ci, c.c_uint, ci, c.POINTER(vp)]
     L.walt_index_size.argtypes = [vp, ci]
@@ -186,7 +199,7 @@ def lib(pattern=None):
     L.walt_comm_world.argtypes = [vp]
     L.walt_comm_close.argtypes = [vp]
     L.walt_comm_close.restype = None
-    _libs[pattern] = L
+    _libs["diag" if diag else pattern] = L
     return L
 
 
@@ -283,8 +296,9 @@ class Index:
         return cls(h, lib())
 
     @classmethod
-    def from_host(cls, chrom_len, genome, counter, index, chrom_names=None, device=0, dir_bits=-1):
-        """genome/counter/index: 4-lists (CT00, CT01, GA10, GA11) of numpy arrays or None."""
+    def from_host(cls, chrom_len, genome, counter, index, chrom_names=None, device=0, dir_bits=-1, diag=False):
+        """genome/counter/index: 4-lists (CT00, CT01, GA10, GA11) of numpy arrays or None.
+        diag: through the diagnostic build of the library (diag_lib)."""
         n = len(chrom_len)
         cl = np.ascontiguousarray(chrom_len, dtype=np.uint32)
         names = None
@@ -306,11 +320,13 @@ class Index:
             keep += [ga, ca, ia]
             g[s], cn[s], ix[s], sz[s] = ga.ctypes.data, ca.ctypes.data, ia.ctypes.data, ia.size
         h = ctypes.c_void_p()
-        _check(lib().walt_index_from_host(n, cl.ctypes.data, names, ctypes.cast(g, ctypes.c_void_p),
-                                          ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(ix, ctypes.c_void_p),
-                                          ctypes.cast(sz, ctypes.c_void_p), int(device), int(dir_bits),
-                                          ctypes.byref(h)))
-        return cls(h, lib())
+        L = diag_lib() if diag else lib()
+        rc = L.walt_index_from_host(n, cl.ctypes.data, names, ctypes.cast(g, ctypes.c_void_p),
+                                    ctypes.cast(cn, ctypes.c_void_p), ctypes.cast(ix, ctypes.c_void_p),
+                                    ctypes.cast(sz, ctypes.c_void_p), int(device), int(dir_bits), ctypes.byref(h))
+        if rc != WALT_OK:
+            raise WaltError(rc, L.walt_last_error().decode("utf-8", "replace"))
+        return cls(h, L)
 
     @classmethod
     def build_device(cls, d_genome_ascii, chrom_len, chrom_names=None, device=0, strands=STRANDS_ALL,
@@ -418,12 +434,26 @@ class Index:
                                        int(max_mismatches), int(b), _ptr(out), _ptr(stats)))
         return out, stats[0]
 
-    def map_se_batch_device(self, d_bases, d_offsets, n, max_read_len, d_out, d_stats, d_workspace, stream=0,
-                            ag_wildcard=False, max_mismatches=6, b=5000):
-        """Device-pointer form (ints are HBM addresses, stream a hipStream_t value)."""
+    def map_se_batch_device(self, d_bases, d_offsets, n, max_read_len, d_out, d_stats, d_workspace, workspace_bytes,
+                            stream=0, ag_wildcard=False, max_mismatches=6, b=5000):
+        """Device-pointer form (ints are HBM addresses, stream a hipStream_t value); workspace_bytes = what
+        d_workspace holds (at least se_workspace_bytes(n, max_read_len))."""
         self._ck(self._L.walt_map_se_batch_device(self._h, d_bases, d_offsets, int(n), int(max_read_len),
                                               int(bool(ag_wildcard)), int(max_mismatches), int(b), d_out, d_stats,
-                                              d_workspace, stream))
+                                              d_workspace, int(workspace_bytes), stream))
+
+    # -- options: tuning values and test hooks (include/walt_amd.h; the library reads no environment on the mapping path)
+    def set_option(self, name, value):
+        self._ck(self._L.walt_index_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_longlong(0)
+        self._ck(self._L.walt_index_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def pe_workspace_bytes(self, n, max_read_len, top_k):
+        """What a paired-end call uses best on this index's device now (never less than the module-level minimum)."""
+        return self._L.walt_pe_workspace_bytes_best(self._h, int(n), int(max_read_len), int(top_k))
 
     @staticmethod
     def check_batch(d_workspace, stream=0):
@@ -431,10 +461,10 @@ class Index:
         _check(lib().walt_batch_check(d_workspace, stream))
 
     def map_pe_batch_device(self, d_bases1, d_offsets1, d_bases2, d_offsets2, n, max_read_len, d_out, d_stats,
-                            d_workspace, stream=0, max_mismatches=6, b=5000, top_k=50, frag_range=1000):
+                            d_workspace, workspace_bytes, stream=0, max_mismatches=6, b=5000, top_k=50, frag_range=1000):
         self._ck(self._L.walt_map_pe_batch_device(self._h, d_bases1, d_offsets1, d_bases2, d_offsets2, int(n),
                                               int(max_read_len), int(max_mismatches), int(b), int(top_k),
-                                              int(frag_range), d_out, d_stats, d_workspace, stream))
+                                              int(frag_range), d_out, d_stats, d_workspace, int(workspace_bytes), stream))
 
     # -- paired-end -----------------------------------------------------------
     def map_pe_batch(self, bases1, offsets1, bases2, offsets2, max_mismatches=6, b=5000, top_k=50,

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,8 +20,34 @@
       return walt::fail(WALT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
   } while (0)
 
+// Tuning values and test hooks of the mapping calls (walt_index_set_option; names in options.h).  The mapping calls
+// read NO environment variable: an index maps the same way whatever the process environment holds.  None of these
+// values can make a call need MORE workspace than walt_se_workspace_bytes / walt_pe_workspace_bytes promise.
+struct walt_options {
+  // single-end
+  int se_pipe = 1;            // the staged heavy pass in two halves on two streams
+  long long se_heavy_chunk = 0;  // reads per chunk of the heavy list (0: the default; test hook: several chunks on a small batch)
+  int se_lit_side = 1;        // the literal pass on a side stream beside the end of the heavy pass
+  long long se_defer_min = -1;   // long seeds: key-equal ranges of more slots go to the verifier (-1: default, 0: never)
+  int se_stage_occ = 0;       // wavefronts per SIMD the stage kernel is built for (0: default)
+  int se_carry = 1;           // pass 1 hands its state to the staged rounds (0: they start over at seed 0)
+  int se_heavy_mono = 0;      // the one-kernel heavy pass instead of the staged rounds (comparison)
+  long long grid = 0;         // blocks of the persistent mapping kernels (0: 8 per compute unit)
+  // paired-end
+  int pe_mode = 0;            // 0: staged path, 1: list kernels only
+  long long pe_chunk = 0;     // pairs per pass (0: default; test hook)
+  long long pe_rounds = 0;    // rounds a staged list is taken in (0: default)
+  long long pe_stage_cap = 0; // reads of a staged round (0: default; test hook)
+  int pe_small_heaps = 0;     // force the 8-slot heaps + overflow list of long literal lists
+  int pe_serial = 0;          // mates and pipeline slots one after the other (profiling)
+  long long pe_defer_min = -1;
+  int pe_roomy = -1;          // -1: decided once per index from the device's free memory
+};
+
 struct walt_index {
   int device = 0;
+  int n_cu = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  walt_options opt;
   walt::IndexHead head;
   std::vector<uint32_t> start_index;  // n_chrom + 1
   walt::IndexView view;               // device pointers
@@ -47,6 +74,7 @@ struct walt_index {
   int n_detail = 0;
   // single-end (created on first use): the side stream the literal pass runs on beside the last verifier launch and
   // the final fold of the staged heavy pass
+  std::mutex se_busy;  // one single-end call at a time per index (the streams and events below are the call's)
   hipStream_t se_side = nullptr;
   hipEvent_t se_fork = nullptr, se_join = nullptr;
   // single-end staged heavy pass in two halves (map_se.hip launch_map_se): the second half's stream and the events
@@ -55,6 +83,7 @@ struct walt_index {
   hipEvent_t se_pipe_ev[3] = {nullptr, nullptr, nullptr};
   // paired-end (created on first use): two pipeline slots, each with a stream for mate 1 + merge (A, unused in
   // slot 0 of a single-pass call: the caller's stream plays that role) and one for mate 2 (B)
+  std::mutex pe_busy;  // one paired-end call at a time per index
   hipStream_t pe_stream[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   hipEvent_t pe_fork[2] = {nullptr, nullptr}, pe_join[2] = {nullptr, nullptr}, pe_done[2] = {nullptr, nullptr};
   hipEvent_t pe_start = nullptr;
@@ -88,6 +117,7 @@ constexpr int kBlock = 256;
 constexpr uint32_t kG2PadWords = 96;  // slack behind the packed genome for window loads
 
 inline unsigned grid_for(uint64_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
+unsigned persistent_grid(const walt_index* idx);  // blocks of the persistent mapping kernels: 8 per compute unit (option grid)
 
 // words per packed read for a maximum read length (template instances 7/8/10/16/32/64)
 inline int nw_for_len(uint32_t max_len) {

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include <stddef.h>
+
 #include "device_common.h"
 
 namespace walt {
@@ -328,12 +330,25 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
   {
     const char* e = getenv("WALT_AMD_FENCE");
     if (index_size && !(e && atoi(e) == 0)) {
-      for (uint32_t k = 0; k < kFenceLevels; ++k) {
+      // best effort, like the dense windows: the long-slot search works without them (core.h slot_kary_search), so a
+      // device that holds the index with little room to spare opens it as before the fences existed
+      bool have = true;
+      const size_t n_before = idx->allocs.size();
+      const uint64_t bytes_before = idx->device_bytes;
+      for (uint32_t k = 0; k < kFenceLevels && have; ++k) {
         const uint64_t n_k = (((uint64_t)index_size - 1) >> (4 * (k + 1))) + 1;
-        if ((rc = dev_alloc(idx, &fen[k], 2 * n_k + 32))) return rc;  // (+ slack: a clamped pivot never reads beyond, a whole line may)
+        have = dev_alloc(idx, &fen[k], 2 * n_k + 32) == WALT_OK;  // (+ slack: a clamped pivot never reads beyond, a whole line may)
       }
-      hipLaunchKernelGGL(k_make_fences, dim3(grid_for(((uint64_t)index_size + 15) / 16)), dim3(kBlock), 0, stream, ent, index_size,
-                         fen[0], fen[1], fen[2], fen[3]);
+      if (have) {
+        hipLaunchKernelGGL(k_make_fences, dim3(grid_for(((uint64_t)index_size + 15) / 16)), dim3(kBlock), 0, stream, ent, index_size,
+                           fen[0], fen[1], fen[2], fen[3]);
+      } else {
+        (void)hipGetLastError();
+        while (idx->allocs.size() > n_before) { (void)hipFree(idx->allocs.back()); idx->allocs.pop_back(); }
+        idx->device_bytes = bytes_before;
+        for (uint32_t k = 0; k < kFenceLevels; ++k) fen[k] = nullptr;
+        if (getenv("WALT_AMD_VERBOSE")) fprintf(stderr, "[walt_amd index: strand %d: no fence keys (device memory)]\n", strand);
+      }
     }
   }
   if (index_size) {
@@ -707,6 +722,10 @@ int new_index(int device, const IndexHead& head, int dir_bits, int n_strands, wa
   WALT_HIP(hipSetDevice(device));
   walt_index* idx = new walt_index();
   idx->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) idx->n_cu = prop.multiProcessorCount;
+  }
   idx->head = head;
   memset(&idx->view, 0, sizeof(idx->view));
   size_t free_b = 0, total_b = 0;
@@ -1029,6 +1048,55 @@ int walt_index_dir_bits(const walt_index* idx) { return idx ? (int)idx->view.dir
 uint64_t walt_index_bad_buckets(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->bad_buckets[strand] : 0;
 }
+// ---- options (include/walt_amd.h): the table of names; every value changes a call's schedule, never its results
+namespace {
+struct OptionName {
+  const char* name;
+  int kind;  // 0: int field, 1: long long field
+  size_t offset;
+  long long lo, hi;
+};
+#define WALT_OPT_I(f, lo, hi) {#f, 0, offsetof(walt_options, f), lo, hi}
+#define WALT_OPT_L(f, lo, hi) {#f, 1, offsetof(walt_options, f), lo, hi}
+const OptionName kOptions[] = {
+    WALT_OPT_I(se_pipe, 0, 1),        WALT_OPT_L(se_heavy_chunk, 0, 1ll << 28), WALT_OPT_I(se_lit_side, 0, 1),
+    WALT_OPT_L(se_defer_min, -1, 1ll << 30), WALT_OPT_I(se_stage_occ, 0, 4),   WALT_OPT_I(se_carry, 0, 1),
+    WALT_OPT_I(se_heavy_mono, 0, 1),  WALT_OPT_L(grid, 0, 1ll << 20),           WALT_OPT_I(pe_mode, 0, 1),
+    WALT_OPT_L(pe_chunk, 0, 1ll << 28), WALT_OPT_L(pe_rounds, 0, 4),            WALT_OPT_L(pe_stage_cap, 0, 1ll << 28),
+    WALT_OPT_I(pe_small_heaps, 0, 1), WALT_OPT_I(pe_serial, 0, 1),              WALT_OPT_L(pe_defer_min, -1, 1ll << 30),
+    WALT_OPT_I(pe_roomy, -1, 1),
+};
+#undef WALT_OPT_I
+#undef WALT_OPT_L
+const OptionName* find_option(const char* name) {
+  if (!name) return nullptr;
+  for (const OptionName& o : kOptions)
+    if (!strcmp(o.name, name)) return &o;
+  return nullptr;
+}
+}  // namespace
+
+int walt_index_set_option(walt_index* idx, const char* name, long long value) {
+  if (!idx) return fail(WALT_EINVAL, "null index");
+  const OptionName* o = find_option(name);
+  if (!o) return fail(WALT_EINVAL, std::string("walt_index_set_option: unknown option '") + (name ? name : "(null)") + "'");
+  if (value < o->lo || value > o->hi)
+    return fail(WALT_EINVAL, std::string("walt_index_set_option: ") + name + " = " + std::to_string(value) + " is outside [" +
+                                 std::to_string(o->lo) + ", " + std::to_string(o->hi) + "]");
+  char* base = reinterpret_cast<char*>(&idx->opt) + o->offset;
+  if (o->kind == 0) *reinterpret_cast<int*>(base) = (int)value;
+  else *reinterpret_cast<long long*>(base) = value;
+  return WALT_OK;
+}
+int walt_index_get_option(const walt_index* idx, const char* name, long long* value) {
+  if (!idx || !value) return fail(WALT_EINVAL, "walt_index_get_option: bad argument");
+  const OptionName* o = find_option(name);
+  if (!o) return fail(WALT_EINVAL, std::string("walt_index_get_option: unknown option '") + (name ? name : "(null)") + "'");
+  const char* base = reinterpret_cast<const char*>(&idx->opt) + o->offset;
+  *value = o->kind == 0 ? (long long)*reinterpret_cast<const int*>(base) : *reinterpret_cast<const long long*>(base);
+  return WALT_OK;
+}
+
 uint64_t walt_index_outliers(const walt_index* idx, int strand) {
   return idx && strand >= 0 && strand < 4 ? idx->outliers[strand] : 0;
 }

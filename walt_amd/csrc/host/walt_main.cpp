@@ -51,6 +51,7 @@ struct Options {
   uint32_t max_mismatches = 6, batch_size = 10000000, b = 5000, top_k = 50;
   int frag_range = 1000, threads = 0;
   std::vector<int> devices;  // -g 0,1,...: every listed GPU holds an index replica and maps a contiguous share of each batch
+  std::vector<std::pair<string, long long>> tune;  // -X name=value: walt_index_set_option on every replica (schedule only, never results)
 };
 
 static bool is_opt(const string& a, const char* s, const char* l) { return a == string("-") + s || a == string("-") + l || a == string("--") + l; }
@@ -91,6 +92,12 @@ static Options parse(int argc, const char** argv) {
     else if (is_opt(a, "g", "gpu")) {  // extension: device ordinal(s), comma separated
       o.devices.clear();
       for (const string& t : split_csv(val())) o.devices.push_back(atoi(t.c_str()));
+    }
+    else if (a == "-X") {  // extension: an option of the mapping library (include/walt_amd.h, walt_index_set_option)
+      const string kv = val();
+      const size_t eq = kv.find('=');
+      if (eq == string::npos || eq == 0) die("-X wants name=value");
+      o.tune.emplace_back(kv.substr(0, eq), atoll(kv.c_str() + eq + 1));
     }
     else die("unknown option " + a);
   }
@@ -272,6 +279,9 @@ struct DeviceSet {
       });
     for (auto& t : th) t.join();
     for (const string& e : err) if (!e.empty()) { close(); die(e); }
+    for (walt_index* i : idx)
+      for (const auto& kv : o.tune)
+        if (walt_index_set_option(i, kv.first.c_str(), kv.second) != WALT_OK) { const string e = walt_last_error(); close(); die(e); }
   }
   void close() {
     for (walt_index*& i : idx) { if (i) walt_index_close(i); i = nullptr; }

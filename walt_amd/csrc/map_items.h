@@ -30,8 +30,10 @@ struct ItemQueue {
   uint4* items;   // cap items of item_quads<NW>() quads
   uint32_t* ctl;  // [0] dense items, [1] gather items, [2] [3] the verifiers' cursors (zeroed by the host)
   uint32_t cap;   // items the array has room for, both kinds TOGETHER: dense items fill it from the front, gather items from
-                  // the back, and each side is checked against cap alone -- a caller must size cap for the most items
-                  // that can come (the stage kernels: two per read and stage), or the two sides would meet
+                  // the back.  A caller sizes cap for the most items that can come (the stage kernels: two per read and
+                  // round); an append that finds its side's count beyond cap is dropped AND counted in *ovf, and the
+                  // verifiers count the two sides having met (items_overflow_check): walt_batch_check reports either
+  uint32_t* ovf;  // overflow counter (the workspace's err[2]); nullptr: none
   // Largest first: dense items of more than kBigFirst candidates go to their own array and the dense verifier takes
   // them BEFORE the others (item numbers [0, bigs) are this array's), dealt round robin over the wavefronts -- a
   // region of thousands of candidates is tens of dependent steps, and a wavefront that met two or three of them at
@@ -116,6 +118,7 @@ __device__ __forceinline__ void item_append2(const bool* take, const bool* dense
     for (int f = 0; f < 2; ++f) {
       const uint32_t k = base + (f ? n0 : 0u) + (uint32_t)__popcll(m[f] & ((1ull << lane) - 1ull));
       if (side < 0) in_bigs[f] = mine[f] && k < room;  // no room: the item goes to the ordinary dense side below
+      if (side >= 0 && mine[f] && k >= room && q.ovf != nullptr) atomicAdd(q.ovf, 1u);  // (never, with a queue sized as above)
       if (mine[f] && k < room) {
         const uint64_t at = side <= 0 ? k : (uint64_t)q.cap - 1 - k;
         uint4* it = (side < 0 ? q.bigs : q.items) + Q * at;
@@ -132,6 +135,11 @@ __device__ __forceinline__ void item_append2(const bool* take, const bool* dense
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+// the two sides of the queue must not have met (one thread of a verifier launch checks the launch's counts)
+__device__ __forceinline__ void items_overflow_check(const ItemQueue& q) {
+  if (q.ovf != nullptr && (uint64_t)q.ctl[0] + q.ctl[1] > q.cap) atomicAdd(q.ovf, 1u);
+}
 
 // A pointer the kernel got inside a by-value struct is a generic pointer to the compiler, and a load through it a
 // FLAT load: it counts as vector-memory AND as LDS traffic, so that waiting for one -- or for any LDS read

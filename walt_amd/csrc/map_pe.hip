@@ -40,28 +40,21 @@ namespace walt {
 // wavefront), so their cost per pass is nearly constant: large passes amortise it.  The ranked lists
 // (2 x top_k x 12 B per pair) bound the pass by a ~10 GB workspace budget.
 constexpr uint32_t kPeChunkMax = 1u << 23;
-// Larger passes taken in fewer rounds when the device has the room (decided ONCE per process, when the first
-// workspace is sized -- the launcher and walt_pe_workspace_bytes must agree): 0 = 8 M-pair passes, staged lists in four
-// rounds (24 GB of workspace at -k 50); 1 = 10 M-pair passes in one round (50 GB: every launch of the staged
-// kernels gets four times the items and the passes are a third fewer -- 273 -> 247 ms per 50 M pairs).  An hg19-scale
-// four-strand index with 2^31-slot directories leaves that room on a 288 GB device (device_index.hip choose_dir_bits).
-static int g_pe_roomy = -1;  // -1: not decided yet (pe_decide_roomy, at the first sizing or launch of the process)
-static int pe_roomy() {
-  if (const char* e = getenv("WALT_AMD_PE_ROOMY")) return atoi(e) != 0 ? 1 : 0;  // (tests / A/B: read at every call, like the other hooks)
-  return g_pe_roomy == 1 ? 1 : 0;
-}
-static inline uint32_t pe_chunk_pairs(uint32_t n, uint32_t top_k) {
-  const uint64_t budget = pe_roomy() ? 12ull << 30 : 10ull << 30;
-  uint64_t c = budget / ((uint64_t)(top_k ? top_k : 1) * 2 * sizeof(Candidate));
-  const uint64_t cmax = pe_roomy() ? 10000000ull : kPeChunkMax;
-  if (c > cmax) c = cmax;
-  if (c < (1u << 16)) c = 1u << 16;
-  if (const char* e = getenv("WALT_AMD_PE_CHUNK")) {  // test hook: force several passes on a small batch
-    const long v = atol(e);
-    if (v > 0) c = (uint64_t)v;
-  }
-  return n < c ? n : (uint32_t)c;
-}
+// The geometry of a call -- pairs per pass, staged reads per round, rounds, survivor pool -- follows from (n, top_k),
+// the index's options and ONE more bit, `roomy`: larger passes taken in fewer rounds when the device has the room
+// (0 = 8 M-pair passes, staged lists in four rounds: 24 GB of workspace at -k 50; 1 = 10 M-pair passes in one round:
+// 50 GB, every launch of the staged kernels gets four times the items and the passes are a third fewer -- 273 -> 247 ms
+// per 50 M pairs).  Nothing about it is kept in the process: the CALLER's workspace size decides (a call is roomy when
+// the workspace it was given holds the roomy geometry; walt_pe_workspace_bytes_best sizes one from the free memory of
+// the index's device), so a sizing call and a mapping call cannot disagree and two indexes on two devices do not share
+// a decision (round 3 kept it in a process-global).
+struct PeGeometry {
+  uint32_t chunk;        // pairs per pass
+  uint32_t rounds;       // rounds a pass takes its staged list in
+  uint32_t ccap;         // staged reads per round, pass and mate
+  uint32_t pool_chunks;  // survivor chunks of a round
+  bool roomy;
+};
 constexpr uint32_t kCoopUnroll = 2;    // 64-candidate groups of a large region verified per step (4 cost a wave per SIMD in registers)
 
 // One read per lane.  LITERAL as in map_se.hip: pass 1 defers reads that hit a
@@ -1267,7 +1260,8 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+static inline uint64_t pe_align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return pe_align_up(v, a); }
 
 constexpr uint32_t kPeInlineHost = 16, kPeChunksHost = 8;  // = kPeMidRegion, kPeChunks (defined with the pattern-3 kernels)
 struct PeWorkspace {
@@ -1291,30 +1285,42 @@ struct PeWorkspace {
   uint32_t* sflag[2];
   uint4* items[2];
   uint4* bigs[2];
-  uint32_t ccap, pool_chunks;
+  uint32_t ccap, pool_chunks, rounds;
 };
 // staged reads per round, pass and mate: a sixteenth of the pass (complex reads and filter hits are a fifth of the
 // reads of an hg19-like genome: four rounds; the state of a staged read is 2.2 KB and the paired-end index leaves
 // little room -- with rounds of an eighth the survivor pool had to shrink and a tenth of the staged reads fell
 // back to the list kernel: 359 ms against 315), all of it when the pass is small
-// rounds a pass takes its staged list in (WALT_AMD_PE_ROUNDS = 1, 2 or 4; the staged state grows accordingly)
-static uint32_t pe_rounds() {
-  const char* e = getenv("WALT_AMD_PE_ROUNDS");  // (read at every call, like WALT_AMD_PE_STAGE_CAP: a caller sizes and launches under one setting)
-  const long v = e ? atol(e) : (pe_roomy() ? 1 : 4);
-  return (uint32_t)(v == 1 || v == 2 ? v : 4);
-}
-static uint32_t pe_stage_cap(uint32_t chunk) {
-  if (const char* e = getenv("WALT_AMD_PE_STAGE_CAP")) {  // test hook: several rounds and the list-kernel fallback on a small batch
-    const long v = atol(e);
-    if (v > 0) return (uint32_t)align_up((uint64_t)v, 64);
+static PeGeometry pe_geometry(uint32_t n, uint32_t top_k, const walt_options& opt, bool roomy) {
+  PeGeometry g;
+  g.roomy = roomy;
+  const uint64_t budget = roomy ? 12ull << 30 : 10ull << 30;
+  uint64_t c = budget / ((uint64_t)(top_k ? top_k : 1) * 2 * sizeof(Candidate));
+  const uint64_t cmax = roomy ? 10000000ull : kPeChunkMax;
+  if (c > cmax) c = cmax;
+  if (c < (1u << 16)) c = 1u << 16;
+  if (opt.pe_chunk > 0) c = (uint64_t)opt.pe_chunk;  // test hook: several passes on a small batch
+  g.chunk = n < c ? n : (uint32_t)c;
+  const long long rv = opt.pe_rounds > 0 ? opt.pe_rounds : (roomy ? 1 : 4);
+  g.rounds = (uint32_t)(rv == 1 || rv == 2 ? rv : 4);
+  if (opt.pe_stage_cap > 0) {  // test hook: several rounds and the list-kernel fallback on a small batch
+    g.ccap = (uint32_t)pe_align_up((uint64_t)opt.pe_stage_cap, 64);
+  } else if (g.chunk <= 65536) {
+    g.ccap = g.chunk ? g.chunk : 1;
+  } else {
+    const uint32_t cc = g.chunk / (4 * g.rounds);  // the rounds together hold a quarter of the pass
+    g.ccap = (uint32_t)pe_align_up(cc > 65536 ? cc : 65536, 64);
   }
-  if (chunk <= 65536) return chunk ? chunk : 1;
-  const uint32_t c = chunk / (4 * pe_rounds());  // the rounds together hold a quarter of the pass
-  return (uint32_t)align_up(c > 65536 ? c : 65536, 64);
+  // 128 survivors per staged read on average (192 when the device is roomy); three quarters static, the dynamic
+  // quarter handed out kPoolGrab chunks at a time
+  const uint32_t pool = roomy ? g.ccap * 3u : g.ccap * 2u + g.ccap / 2u;
+  g.pool_chunks = pool > 8192 ? pool : 8192;
+  return g;
 }
 
-static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, uint32_t max_read_len) {
+static PeWorkspace carve_pe(void* base, const PeGeometry& geo, int nw, uint32_t top_k, uint32_t max_read_len) {
   PeWorkspace w;
+  const uint32_t chunk = geo.chunk;
   uint8_t* p = reinterpret_cast<uint8_t*>(base);
   uint64_t off = 0;
   auto take = [&](uint64_t bytes) {
@@ -1331,11 +1337,9 @@ static PeWorkspace carve_pe(void* base, uint32_t chunk, int nw, uint32_t top_k, 
   for (int m = 0; m < 2; ++m) w.defer_list[m] = reinterpret_cast<uint32_t*>(take(3 * w.stride * 4 + 64));  // literal list, its sorted copy, complex list
   for (int m = 0; m < 2; ++m) w.codes2[m] = reinterpret_cast<uint32_t*>(take(codes2_words((uint64_t)chunk * max_read_len) * 4 + 64));
   for (int m = 0; m < 2; ++m) w.ranked[m] = reinterpret_cast<Candidate*>(take((uint64_t)chunk * top_k * sizeof(Candidate) + 64));
-  w.ccap = pe_stage_cap(chunk);
-  // 128 survivors per staged read on average (192 when the device is roomy); three quarters static, the dynamic
-  // quarter handed out kPoolGrab chunks at a time
-  const uint32_t pool = pe_roomy() ? w.ccap * 3u : w.ccap * 2u + w.ccap / 2u;
-  w.pool_chunks = pool > 8192 ? pool : 8192;
+  w.ccap = geo.ccap;
+  w.pool_chunks = geo.pool_chunks;
+  w.rounds = geo.rounds;
   const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
   for (int m = 0; m < 2; ++m) {
     w.fb_list[m] = reinterpret_cast<uint32_t*>(take(w.stride * 4 + 64));
@@ -1369,17 +1373,17 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
   (void)lit_sorted; (void)cplx_list; (void)cplx_count; (void)w; (void)mate;
   // patterns 5 / 7: the strand-major list kernel over every read with the directory/key search, Bloom hits
   // deferred to the literal list
-  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(1536), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
+  hipLaunchKernelGGL((k_pe_topk_list<NW, false>), dim3(6u * (unsigned)idx->n_cu), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, nullptr, nullptr, lit_count, lit_list, n);
-  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(1536), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
+  hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(6u * (unsigned)idx->n_cu), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_list, nullptr, nullptr, 0u);
   return WALT_OK;
 #else
-  const unsigned g1 = grid_for(n) < kPersistentGrid ? grid_for(n) : kPersistentGrid;
-  const unsigned g2 = 1536;  // x 4 waves: the list kernels size their per-wave share from the list length
-  // WALT_AMD_PE=list: complex reads and filter hits mapped by the list kernels only (the path before the staged one)
-  const char* pe_mode = getenv("WALT_AMD_PE");
-  const bool list_only = pe_mode && !strcmp(pe_mode, "list");
+  const unsigned pg = persistent_grid(idx);
+  const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
+  const unsigned g2 = 6u * (unsigned)idx->n_cu;  // x 4 waves: the list kernels size their per-wave share from the list length
+  // option pe_mode = 1: complex reads and filter hits mapped by the list kernels only (the path before the staged one)
+  const bool list_only = idx->opt.pe_mode == 1;
   uint32_t* over_count = ctl + 25;  // zeroed with the control block at the start of the pass
   if (!list_only) {
     static_assert(kPeMidRegion == kPeInlineHost && kPeChunks == kPeChunksHost && kPeChunkEnts == 64, "carve_pe sizes the survivor storage");
@@ -1387,39 +1391,36 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     PeStage ps;
     ps.inl = w.inl[mate]; ps.surv_n = w.surv_n[mate]; ps.cz = w.cz[mate]; ps.chunk = w.chunk_tab[mate]; ps.pool = w.pool[mate];
     ps.pool_next = ctl + 27; ps.pool_chunks = w.pool_chunks; ps.static_n = w.pool_chunks / 4; ps.flag = w.sflag[mate];
-    ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 2 * w.ccap;
+    ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 2 * w.ccap; ps.q.ovf = nullptr;
     ps.q.bigs = w.bigs[mate]; ps.q.big_n = ctl + 2; ps.q.big_cap = w.ccap / 8 + 64;
     ps.ccap = w.ccap;
-    static const uint32_t defer_min = [] {  // WALT_AMD_DEFER=0: never (A/B); =n: ranges of more than n slots (n >= the in-lane limit)
-      const char* e = getenv("WALT_AMD_DEFER");
-      if (!e) return (uint32_t)kSmallRegion;  // (measured: 4 / 8 / 16 -> 32.5 / 33.2 / 34.2 ms per 25 M 150-base reads)
-      const long v = atol(e);
-      return v <= 0 ? 0xFFFFFFFFu : (uint32_t)(v < (long)kSmallRegion ? (long)kSmallRegion : v);
-    }();
-    ps.defer_min = defer_min;
+    // option pe_defer_min = 0: never (A/B); = n: ranges of more than n slots (n >= the in-lane limit)
+    const long long dm = idx->opt.pe_defer_min;
+    ps.defer_min = dm < 0 ? (uint32_t)kSmallRegion : dm == 0 ? 0xFFFFFFFFu : (uint32_t)(dm < (long long)kSmallRegion ? (long long)kSmallRegion : dm);
     uint32_t* fb_count = ctl + 26;
     uint32_t* fb_list = w.fb_list[mate];
-    static const unsigned vg_dense = [] {
+    static const int vb_dense = [] {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pe_verify<NW, NW <= 10>, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
-      return (unsigned)nb * 256u;
+      return nb;
     }();
-    static const unsigned vg_gather = [] {
+    static const int vb_gather = [] {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pe_verify<NW, false>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
-      return (unsigned)nb * 256u;
+      return nb;
     }();
-    const unsigned gs = grid_for(w.ccap) < kPersistentGrid ? grid_for(w.ccap) : kPersistentGrid;
+    const unsigned vg_dense = (unsigned)vb_dense * (unsigned)idx->n_cu, vg_gather = (unsigned)vb_gather * (unsigned)idx->n_cu;
+    const unsigned gs = grid_for(w.ccap) < pg ? grid_for(w.ccap) : pg;
     auto verify = [&]() {
       if constexpr (NW > 8 && NW <= 10)
-        hipLaunchKernelGGL((k_pe_tail_narrow<NW>), dim3(256 * 4), dim3(kBlock), 0, stream, view, sb, ps, b);
+        hipLaunchKernelGGL((k_pe_tail_narrow<NW>), dim3(4u * (unsigned)idx->n_cu), dim3(kBlock), 0, stream, view, sb, ps, b);
       if constexpr (NW <= 10)
         hipLaunchKernelGGL((k_pe_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps, b);
       hipLaunchKernelGGL((k_pe_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, stream, view, sb, max_mm, top_k, stats, ps, b);
     };
     // the staged state holds ccap reads: a list is taken in rounds of ccap (the list's length is on the device: a
     // fixed number of rounds, the empty ones cost a few launches), the last round hands the rest to the list kernel
-    const uint32_t kRounds = pe_rounds();  // together a quarter of the pass
+    const uint32_t kRounds = w.rounds;  // together a quarter of the pass
     uint32_t* big_count = ctl + 1;  // reads of the round with more than kPushSmall survivors
     uint32_t* big_list = w.big_list[mate];
     auto clear_round = [&]() {  // pool + queue, the push kernels' list
@@ -1481,7 +1482,7 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
   // literal list: 8-slot heaps, so that 64 reads share a wavefront instead of 15 at -k 50 (with thousands of
   // contigs a tenth of the reads is here); the few reads with more candidates overflow into the complex list's
   // area, which is free again, and are mapped with full heaps
-  const uint32_t kSmallHeap = 8u | (getenv("WALT_AMD_SMALL_HEAPS") ? 0x80000000u : 0u);  // env: force (tests)
+  const uint32_t kSmallHeap = 8u | (idx->opt.pe_small_heaps ? 0x80000000u : 0u);  // option: force (tests)
   hipLaunchKernelGGL((k_pe_topk_list<NW, true>), dim3(g2), dim3(kBlock), 0, stream, view, codes2, offsets, err, sb,
                      max_mm, b, top_k, idx->d_mask_table, ranked, heap_n, stats, lit_count, lit_sorted, nullptr, nullptr, 0u,
                      kSmallHeap, over_count, cplx_list);
@@ -1516,8 +1517,8 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   WALT_HIP(hipMemsetAsync(w.err + 64, 0, 128 * sizeof(uint32_t), stream));
   // The two mates are independent until the merge; mate 2 runs on a second stream so that its
   // throughput-bound pass 1 overlaps mate 1's list kernels (a few slow reads, mostly idle CUs) and vice versa.
-  // WALT_AMD_PE_SERIAL=1 (profiling): both mates and every pass on one stream, so that a kernel's duration is its own
-  static const bool serial = [] { const char* e = getenv("WALT_AMD_PE_SERIAL"); return e && atoi(e) != 0; }();
+  // option pe_serial = 1 (profiling): both mates and every pass on one stream, so that a kernel's duration is its own
+  const bool serial = idx->opt.pe_serial != 0;
   hipStream_t stream_b = serial ? stream : idx->pe_stream[slot][1];
   WALT_HIP(hipEventRecord(idx->pe_fork[slot], stream));
   WALT_HIP(hipStreamWaitEvent(stream_b, idx->pe_fork[slot], 0));
@@ -1557,7 +1558,7 @@ static int pe_chunk(walt_index* idx, const uint8_t* d_bases1, const uint64_t* d_
   hipLaunchKernelGGL(k_pe_merge, dim3(grid_for(n)), dim3(kBlock), 0, stream, idx->view, w.ranked[0], w.heap_n[0],
                      w.ranked[1], w.heap_n[1], d_off1, d_off2, n, top_k, frag_range, max_mm, d_out, heavy_count,
                      heavy_list);
-  hipLaunchKernelGGL(k_pe_merge_heavy, dim3(grid_for(n) < 2048u ? grid_for(n) : 2048u), dim3(kBlock),
+  hipLaunchKernelGGL(k_pe_merge_heavy, dim3(grid_for(n) < persistent_grid(idx) ? grid_for(n) : persistent_grid(idx)), dim3(kBlock),
                      (size_t)(kBlock / 64) * 2 * top_k * sizeof(uint4), stream,
                      idx->view, w.ranked[0], w.heap_n[0], w.ranked[1], w.heap_n[1], d_off1, d_off2, top_k, frag_range,
                      max_mm, d_out, heavy_count, heavy_list);
@@ -1584,49 +1585,68 @@ using namespace walt;
 
 extern "C" {
 
-// roomy when the device has room for this batch's roomy workspace and its pair records beside what is allocated already
-static void pe_decide_roomy(uint32_t n, uint32_t max_read_len, uint32_t top_k) {
-  if (g_pe_roomy >= 0 || getenv("WALT_AMD_PE_ROOMY")) return;
-  int nw = nw_for_len(max_read_len);
-  if (!nw) nw = 64;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { g_pe_roomy = 0; return; }
-  g_pe_roomy = 1;  // size it as if
-  const uint32_t chunk = pe_chunk_pairs(n, top_k);
-  const uint64_t want = (uint64_t)carve_pe(nullptr, chunk, nw, top_k, max_read_len).total_bytes * (n > chunk ? 2 : 1) + (uint64_t)n * sizeof(PairResult) +
-                        (2ull << 30);
-  g_pe_roomy = free_b >= want ? 1 : 0;
+// bytes a call needs under geometry g: a call of several passes keeps two of them in flight (two workspaces)
+static size_t pe_bytes(const PeGeometry& g, uint32_t n, int nw, uint32_t top_k, uint32_t max_read_len, bool serial) {
+  return (size_t)carve_pe(nullptr, g, nw, top_k, max_read_len).total_bytes * ((n > g.chunk && !serial) ? 2 : 1);
+}
+// the geometry of a call whose workspace has `have` bytes (0: unknown -- the least): roomy when that fits (or is forced)
+static int pe_choose(const walt_options& opt, uint32_t n, int nw, uint32_t top_k, uint32_t max_read_len, size_t have, PeGeometry* out) {
+  const PeGeometry g1 = pe_geometry(n, top_k, opt, true), g0 = pe_geometry(n, top_k, opt, false);
+  const bool serial = opt.pe_serial != 0;
+  const bool roomy = opt.pe_roomy == 1 || (opt.pe_roomy < 0 && have >= pe_bytes(g1, n, nw, top_k, max_read_len, serial));
+  *out = roomy ? g1 : g0;
+  if (pe_bytes(*out, n, nw, top_k, max_read_len, serial) > have)
+    return fail(WALT_EINVAL, "walt_map_pe_batch_device: the workspace is smaller than this call needs under the index's options (" +
+                                 std::to_string(pe_bytes(*out, n, nw, top_k, max_read_len, serial)) + " bytes; walt_pe_workspace_bytes_best)");
+  return WALT_OK;
 }
 
 size_t walt_pe_workspace_bytes(uint32_t n, uint32_t max_read_len, uint32_t top_k) {
-  pe_decide_roomy(n, max_read_len, top_k);
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
-  uint32_t chunk = pe_chunk_pairs(n, top_k);
-  // a call of several passes keeps two of them in flight (two workspaces)
-  return (size_t)carve_pe(nullptr, chunk, nw, top_k, max_read_len).total_bytes * (n > chunk ? 2 : 1);
+  const walt_options defaults;
+  return pe_bytes(pe_geometry(n, top_k, defaults, false), n, nw, top_k, max_read_len, false);
+}
+
+size_t walt_pe_workspace_bytes_best(walt_index* idx, uint32_t n, uint32_t max_read_len, uint32_t top_k) {
+  if (!idx) return walt_pe_workspace_bytes(n, max_read_len, top_k);
+  int nw = nw_for_len(max_read_len);
+  if (!nw) nw = 64;
+  const walt_options& opt = idx->opt;
+  const bool serial = opt.pe_serial != 0;
+  const size_t small = pe_bytes(pe_geometry(n, top_k, opt, false), n, nw, top_k, max_read_len, serial);
+  const size_t roomy = pe_bytes(pe_geometry(n, top_k, opt, true), n, nw, top_k, max_read_len, serial);
+  if (opt.pe_roomy == 0) return small;
+  if (opt.pe_roomy == 1) return roomy;
+  // roomy when idx's device has room for the roomy workspace and the batch's pair records beside what is allocated already
+  size_t free_b = 0, total_b = 0;
+  if (hipSetDevice(idx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return small;
+  return free_b >= roomy + (uint64_t)n * sizeof(PairResult) + (2ull << 30) ? roomy : small;
 }
 
 int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* d_offsets1, const void* d_bases2,
                              const void* d_offsets2, uint32_t n, uint32_t max_read_len, uint32_t max_mismatches,
                              uint32_t b, uint32_t top_k, int frag_range, void* d_out, void* d_stats,
-                             void* d_workspace, void* stream_) {
+                             void* d_workspace, size_t workspace_bytes, void* stream_) {
   int nw = 0;
   int rc = pe_check_args(idx, top_k, max_read_len, &nw);
   if (rc) return rc;
   if (n == 0) return WALT_OK;
+  std::unique_lock<std::mutex> busy(idx->pe_busy, std::try_to_lock);
+  if (!busy.owns_lock()) return fail(WALT_EINVAL, "walt_map_pe_batch: another paired-end call is running on this index (an index is not re-entrant)");
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   WALT_HIP(hipSetDevice(idx->device));
-  pe_decide_roomy(n, max_read_len, top_k);  // (a caller that sized its workspace has decided it already)
-  const uint32_t chunk = pe_chunk_pairs(n, top_k);
+  PeGeometry geo;
+  if ((rc = pe_choose(idx->opt, n, nw, top_k, max_read_len, workspace_bytes, &geo))) return rc;
+  const uint32_t chunk = geo.chunk;
   if ((rc = pe_streams(idx))) return rc;
   // Passes alternate between two pipeline slots (own workspace and streams), so the latency-bound list
   // kernels and the merge of one pass run beside the throughput-bound pass 1 of the next.
-  static const bool serial = [] { const char* e = getenv("WALT_AMD_PE_SERIAL"); return e && atoi(e) != 0; }();
+  const bool serial = idx->opt.pe_serial != 0;
   const bool two = n > chunk && !serial;
   PeWorkspace w[2];
-  w[0] = carve_pe(d_workspace, chunk, nw, top_k, max_read_len);
-  w[1] = two ? carve_pe(static_cast<uint8_t*>(d_workspace) + w[0].total_bytes, chunk, nw, top_k, max_read_len) : w[0];
+  w[0] = carve_pe(d_workspace, geo, nw, top_k, max_read_len);
+  w[1] = two ? carve_pe(static_cast<uint8_t*>(d_workspace) + w[0].total_bytes, geo, nw, top_k, max_read_len) : w[0];
   WALT_HIP(hipMemsetAsync(w[0].err, 0, 128 * sizeof(uint32_t), stream));
   for (int k = 0; k < (two ? 2 : 1); ++k)
     for (int m = 0; m < 2; ++m) WALT_HIP(hipMemsetAsync(w[k].shards[m], 0, kStatShardBytes, stream));
@@ -1634,6 +1654,12 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
     WALT_HIP(hipEventRecord(idx->pe_start, stream));
     for (int k = 0; k < 2; ++k) WALT_HIP(hipStreamWaitEvent(idx->pe_stream[k][0], idx->pe_start, 0));
   }
+  // work queued on the index's own streams must not outlive an error return (the caller frees its workspace)
+  auto unwind = [&]() {
+    for (int k = 0; k < 2; ++k)
+      for (int j = 0; j < 2; ++j)
+        if (idx->pe_stream[k][j]) (void)hipStreamSynchronize(idx->pe_stream[k][j]);
+  };
   uint32_t pass = 0;
   for (uint32_t start = 0; start < n; start += chunk, ++pass) {
     uint32_t cnt = n - start < chunk ? n - start : chunk;
@@ -1643,12 +1669,14 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
                   nw, max_read_len, max_mismatches, b, top_k, frag_range, reinterpret_cast<PairResult*>(d_out) + start,
                   reinterpret_cast<unsigned long long*>(d_stats), w[slot], w[0].err, slot,
                   two ? idx->pe_stream[slot][0] : stream);
-    if (rc) return rc;
+    if (rc) { unwind(); return rc; }
   }
   if (two)
     for (int k = 0; k < 2; ++k) {
-      WALT_HIP(hipEventRecord(idx->pe_done[k], idx->pe_stream[k][0]));
-      WALT_HIP(hipStreamWaitEvent(stream, idx->pe_done[k], 0));
+      if (hipEventRecord(idx->pe_done[k], idx->pe_stream[k][0]) != hipSuccess || hipStreamWaitEvent(stream, idx->pe_done[k], 0) != hipSuccess) {
+        unwind();
+        return fail(WALT_EHIP, "paired-end: joining the pipeline slots failed");
+      }
     }
   return WALT_OK;
 }
@@ -1690,14 +1718,28 @@ int walt_map_pe_batch(walt_index* idx, const char* bases1, const uint64_t* offse
     if ((e = hipMemcpy(d_bases[m], bases[m] + offs[m][0], nbytes, hipMemcpyHostToDevice)) != hipSuccess) break;
     e = hipMemcpy(d_off[m], off_src, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
   }
-  const uint32_t chunk = pe_chunk_pairs(n, top_k);
-  const size_t ws_bytes = carve_pe(nullptr, chunk, nw, top_k, max_len).total_bytes;
   if (e == hipSuccess) e = host_api_buffer(idx, 4, (size_t)n * sizeof(walt_pair_result), &d_out);
   if (e == hipSuccess) e = host_api_buffer(idx, 5, 2 * sizeof(walt_batch_stats), &d_stats);
+  // the same decision the device form's callers make (walt_pe_workspace_bytes_best): the larger passes when the device has
+  // the room.  One pass at a time here (the ranked lists are copied out between passes): one workspace.
+  walt_options one_slot = idx->opt;
+  one_slot.pe_serial = 1;
+  PeGeometry geo = pe_geometry(n, top_k, one_slot, false);
+  {
+    const PeGeometry g1 = pe_geometry(n, top_k, one_slot, true);
+    const size_t roomy_bytes = carve_pe(nullptr, g1, nw, top_k, max_len).total_bytes;
+    size_t free_b = 0, total_b = 0;
+    const bool have = idx->host_api_cap[6] >= roomy_bytes;
+    if (one_slot.pe_roomy == 1 || (one_slot.pe_roomy < 0 && (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                                                                   free_b >= roomy_bytes + (2ull << 30)))))
+      geo = g1;
+  }
+  const uint32_t chunk = geo.chunk;
+  const size_t ws_bytes = carve_pe(nullptr, geo, nw, top_k, max_len).total_bytes;
   if (e == hipSuccess) e = host_api_buffer(idx, 6, ws_bytes, &d_ws);
   if (e == hipSuccess) e = hipMemset(d_stats, 0, 2 * sizeof(walt_batch_stats));
   if (e != hipSuccess) return fail(WALT_EHIP, std::string("paired-end upload failed: ") + hipGetErrorString(e));
-  PeWorkspace w = carve_pe(d_ws, chunk, nw, top_k, max_len);
+  PeWorkspace w = carve_pe(d_ws, geo, nw, top_k, max_len);
   if ((rc = pe_streams(idx))) return rc;
   e = hipMemset(w.err, 0, 128 * sizeof(uint32_t));
   for (int m = 0; m < 2 && e == hipSuccess; ++m) e = hipMemset(w.shards[m], 0, kStatShardBytes);

@@ -308,30 +308,144 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 
 constexpr uint32_t kMidRegion = 16;  // heavy pass: regions up to this size are verified by their own lane, in batches
 
-// ---- staged heavy pass --------------------------------------------------------------------------------------
-// The heavy list is mapped in kPat + 1 stages per chunk of `hcap` reads: stage k = 0 .. kPat - 1 does what the monolithic
-// heavy kernel does for seed shift k (both strands' lookups, the regions of up to kMidRegion candidates) but turns
-// every larger region into a work ITEM instead of borrowing the wavefront for it; k_se_verify streams the items
-// with one wavefront per region and writes their RegionSummary; stage k + 1 starts by reading the summaries of
-// the seeds before it (they decide which probes the reference makes next, mapping.cpp:250-257); stage kPat only
-// folds and writes the record.  State per read of the chunk: 2 kPat summaries (seed x strand) and a flag.
+// ---- staged heavy pass (round 4: run until blocked) ------------------------------------------------------------
+// The heavy list is mapped chunk by chunk (hcap reads) in ROUNDS.  In a round a lane takes one read and goes through
+// its seed shifts exactly as the reference does (mapping.cpp:248-263: '+' folded at once, '-' kept per seed) until a
+// probe produces a region too large for the lane -- a work ITEM for k_se_verify (one region per wavefront) -- and then
+// stops: it stores its folded state and the read goes onto the list of the next round, which starts behind the
+// verifier launch that wrote the item's RegionSummary.  A read that produces no item is finished in ONE visit (half of
+// the heavy reads of an hg19-like genome); the others are visited once more per seed shift that blocked them, and a
+// revisit finds everything it needs -- the packed read, the running BestMatch, the pending summaries -- in arrays
+// indexed by the read's position j in the chunk (coalesced 16-byte loads, no offsets -> bases -> conversion chain and
+// no replay of the earlier seeds' summaries; round 3 visited every read kPat + 1 times and started each visit over).
+// Round 0 does not start over either: pass 1 hands over the seed shift it gave up at together with its BestMatch and
+// '-' summaries (SeCarry), because the reference probes a seed once (mapping.cpp:265-277).
 struct HeavyStage {
-  uint4* sums;       // [2 kPat][hcap]: RegionSummary of (seed, strand) = sums[(2 * seed + strand) * hcap + j]
-  uint32_t* flag;    // [hcap]: 1 = the read went to the literal list at an earlier stage
+  uint4* st;         // [hcap]: {best.genome_pos, best.times, best.mismatch, smallest mismatch count of the kept '-' summaries}
+  uint4* rdq;        // [rd_quads<NW>()][hcap]: the converted read: {len, rd[0..2]}, {rd[3..6]}, ...
+  uint4* sums;       // [kPat + 1][hcap]: row 0 = '+' summary of the seed the read is blocked at, row 1 + k = '-' summary of seed k
   uint4* items;      // 2 * hcap items of item_quads<NW>() 16-byte words; dense items from the front, gather items from the back
   uint4* giants;     // hcap / 8 items: the dense regions of more than kBigFirst candidates, verified first (count: ctl[5])
-  uint32_t* ctl;     // this (chunk, stage)'s counters: [0] dense items, [1] gather items, [2] [3] the verifiers' cursors,
-                     // [4] reads that go on to the next stage
-  const uint32_t* list_in;  // stages 1 .. kPat - 1: the chunk positions j this stage visits (count in count_in[4]); else every j
+  uint32_t* ctl;     // this (chunk, round)'s counters: [0] dense items, [1] gather items, [2] [3] the verifiers' cursors,
+                     // [4] reads that go on to the next round, [5] giants, [6] items that found no room (must stay 0)
+  const uint32_t* list_in;  // rounds >= 1: the reads this round visits (stage_entry; count in count_in[4]); round 0: every j
   const uint32_t* count_in;
-  uint32_t* list_out;       // stages 0 .. kPat - 2: positions that may need the next seed
+  uint32_t* list_out;       // rounds < kPat: the reads this round blocks
   uint32_t hcap;     // reads per chunk
   uint32_t first;    // heavy-list index of the chunk's first read (even == 0)
   uint32_t chunk;    // even != 0: the heavy list is cut into an EVEN number of equal chunks of at most hcap reads, and
   uint32_t even;     // this is chunk number `chunk` of them (heavy_chunk_span; the list's length is known on the device only)
-  uint32_t stage;    // 0 .. kPat - 1: seed shift of the stage, kPat: final fold
+  uint32_t round;    // 0 .. kPat
   uint32_t defer_min;  // long seeds: key-equal ranges of more slots than this are narrowed by the verifier (0xFFFFFFFF: never)
 };
+// What pass 1 hands to round 0 for a read it gives up (arrays indexed by the read's number in the batch, nullptr: the
+// heavy pass starts over at seed 0): the heavy-list entry carries the seed shift and best.strand (heavy_entry), st the
+// BestMatch after the '+' folds of the seeds before it and the '-' bound, neg[k] the '-' summary of seed k < that seed.
+struct SeCarry {
+  uint4* st;    // [n]
+  uint4* neg;   // [kPat - 1][stride]
+  uint64_t stride;
+};
+constexpr uint32_t kHeavySeedShift = 28;  // heavy-list entry: read (n <= 2^28) | seed shift pass 1 gave it up at << 28
+__device__ __forceinline__ uint32_t heavy_entry(uint32_t r, uint32_t seed) { return r | (seed << kHeavySeedShift); }
+// list entry of the staged rounds: chunk position j (hcap <= 2^26) | seed shift the read is blocked at << 26
+constexpr uint32_t kStageJBits = 26;
+__device__ __forceinline__ uint32_t stage_entry(uint32_t j, uint32_t seed) { return j | (seed << kStageJBits); }
+template <int NW>
+constexpr uint32_t rd_quads() { return (NW + 1 + 3) / 4; }
+// Regions of kSmallRegion < size <= kMidRegion candidates stay with their lane (heavy kernels): all positions in one
+// round of loads, then the genome windows four at a time.  A lane usually has one such region, on either strand, so the
+// strands are not taken in turn: in the first pass every lane works on its '+' mid region, or on its '-' one if it has
+// no '+'; the second pass (skipped unless some lane has both) takes the remaining '-' ones.  All loads of a round are
+// unconditional (idle candidates read the first words of the genome): a load under `if (candidate ok)` is waited for
+// at the end of its branch, which made the four candidates of a round four round trips.
+// MULTI (patterns 5 / 7, long seeds): a region may be a key-equal RANGE whose candidates still owe their tail
+// characters (map_common.h probe_resolve_dual, multi_max): those that match are counted (nin: the region's size for
+// -b), one that fails an edge filter asks for the literal narrowing (fb).
+struct MidTail {
+  bool multi_p = false, multi_m = false;
+  bool fb_p = false, fb_m = false;
+  uint32_t nin_p = 0, nin_m = 0;
+};
+template <int NW, bool MULTI>
+__device__ __forceinline__ void se_mid_regions(const IndexView& iv, const BlockShared& sh, const StrandView& svp,
+                                               const StrandView& svm, uint32_t nmid_p, uint32_t nmid_m, uint32_t l_p,
+                                               uint32_t l_m, uint32_t seed_i, uint32_t len, const uint32_t* rd,
+                                               const uint32_t* mk, uint32_t n_chrom, uint32_t top_step, uint32_t tail_cut,
+                                               MidTail& mt, RegionSummary& sum_p, RegionSummary& sum_m, uint32_t& n_verified) {
+#pragma unroll 1
+  for (uint32_t pass = 0; pass < 2; ++pass) {
+    const bool on_m = pass == 0 ? (nmid_p == 0 && nmid_m != 0) : (nmid_p != 0 && nmid_m != 0);
+    const bool on_p = pass == 0 && nmid_p != 0;
+    const uint32_t nmid = on_p ? nmid_p : (on_m ? nmid_m : 0u);
+    if (!__ballot(nmid != 0)) continue;
+    const Ent* const ent = on_m ? svm.ent : svp.ent;
+    const uint32_t* const g2 = on_m ? svm.g2 : svp.g2;
+    const uint32_t my_l = nmid ? (on_m ? l_m : l_p) : 0u;
+    uint32_t posb[kMidRegion];
+#pragma unroll
+    for (uint32_t k = 0; k < kMidRegion; ++k) posb[k] = ent[k < nmid ? my_l + k : 0u].pos;  // (what a lane does not have: entry 0, one broadcast access)
+    RegionSummary acc = summary_empty();
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < kMidRegion; k0 += 4) {
+      if (!__ballot(k0 < nmid)) break;
+      bool ok[4];
+      uint32_t gpv[4], win[4][NW + 1];
+#pragma unroll
+      for (uint32_t jj = 0; jj < 4; ++jj) {
+        // posb[k0 + jj] by selects (k0 is not a compile-time constant: indexing would go to scratch)
+        uint32_t pos = 0;
+#pragma unroll
+        for (uint32_t k = jj; k < kMidRegion; k += 4) pos = (k == k0 + jj) ? posb[k] : pos;
+        uint32_t c_lo, c_hi;
+        if (n_chrom <= kLdsChroms) {
+          const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, pos);
+          c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
+        } else {
+          const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
+          c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
+        }
+        const uint32_t g = pos - seed_i;
+        ok[jj] = k0 + jj < nmid && (pos - c_lo >= seed_i) && (g + len < c_hi);  // mapping.cpp:280-286
+        if constexpr (MULTI) {
+          if (k0 + jj < nmid && !ok[jj]) { mt.fb_p = mt.fb_p || (on_p && mt.multi_p); mt.fb_m = mt.fb_m || (on_m && mt.multi_m); }
+        }
+        gpv[jj] = ok[jj] ? g : 0u;
+        const uint32_t* gw = g2 + (gpv[jj] >> 4);
+#pragma unroll
+        for (int w = 0; w <= NW; w += 4) {
+          constexpr int kAll = NW + 1;
+          const int cnt = kAll - w < 4 ? kAll - w : 4;
+          uint32_t q[4] = {0, 0, 0, 0};
+          __builtin_memcpy(q, gw + w, 4 * cnt);
+#pragma unroll
+          for (int t = 0; t < cnt; ++t) win[jj][w + t] = q[t];
+        }
+      }
+#pragma unroll
+      for (uint32_t jj = 0; jj < 4; ++jj) {
+        uint32_t mm = 0;
+        bool keep = ok[jj];
+        if constexpr (MULTI) {
+          uint32_t tmm = 0;
+          count_mismatch_regs_tail<NW>(win[jj], 2 * (gpv[jj] & 15u), rd, mk, seed_i, tail_cut, mm, tmm);
+          const bool mine = on_p ? mt.multi_p : (on_m && mt.multi_m);
+          keep = keep && (!mine || tmm == 0);
+          if (mine && keep) { if (on_p) ++mt.nin_p; else ++mt.nin_m; }
+        } else {
+          mm = count_mismatch_regs<NW>(win[jj], 2 * (gpv[jj] & 15u), rd, mk);
+        }
+        if (keep) {
+          acc = summary_merge(acc, summary_one(mm, gpv[jj]));
+          ++n_verified;
+        }
+      }
+    }
+    if (on_p) sum_p = acc;
+    if (on_m) sum_m = acc;
+  }
+}
+
 // does the reference probe seed shift seed_i when the best mismatch count so far is mm?  (mapping.cpp:248-263: never
 // again after an exact match; after a one-mismatch match only the first kExitOneMismatch shifts.)  Monotone: a larger
 // mm never needs fewer seeds, a later seed is never needed when an earlier one is not.
@@ -348,7 +462,7 @@ __device__ __forceinline__ void heavy_chunk_span(uint32_t H, uint32_t hcap, uint
   len = first < H ? (H - first < per ? H - first : per) : 0u;
 }
 
-template <int NW, bool DIAG, bool HEAVY, bool STAGED = false>
+template <int NW, bool DIAG, bool HEAVY>
 __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared& sh, const PreFilter& pf, const uint32_t* si,
                                                 const uint32_t* __restrict__ codes2, uint64_t o_first,
                                                 uint64_t o_read, uint64_t oe_read, uint32_t* __restrict__ err,
@@ -358,15 +472,13 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
                                                 uint32_t* __restrict__ defer_list, uint32_t* __restrict__ heavy_count,
                                                 uint32_t* __restrict__ heavy_list, MapCounters& ctr_out,
                                                 uint32_t& len_out, uint32_t ablate_rt, StampsT<DIAG>& st,
-                                                const HeavyStage& hs = HeavyStage(), uint32_t j = 0,
-                                                WaveList* wl_heavy = nullptr) {
-  static_assert(!STAGED || HEAVY, "the staged kernels are heavy-pass kernels");
-  if constexpr (STAGED) valid = valid && !(hs.stage && hs.flag[j]);  // gone to the literal list at an earlier stage
+                                                WaveList* wl_heavy = nullptr, const SeCarry& carry = SeCarry()) {
   const uint32_t ablate = DIAG ? ablate_rt : 0u;
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t top_step = top_step_of(n_chrom);
   MapCounters ctr = {0, 0, 0};  // this read's work; counted once, by the pass that completes the read
   bool heavy = false;
+  uint32_t heavy_seed = 0;  // pass 1: the seed shift it gives the read up at (seeds before it are complete: SeCarry)
   const uint32_t lane = threadIdx.x & 63;
   const StrandView& svp = iv.s[strand_base];
   const StrandView& svm = iv.s[strand_base + 1];
@@ -391,29 +503,13 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
 #pragma unroll 1
   for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
     RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
-    bool replay = false;
-    if constexpr (STAGED) {
-      if (seed_i > hs.stage) break;
-      replay = seed_i < hs.stage;  // a seed of an earlier stage: its summaries are in the state arrays
-    }
+    const MapCounters ctr_seed = ctr;  // (a seed pass 1 gives up at is counted by the heavy pass, which does it again)
+    const bool was_heavy = heavy;
     // '+': exact (mapping.cpp:250-257 with the state after the '+' folds so far)
     bool need_p = mappable && seed_needed(best.mismatch, seed_i);
     // '-': superset of the reference's decision (see header comment)
     const uint32_t lb = best.mismatch < minus_lb ? best.mismatch : minus_lb;
     bool need_m = mappable && seed_needed(lb, seed_i);
-    if (replay) {
-      // only what the stage of this seed computed: a read that left the stage lists early (its need was already
-      // decided by part of the summaries; more of them only lower the best) has nothing valid stored for later seeds
-      if (need_p) {
-        const uint4 a = hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j];
-        sum_p.min_mm = a.x; sum_p.count = a.y; sum_p.first = a.z; sum_p.last = a.w;
-      }
-      if (need_m) {
-        const uint4 c = hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j];
-        sum_m.min_mm = c.x; sum_m.count = c.y; sum_m.first = c.z; sum_m.last = c.w;
-      }
-    } else {
-    bool pend_p = false, pend_m = false;  // staged: the summary comes from k_se_verify
     if (ablate & 4u) need_p = need_m = false;
 
     uint32_t care[kCareWords] = {0, 0, 0, 0};
@@ -471,11 +567,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     probe_entries(svm, pm);
     Lookup lp, lm;
     bool tail_p, tail_m;
-    bool defer_p = false, defer_m = false;  // staged, long seeds: the verifier narrows the key-equal range (map_common.h DEFER)
-    if constexpr (HEAVY && STAGED && kLong && (NW <= 10)) {
-      probe_resolve_dual<true, true>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m, &defer_p, &defer_m, hs.defer_min,
-                                     win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len), kPat != 3 ? kMidRegion : 0u);
-    } else if constexpr (HEAVY) {
+    if constexpr (HEAVY) {
       probe_resolve_dual<kLong>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m);
     } else {
       bool unres_p = false, unres_m = false;  // patterns 5 / 7: a key-equal range of several slots still owes its tail characters
@@ -493,13 +585,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
     uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
     ctr.probes += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
-    // patterns 5 / 7, staged: a key-equal range of several slots whose candidates owe their tail characters (probe_resolve_dual)
-    constexpr bool kMulti = HEAVY && STAGED && kLong && kPat != 3 && NW <= 10;
-    const bool multi_p = kMulti && tail_p && size_p > 1, multi_m = kMulti && tail_m && size_m > 1;
-    bool fb_p = false, fb_m = false;    // ... one of them fails an edge filter: the range may be unsorted there, lit_region decides
-    uint32_t nin_p = 0, nin_m = 0;      // ... those whose tail characters match: the region's size for -b
-    if (size_p > b && !defer_p && !multi_p) size_p = 0;  // mapping.cpp:275-277 (a deferred range: the verifier counts the region)
-    if (size_m > b && !defer_m && !multi_m) size_m = 0;
+    if (size_p > b) size_p = 0;  // mapping.cpp:275-277
+    if (size_m > b) size_m = 0;
     if (ablate & 1u) size_p = size_m = 0;
     if (!HEAVY && (size_p > kSmallRegion || size_m > kSmallRegion)) {  // a large region: the heavy pass verifies it
       heavy = true;
@@ -528,10 +615,6 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
           const uint32_t cut = tail_care_cut(seed_i, seed_len);
           verify_nobranch_tail<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, cut, ok_p, gp_p, mm_p, t_p);
           verify_nobranch_tail<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, cut, ok_m, gp_m, mm_m, t_m);
-          fb_p = fb_p || (multi_p && act_p && !ok_p);
-          fb_m = fb_m || (multi_m && act_m && !ok_m);
-          nin_p += (multi_p && ok_p && t_p) ? 1u : 0u;
-          nin_m += (multi_m && ok_m && t_m) ? 1u : 0u;
           ok_p = ok_p && (!tail_p || t_p);
           ok_m = ok_m && (!tail_m || t_m);
         } else {
@@ -550,140 +633,25 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     }
     stamp(st, 5);
     if constexpr (HEAVY) {
-    // In a heavy wave nearly every lane owns a region of more than kSmallRegion candidates, and taking the owners
-    // one at a time costs each of them three dependent round trips however small its region is (with ~70 such
-    // regions per 64 reads that was 20 of the heavy pass's 53 ms).  So:
-    //  * a lane with a large region fetches its dense range now (two loads, all lanes together);
-    //  * regions of up to kMidRegion candidates stay with their lane: all positions in one round of loads, then
-    //    the genome windows four at a time -- five round trips for ALL such lanes of the wave;
-    //  * only the larger ones take the whole wavefront.
-    // (a deferred range -- long seeds, map_common.h DEFER -- is an item whatever its size: only the verifier can narrow it)
-    DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, (size_p > kMidRegion || defer_p) && win_usable<NW>(svp, lr.len));
-    DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, (size_m > kMidRegion || defer_m) && win_usable<NW>(svm, lr.len));
-    // mid regions: a lane usually has one, on either strand, so the strands are not taken in turn: in the first
-    // pass every lane works on its '+' mid region, or on its '-' one if it has no '+'; the second pass (skipped
-    // unless some lane has both) takes the remaining '-' ones.  All loads of a round are unconditional (idle
-    // candidates read the first words of the genome): a load under `if (candidate ok)` is waited for at the end of
-    // its branch, which made the four candidates of a round four round trips.
+    // The one-kernel heavy pass (WALT_AMD_HEAVY=mono in the diagnostic build; kept for comparison, the product path is
+    // the staged pass below): a lane with a large region fetches its dense range (two loads, all lanes together);
+    // regions of up to kMidRegion candidates stay with their lane (se_mid_regions); the larger ones take the whole
+    // wavefront, one owner at a time.
+    DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, size_p > kMidRegion && win_usable<NW>(svp, lr.len));
+    DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, size_m > kMidRegion && win_usable<NW>(svm, lr.len));
     {
-      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kMidRegion && !defer_p) ? size_p : 0u;
-      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kMidRegion && !defer_m) ? size_m : 0u;
-#pragma unroll 1
-      for (uint32_t pass = 0; pass < 2; ++pass) {
-        const bool on_m = pass == 0 ? (nmid_p == 0 && nmid_m != 0) : (nmid_p != 0 && nmid_m != 0);
-        const bool on_p = pass == 0 && nmid_p != 0;
-        const uint32_t nmid = on_p ? nmid_p : (on_m ? nmid_m : 0u);
-        if (!__ballot(nmid != 0)) continue;
-        const Ent* const ent = on_m ? svm.ent : svp.ent;
-        const uint32_t* const g2 = on_m ? svm.g2 : svp.g2;
-        const uint32_t my_l = nmid ? (on_m ? lm.reg.l : lp.reg.l) : 0u;
-        uint32_t posb[kMidRegion];
-#pragma unroll
-        for (uint32_t k = 0; k < kMidRegion; ++k) posb[k] = ent[my_l + (k < nmid ? k : 0u)].pos;
-        RegionSummary acc = summary_empty();
-#pragma unroll 1
-        for (uint32_t k0 = 0; k0 < kMidRegion; k0 += 4) {
-          if (!__ballot(k0 < nmid)) break;
-          bool ok[4];
-          uint32_t gpv[4], win[4][NW + 1];
-#pragma unroll
-          for (uint32_t jj = 0; jj < 4; ++jj) {
-            // posb[k0 + jj] by selects (k0 is not a compile-time constant: indexing would go to scratch)
-            uint32_t pos = 0;
-#pragma unroll
-            for (uint32_t k = jj; k < kMidRegion; k += 4) pos = (k == k0 + jj) ? posb[k] : pos;
-            uint32_t c_lo, c_hi;
-            if (n_chrom <= kLdsChroms) {
-              const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, pos);
-              c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
-            } else {
-              const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
-              c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
-            }
-            const uint32_t g = pos - seed_i;
-            ok[jj] = k0 + jj < nmid && (pos - c_lo >= seed_i) && (g + lr.len < c_hi);  // mapping.cpp:280-286
-            if constexpr (kMulti) {
-              if (k0 + jj < nmid && !ok[jj]) { fb_p = fb_p || (on_p && multi_p); fb_m = fb_m || (on_m && multi_m); }
-            }
-            gpv[jj] = ok[jj] ? g : 0u;
-            const uint32_t* gw = g2 + (gpv[jj] >> 4);
-#pragma unroll
-            for (int w = 0; w <= NW; w += 4) {
-              constexpr int kAll = NW + 1;
-              const int cnt = kAll - w < 4 ? kAll - w : 4;
-              uint32_t q[4] = {0, 0, 0, 0};
-              __builtin_memcpy(q, gw + w, 4 * cnt);
-#pragma unroll
-              for (int t = 0; t < cnt; ++t) win[jj][w + t] = q[t];
-            }
-          }
-#pragma unroll
-          for (uint32_t jj = 0; jj < 4; ++jj) {
-            uint32_t mm = 0;
-            bool keep = ok[jj];
-            if constexpr (kMulti) {
-              uint32_t tmm = 0;
-              count_mismatch_regs_tail<NW>(win[jj], 2 * (gpv[jj] & 15u), lr.rd, mk, seed_i, tail_care_cut(seed_i, seed_len), mm, tmm);
-              const bool mine = on_p ? multi_p : (on_m && multi_m);
-              keep = keep && (!mine || tmm == 0);
-              if (mine && keep) { if (on_p) ++nin_p; else ++nin_m; }
-            } else {
-              mm = count_mismatch_regs<NW>(win[jj], 2 * (gpv[jj] & 15u), lr.rd, mk);
-            }
-            if (keep) {
-              acc = summary_merge(acc, summary_one(mm, gpv[jj]));
-              ++ctr.verified;
-            }
-          }
-        }
-        if (on_p) sum_p = acc;
-        if (on_m) sum_m = acc;
-      }
-    }
-    if constexpr (kMulti) {
-      // the region's size is the number of candidates whose tail characters match (mapping.cpp:275-277); a range with a
-      // candidate at a chromosome's edge is narrowed the reference's way and verified one candidate after the other (rare)
-      if (multi_p && !fb_p && nin_p > b) sum_p = summary_empty();
-      if (multi_m && !fb_m && nin_m > b) sum_m = summary_empty();
-      if (__ballot(fb_p || fb_m)) {
-#pragma unroll 1
-        for (uint32_t fi = 0; fi < 2; ++fi) {
-          const bool mine = fi ? fb_m : fb_p;
-          if (!mine) continue;
-          const StrandView& sv = fi ? svm : svp;
-          const Region rg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, fi ? lm.reg.l : lp.reg.l, fi ? lm.reg.u : lp.reg.u);
-          RegionSummary acc = summary_empty();
-          if (rg.l <= rg.u && rg.u - rg.l + 1 <= b) {
-            for (uint32_t sl = rg.l; sl <= rg.u; ++sl) {
-              uint32_t gp_c, mm_c;
-              if (verify_candidate<NW>(sv, si, n_chrom, sv.ent[sl].pos, seed_i, lr.len, lr.rd, mk, gp_c, mm_c))
-                acc = summary_merge(acc, summary_one(mm_c, gp_c));
-            }
-          }
-          if (fi) sum_m = acc; else sum_p = acc;
-        }
-      }
-    }
-    if constexpr (STAGED) {  // both strands' large regions become work items: one atomic for the two (map_items.h item_append2)
-      const bool big2[2] = {size_p > kMidRegion || defer_p, size_m > kMidRegion || defer_m};
-      const bool dense2[2] = {big2[0] && dr_p.hi > dr_p.lo, big2[1] && dr_m.hi > dr_m.lo};
-      const uint32_t id2[2] = {j, j | (1u << 31)}, l2[2] = {lp.reg.l, lm.reg.l}, size2[2] = {size_p, size_m};
-      const uint32_t rec2[2] = {dense2[0] ? (uint32_t)dr_p.rec : kItemDenseNone, dense2[1] ? (uint32_t)dr_m.rec : kItemDenseNone};
-      ItemQueue q;
-      q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
-      q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
-      const bool tail2[2] = {defer_p, defer_m};
-      item_append2<NW>(big2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, q, tail2);
-      if (big2[0]) { ++ctr.big; pend_p = true; }
-      if (big2[1]) { ++ctr.big; pend_m = true; }
+      const uint32_t nmid_p = (size_p > kSmallRegion && size_p <= kMidRegion) ? size_p : 0u;
+      const uint32_t nmid_m = (size_m > kSmallRegion && size_m <= kMidRegion) ? size_m : 0u;
+      MidTail none;
+      se_mid_regions<NW, false>(iv, sh, svp, svm, nmid_p, nmid_m, lp.reg.l, lm.reg.l, seed_i, lr.len, lr.rd, mk, n_chrom, top_step,
+                                0u, none, sum_p, sum_m, ctr.verified);
     }
 #pragma unroll 1
     for (uint32_t fi = 0; fi < 2; ++fi) {
-      if constexpr (STAGED) break;
       const StrandView& sv = fi ? svm : svp;
       const uint32_t my_size = fi ? size_m : size_p;
       const uint32_t my_l = fi ? lm.reg.l : lp.reg.l;
-      unsigned long long big = STAGED ? 0ull : __ballot(my_size > kMidRegion);
+      unsigned long long big = __ballot(my_size > kMidRegion);
       while (big) {
         const int owner = (int)__ffsll((long long)big) - 1;
         big &= big - 1;
@@ -709,24 +677,29 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     }
     }
     stamp(st, 6);
-    if constexpr (STAGED) {
-      // this stage's summaries: what the lane worked out itself now, the items' when k_se_verify has run
-      if (valid && !pend_p) hs.sums[(uint64_t)(2 * seed_i) * hs.hcap + j] = make_uint4(sum_p.min_mm, sum_p.count, sum_p.first, sum_p.last);
-      if (valid && !pend_m) hs.sums[(uint64_t)(2 * seed_i + 1) * hs.hcap + j] = make_uint4(sum_m.min_mm, sum_m.count, sum_m.first, sum_m.last);
-      if (seed_i + 1 < kPat) {
-        // the next seed is probed on '+' while the best of the '+' strand asks for it (seed_needed, mapping.cpp:250-257),
-        // and never on '-' otherwise (the '-' bound is at most the '+' best); pending summaries can only lower it
-        const uint32_t known = (!pend_p && sum_p.count && sum_p.min_mm < best.mismatch) ? sum_p.min_mm : best.mismatch;
-        wavelist_append(*wl_heavy, mappable && seed_needed(known, seed_i + 1), j, &hs.ctl[4], hs.list_out);  // (the staged kernels' use of the buffer)
-      }
-      break;
+    if (!HEAVY && heavy && !was_heavy) {  // given up at this seed: the seeds before it are what pass 1 hands over
+      heavy_seed = seed_i;
+      ctr = ctr_seed;
     }
-    }  // !replay
     fold_region(best, sum_p, '+');  // empty when the '+' probe was not needed
 #pragma unroll
     for (uint32_t k = 0; k < kPat; ++k)  // (selects: an index into the array would send it to scratch)
       if (seed_i == k) mneg[k] = sum_m;
     if (sum_m.count && sum_m.min_mm < minus_lb) minus_lb = sum_m.min_mm;
+  }
+  if constexpr (!HEAVY) {
+    // a read given to the heavy pass: its state after the seeds pass 1 completed (best: '+' folds only; the '-' summaries
+    // wait for the end as they do here) -- the staged rounds go on from there (SeCarry)
+    if (heavy && !deferred && carry.st != nullptr) {
+      carry.st[r] = make_uint4(best.genome_pos, best.times, best.mismatch, minus_lb);
+#pragma unroll
+      for (uint32_t k = 0; k + 1 < kPat; ++k)
+        if (k < heavy_seed) carry.neg[k * carry.stride + r] = make_uint4(mneg[k].min_mm, mneg[k].count, mneg[k].first, mneg[k].last);
+    }
+    const bool carried = heavy && !deferred && carry.st != nullptr;
+    // (only '+' folds have reached `best` here, so its strand is '+': nothing more to hand over)
+    wavelist_append(*wl_heavy, heavy && !deferred, heavy_entry(r, carried ? heavy_seed : 0u), heavy_count, heavy_list);  // (buffered: map_common.h WaveList)
+    if (carried) { ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big; }
   }
   // '-' strand folds in reference order under the exact exit conditions
   {
@@ -738,16 +711,8 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
     }
   }
   wave_append(deferred, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, defer_count, defer_list);
-  if constexpr (!HEAVY) wavelist_append(*wl_heavy, heavy && !deferred, r, heavy_count, heavy_list);  // (buffered: map_common.h WaveList)
-  if constexpr (STAGED) {
-    if (hs.stage == 0 ? valid || deferred : deferred) hs.flag[j] = deferred ? 1u : 0u;
-    if (hs.stage == kPat && valid) out[r] = best;
-    // the stage's own work (the literal pass counts a deferred read's again: these counters are diagnostic)
-    ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big;
-  } else {
-    if (!deferred && !heavy && valid) out[r] = best;
-    if (!deferred && !heavy) { ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big; }
-  }
+  if (!deferred && !heavy && valid) out[r] = best;
+  if (!deferred && !heavy) { ctr_out.probes += ctr.probes; ctr_out.verified += ctr.verified; ctr_out.big += ctr.big; }
   stamp(st, 7);
 }
 
@@ -854,9 +819,9 @@ void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_sta
   hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(kStatShards), 0, stream, d_shards, d_stats);
 }
 
-// pass 1: every read of the batch, one per lane (HEAVY = false); pass 1b: the reads of the heavy list (HEAVY = true)
-template <int NW, bool DIAG, bool HEAVY, bool STAGED = false, int OCC = 0>  // OCC: wavefronts per SIMD the registers are capped for (0: the default below)
-__global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 : 3) : (NW <= 10 ? (STAGED ? 3 : 2) : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
+// pass 1: every read of the batch, one per lane (HEAVY = false); the one-kernel heavy pass over the heavy list (HEAVY = true)
+template <int NW, bool DIAG, bool HEAVY>
+__global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_map_se(IndexView iv, const uint32_t* __restrict__ codes2,
                                                     const uint64_t* __restrict__ offsets,
                                                     uint32_t* __restrict__ err,
                                                     uint32_t n_all, uint32_t strand_base,
@@ -869,26 +834,15 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 
                                                     uint32_t* __restrict__ heavy_count,
                                                     uint32_t* __restrict__ heavy_list, uint32_t ablate,
                                                     unsigned long long* __restrict__ stamps,
-                                                    HeavyStage hs = HeavyStage()) {
-  uint32_t n = HEAVY ? *heavy_count : n_all;
-  uint32_t h_first = 0;
-  if constexpr (STAGED) {  // this chunk of the heavy list, or what the previous stage left of it
-    if (hs.even) {
-      heavy_chunk_span(n, hs.hcap, hs.chunk, h_first, n);
-    } else {
-      h_first = hs.first;
-      n = n > hs.first ? n - hs.first : 0u;
-      n = n < hs.hcap ? n : hs.hcap;
-    }
-    if (hs.list_in) n = hs.count_in[4];
-  }
+                                                    SeCarry carry = SeCarry()) {
+  const uint32_t n = HEAVY ? *heavy_count : n_all;
   if (HEAVY && n == 0) return;
   __shared__ BlockShared sh;
   __shared__ PreFilter pf;
-  // per-wavefront list buffers: pass 1's heavy list; a stage kernel's list of the reads that go on to the next stage
-  __shared__ uint32_t s_wl[(HEAVY && !STAGED) ? 1 : (kBlock / 64) * kWaveBuf];
+  // per-wavefront list buffers of pass 1's heavy list
+  __shared__ uint32_t s_wl[HEAVY ? 1 : (kBlock / 64) * kWaveBuf];
   WaveList wl_heavy;
-  wl_heavy.buf = s_wl + ((HEAVY && !STAGED) ? 0 : (threadIdx.x >> 6) * kWaveBuf);
+  wl_heavy.buf = s_wl + (HEAVY ? 0 : (threadIdx.x >> 6) * kWaveBuf);
   wl_heavy.n = 0;
   wl_heavy.cap = kWaveBuf;
   prefilter_stage(pf, iv, strand_base);
@@ -908,14 +862,9 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 
   const uint64_t o_first = offsets[0];
   // this lane's read offsets are fetched one chunk ahead
   uint64_t o_nx = 0, oe_nx = 0;
-  uint32_t r_nx = 0, j_nx = 0;
+  uint32_t r_nx = 0;
   auto fetch = [&](uint64_t i) {
-    if constexpr (STAGED) {
-      j_nx = hs.list_in ? hs.list_in[i] : (uint32_t)i;
-      r_nx = heavy_list[h_first + j_nx];
-    } else {
-      r_nx = HEAVY ? heavy_list[i] : (uint32_t)i;
-    }
+    r_nx = HEAVY ? (heavy_list[i] & kDeferMask) : (uint32_t)i;  // (heavy_entry: the seed pass 1 stopped at rides on top)
     o_nx = offsets[r_nx];
     oe_nx = offsets[(uint64_t)r_nx + 1];
   };
@@ -923,20 +872,346 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : HEAVY ? (NW <= 8 ? (STAGED ? 4 
   for (uint64_t c = c_lo; c < c_hi; ++c) {
     const uint64_t i64 = c * blockDim.x + threadIdx.x;
     const bool valid = i64 < n;
-    const uint32_t r = valid ? r_nx : 0, j_cur = j_nx;
+    const uint32_t r = valid ? r_nx : 0;
     const uint64_t o_cur = o_nx, oe_cur = oe_nx;
     if (c + 1 < c_hi && i64 + blockDim.x < n) fetch(i64 + blockDim.x);
     uint32_t len;
-    se_process_dual<NW, DIAG, HEAVY, STAGED>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
-                                             out, defer_count, defer_list, heavy_count, heavy_list, ctr, len, ablate, st, hs,
-                                             j_cur, &wl_heavy);
+    se_process_dual<NW, DIAG, HEAVY>(iv, sh, pf, si, codes2, o_first, o_cur, oe_cur, err, r, valid, strand_base, max_mm, b,
+                                     out, defer_count, defer_list, heavy_count, heavy_list, ctr, len, ablate, st, &wl_heavy, carry);
     // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 sees every read
     if (!HEAVY) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
   if constexpr (!HEAVY) wavelist_flush(wl_heavy, heavy_count, heavy_list);
-  if constexpr (STAGED) { if (hs.list_out != nullptr) wavelist_flush(wl_heavy, &hs.ctl[4], hs.list_out); }
   stamp_end(st);
   flush_counters(ctr, shortv, stats);
+}
+
+// ---------------------------------------------------------------------------
+// k_se_stage: one ROUND of the staged heavy pass over one chunk of the heavy list (HeavyStage).  One read per lane;
+// a lane runs its seed shifts until a probe produces a work item, a dangerous probe sends the read to the literal list,
+// or the read is finished.  What the seed loop does per seed is what pass 1 does, with long slots searched (both
+// strands together: map_common.h probe_resolve_dual) and regions of up to kMidRegion candidates verified in the lane.
+// ---------------------------------------------------------------------------
+template <int NW, int OCC = 0>  // OCC: wavefronts per SIMD the registers are capped for (0: the default)
+__global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_se_stage(
+    IndexView iv, const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
+    uint32_t strand_base, uint32_t max_mm, uint32_t b, const uint32_t* __restrict__ mask_table, BestMatch* __restrict__ out,
+    unsigned long long* __restrict__ stats, uint32_t* __restrict__ defer_count, uint32_t* __restrict__ defer_list,
+    const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list, HeavyStage hs, SeCarry carry) {
+  uint32_t n = *heavy_count, h_first = 0;
+  if (hs.even) {
+    heavy_chunk_span(n, hs.hcap, hs.chunk, h_first, n);
+  } else {
+    h_first = hs.first;
+    n = n > hs.first ? n - hs.first : 0u;
+    n = n < hs.hcap ? n : hs.hcap;
+  }
+  if (hs.round) n = hs.count_in[4] < hs.hcap ? hs.count_in[4] : hs.hcap;
+  if (n == 0) return;
+  __shared__ BlockShared sh;
+  __shared__ PreFilter pf;
+  __shared__ uint32_t s_wl[(kBlock / 64) * kWaveBuf];  // per-wavefront buffers of the next round's list
+  WaveList wl;
+  wl.buf = s_wl + (threadIdx.x >> 6) * kWaveBuf;
+  wl.n = 0;
+  wl.cap = kWaveBuf;
+  prefilter_stage(pf, iv, strand_base);
+  const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
+  constexpr uint32_t RQ = rd_quads<NW>();
+  constexpr bool kLong = long_seed_nw<NW>();                    // seeds of more than the 44 characters of hash + key exist
+  constexpr bool kDefer = kLong && NW <= 10;                    // ... and the verifier narrows their key-equal ranges (section 4b)
+  constexpr bool kMulti = kLong && kPat != 3 && NW <= 10;       // patterns 5 / 7: short key-equal ranges verified side by side in the lane
+  const uint32_t n_chrom = iv.n_chrom, top_step = top_step_of(n_chrom);
+  const StrandView& svp = iv.s[strand_base];
+  const StrandView& svm = iv.s[strand_base + 1];
+  const uint32_t ga = strand_base >> 1, Bd = iv.dir_bits;
+  const uint64_t hcap = hs.hcap;
+  heavy_list += h_first;
+  MapCounters ctr = {0, 0, 0};
+  ItemQueue q;
+  q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap; q.ovf = err + 2;
+  q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
+  const uint64_t chunks = ((uint64_t)n + blockDim.x - 1) / blockDim.x;
+  const uint64_t per_block = (chunks + gridDim.x - 1) / gridDim.x;
+  const uint64_t c_lo = (uint64_t)blockIdx.x * per_block;
+  const uint64_t c_hi = c_lo + per_block < chunks ? c_lo + per_block : chunks;
+  const uint64_t o_first = offsets[0];
+  // fetched one chunk ahead: round 0: the heavy-list entry and the read's offsets; later rounds: the list entry
+  uint32_t e_nx = 0;
+  uint64_t o_nx = 0, oe_nx = 0;
+  auto fetch = [&](uint64_t i) {
+    if (hs.round == 0) {
+      e_nx = heavy_list[i];
+      const uint32_t r = e_nx & kDeferMask;
+      o_nx = offsets[r];
+      oe_nx = offsets[(uint64_t)r + 1];
+    } else {
+      e_nx = hs.list_in[i];
+    }
+  };
+  if (c_lo < c_hi && c_lo * blockDim.x + threadIdx.x < n) fetch(c_lo * blockDim.x + threadIdx.x);
+  for (uint64_t c = c_lo; c < c_hi; ++c) {
+    const uint64_t i64 = c * blockDim.x + threadIdx.x;
+    const bool valid = i64 < n;
+    const uint32_t e_cur = e_nx;
+    const uint64_t o_cur = o_nx, oe_cur = oe_nx;
+    if (c + 1 < c_hi && i64 + blockDim.x < n) fetch(i64 + blockDim.x);
+
+    // ---- this lane's read and its state
+    LaneRead<NW> lr;
+    BestMatch best;  // mapping.cpp:486; only '+' folds reach it before the end, so its strand is '+' throughout
+    best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
+    uint32_t minus_lb = 0xFFFFFFFFu;  // smallest mismatch count any kept '-' summary holds
+    uint32_t j = 0, r = 0, seed_i = 0;
+    if (hs.round == 0) {
+      j = (uint32_t)i64;
+      r = valid ? e_cur & kDeferMask : 0u;
+      lane_load_read<NW>(lr, codes2, o_first, o_cur, oe_cur, valid, ga, err, iv);
+      if (valid) {
+        if (carry.st != nullptr) {  // (uniform) what pass 1 worked out before it gave the read up
+          seed_i = (e_cur >> kHeavySeedShift) & 7u;
+          const uint4 cs = load_global(carry.st + r);
+          uint4 ng[kPat > 1 ? kPat - 1 : 1];
+#pragma unroll
+          for (uint32_t k = 0; k + 1 < kPat; ++k)
+            if (k < seed_i) ng[k] = load_global(carry.neg + k * carry.stride + r);
+          best.genome_pos = cs.x; best.times = cs.y; best.mismatch = cs.z;
+          minus_lb = cs.w;
+#pragma unroll
+          for (uint32_t k = 0; k + 1 < kPat; ++k)
+            if (k < seed_i) hs.sums[(uint64_t)(1 + k) * hcap + j] = ng[k];
+        }
+        uint32_t w[4 * RQ];
+#pragma unroll
+        for (uint32_t t = 0; t < 4 * RQ; ++t) w[t] = t == 0 ? lr.len : (t <= (uint32_t)NW ? lr.rd[t - 1] : 0u);
+#pragma unroll
+        for (uint32_t t = 0; t < RQ; ++t) hs.rdq[(uint64_t)t * hcap + j] = make_uint4(w[4 * t], w[4 * t + 1], w[4 * t + 2], w[4 * t + 3]);
+      }
+    } else {
+      lr.len = 0; lr.repeats = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) lr.rd[w] = 0;
+      if (valid) {  // everything by j: one round of loads
+        j = e_cur & ((1u << kStageJBits) - 1u);
+        const uint32_t s_blocked = (e_cur >> kStageJBits) & 7u;
+        const uint32_t he = heavy_list[j];
+        const uint4 stv = load_global(hs.st + j);
+        const uint4 sp = load_global(hs.sums + j), sm = load_global(hs.sums + (uint64_t)(1 + s_blocked) * hcap + j);
+        uint4 rq[RQ];
+#pragma unroll
+        for (uint32_t t = 0; t < RQ; ++t) rq[t] = load_global(hs.rdq + (uint64_t)t * hcap + j);
+        r = he & kDeferMask;
+        uint32_t w[4 * RQ];
+#pragma unroll
+        for (uint32_t t = 0; t < RQ; ++t) { w[4 * t] = rq[t].x; w[4 * t + 1] = rq[t].y; w[4 * t + 2] = rq[t].z; w[4 * t + 3] = rq[t].w; }
+        lr.len = w[0];
+        lr.repeats = lr.len >= kMinReadLen ? seed_repeats(lr.len) : 0;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) lr.rd[t] = w[t + 1];
+        best.genome_pos = stv.x; best.times = stv.y; best.mismatch = stv.z;
+        minus_lb = stv.w;
+        // the seed the read was blocked at: its '+' summary (the lane's own, or the verifier's) is folded now, its '-'
+        // summary stays in its row for the end and counts for the '-' bound (mapping.cpp:306-313, 250-257)
+        RegionSummary a; a.min_mm = sp.x; a.count = sp.y; a.first = sp.z; a.last = sp.w;
+        fold_region(best, a, '+');
+        if (sm.y && sm.x < minus_lb) minus_lb = sm.x;
+        seed_i = s_blocked + 1;
+      }
+    }
+    const uint32_t seed_len = seed_len_of(lr.repeats);
+    bool active = valid && lr.len >= kMinReadLen && seed_i < kPat;
+    bool fin = valid && !active;  // finished: the '-' folds and the record are left (seed_i = seeds that have been done)
+    bool deferred = false;
+    uint32_t defer_iter = 0;
+
+    // ---- seed shifts, until blocked (a lane's seed_i is its own)
+    while (__ballot(active)) {
+      // '+': exact (mapping.cpp:250-257 with the state after the '+' folds so far); '-': a superset of the reference's
+      // decision (se_process_dual's header comment).  Monotone in the seed: when neither is needed, nothing later is.
+      bool need_p = active && seed_needed(best.mismatch, seed_i);
+      const uint32_t lb = best.mismatch < minus_lb ? best.mismatch : minus_lb;
+      bool need_m = active && seed_needed(lb, seed_i);
+      if (active && !need_p && !need_m) { fin = true; active = false; }
+      if (!__ballot(active)) break;
+      const uint32_t sd = active ? seed_i : 0u;  // (an idle lane computes along on seed 0)
+      RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
+      bool pend_p = false, pend_m = false;  // the summary comes from k_se_verify
+
+      uint32_t care[kCareWords] = {0, 0, 0, 0};
+      uint32_t slot = 0, span = 0;
+      if (need_p || need_m) seed_query<NW>(lr.rd, seed_len, sd, ga, Bd, sh.pcode4, care, slot, span);
+      // Bloom blocks of both strands and the directory pairs of both strands: independent loads, one wait
+      const uint32_t bkey = bloom_key_of_care(care);
+      uint64_t bw_p = 0, bw_m = 0;
+      if (need_p && prefilter_hit(pf, 0, bkey)) bw_p = svp.bloom[bloom_block(bkey, svp.bloom_mask)];
+      if (need_m && prefilter_hit(pf, 1, bkey)) bw_m = svm.bloom[bloom_block(bkey, svm.bloom_mask)];
+      SlotProbe pp, pm;
+      uint32_t hi_p, hi_m;
+      probe_issue(svp, need_p, slot, span, pp, hi_p);
+      probe_issue(svm, need_m, slot, span, pm, hi_m);
+      const bool bad_p = need_p && bw_p && danger_filter_hit(bw_p, care);
+      const bool bad_m = need_m && bw_m && danger_filter_hit(bw_m, care);
+      if (bad_p || bad_m) {  // a filter hit is a superset of the dangerous probes: the exact test
+        const bool dng_p = bad_p && probe_is_dangerous(svp, care, seed_len);
+        const bool dng_m = bad_m && probe_is_dangerous(svm, care, seed_len);
+        if (dng_p || dng_m) {  // the literal pass maps the read from scratch
+          deferred = true;
+          active = false;
+          need_p = need_m = false;
+          defer_iter = sd + (dng_p ? 0u : kPat);  // (grouping only: map_common.h kDeferShift)
+          defer_iter = defer_iter < 7u ? defer_iter : 7u;
+        }
+      }
+      pp.ne = (need_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
+      pm.ne = (need_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
+      probe_entries(svp, pp);
+      probe_entries(svm, pm);
+      Lookup lp, lm;
+      bool tail_p, tail_m;
+      bool defer_p = false, defer_m = false;  // long seeds: the verifier narrows the key-equal range (map_common.h DEFER)
+      if constexpr (kDefer) {
+        probe_resolve_dual<true, true>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m, &defer_p, &defer_m, hs.defer_min,
+                                       win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len), kPat != 3 ? kMidRegion : 0u);
+      } else {
+        probe_resolve_dual<kLong>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m);
+      }
+      uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
+      uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
+      ctr.probes += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
+      // patterns 5 / 7: a key-equal range of several slots whose candidates owe their tail characters (probe_resolve_dual)
+      MidTail mt;
+      mt.multi_p = kMulti && tail_p && size_p > 1;
+      mt.multi_m = kMulti && tail_m && size_m > 1;
+      if (size_p > b && !defer_p && !mt.multi_p) size_p = 0;  // mapping.cpp:275-277 (a deferred range: the verifier counts the region)
+      if (size_m > b && !defer_m && !mt.multi_m) size_m = 0;
+      uint32_t mk[NW];
+      make_masks<NW>(mk, sh.mask_table, sd, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
+      const uint32_t tail_cut = tail_care_cut(sd, seed_len);
+
+      // small regions: candidate k of both strands checked side by side
+      const bool small_p = size_p && size_p <= kSmallRegion, small_m = size_m && size_m <= kSmallRegion;
+      if (__ballot(small_p || small_m)) {
+        const uint32_t kmax = (small_p ? size_p : 0u) > (small_m ? size_m : 0u) ? size_p : (small_m ? size_m : 0u);
+#pragma unroll 1
+        for (uint32_t k = 0; __ballot(k < kmax); ++k) {  // rolled (code size); pos[] picked by selects, not indexing
+          const bool act_p = small_p && k < size_p, act_m = small_m && k < size_m;
+          uint32_t pos_p = k == 0 ? lp.pos[0] : k == 1 ? lp.pos[1] : k == 2 ? lp.pos[2] : lp.pos[3];
+          uint32_t pos_m = k == 0 ? lm.pos[0] : k == 1 ? lm.pos[1] : k == 2 ? lm.pos[2] : lm.pos[3];
+          if (act_p && k >= lp.npos) pos_p = svp.ent[lp.reg.l + k].pos;
+          if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
+          bool ok_p, ok_m;
+          uint32_t gp_p, gp_m, mm_p, mm_m;
+          if constexpr (kLong && kPat != 3) {  // long seeds: a key-equal candidate still owes its care chars >= 44 (probe_resolve)
+            bool t_p, t_m;
+            verify_nobranch_tail<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, sd, lr.len, lr.rd, mk, tail_cut, ok_p, gp_p, mm_p, t_p);
+            verify_nobranch_tail<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, sd, lr.len, lr.rd, mk, tail_cut, ok_m, gp_m, mm_m, t_m);
+            mt.fb_p = mt.fb_p || (mt.multi_p && act_p && !ok_p);
+            mt.fb_m = mt.fb_m || (mt.multi_m && act_m && !ok_m);
+            mt.nin_p += (mt.multi_p && ok_p && t_p) ? 1u : 0u;
+            mt.nin_m += (mt.multi_m && ok_m && t_m) ? 1u : 0u;
+            ok_p = ok_p && (!tail_p || t_p);
+            ok_m = ok_m && (!tail_m || t_m);
+          } else {
+            verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, sd, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+            verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, sd, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+            if (kLong) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
+              // inactive lanes carry no valid position: read from 0 like verify_nobranch does
+              const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, seed_len), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, seed_len);
+              ok_p = ok_p && (!tail_p || t_p);
+              ok_m = ok_m && (!tail_m || t_m);
+            }
+          }
+          if (ok_p) { sum_p = summary_merge(sum_p, summary_one(mm_p, gp_p)); ++ctr.verified; }
+          if (ok_m) { sum_m = summary_merge(sum_m, summary_one(mm_m, gp_m)); ++ctr.verified; }
+        }
+      }
+      // larger regions: the dense range of those that become items (two loads, all lanes together); regions of up to
+      // kMidRegion candidates stay with their lane (a deferred range -- long seeds -- is an item whatever its size: only
+      // the verifier can narrow it)
+      const bool big_p = size_p > kMidRegion || defer_p, big_m = size_m > kMidRegion || defer_m;
+      const DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, big_p && win_usable<NW>(svp, lr.len));
+      const DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, big_m && win_usable<NW>(svm, lr.len));
+      {
+        const uint32_t nmid_p = (size_p > kSmallRegion && !big_p) ? size_p : 0u;
+        const uint32_t nmid_m = (size_m > kSmallRegion && !big_m) ? size_m : 0u;
+        if (__ballot(nmid_p | nmid_m))
+          se_mid_regions<NW, kMulti>(iv, sh, svp, svm, nmid_p, nmid_m, lp.reg.l, lm.reg.l, sd, lr.len, lr.rd, mk, n_chrom, top_step,
+                                     tail_cut, mt, sum_p, sum_m, ctr.verified);
+      }
+      if constexpr (kMulti) {
+        // the region's size is the number of candidates whose tail characters match (mapping.cpp:275-277); a range with a
+        // candidate at a chromosome's edge is narrowed the reference's way and verified one candidate after the other (rare)
+        if (mt.multi_p && !mt.fb_p && mt.nin_p > b) sum_p = summary_empty();
+        if (mt.multi_m && !mt.fb_m && mt.nin_m > b) sum_m = summary_empty();
+        if (__ballot(mt.fb_p || mt.fb_m)) {
+#pragma unroll 1
+          for (uint32_t fi = 0; fi < 2; ++fi) {
+            const bool mine = fi ? mt.fb_m : mt.fb_p;
+            if (!mine) continue;
+            const StrandView& sv = fi ? svm : svp;
+            const Region rg = lit_region(sv, care, kKeyWeight + kKeyChars, seed_len, fi ? lm.reg.l : lp.reg.l, fi ? lm.reg.u : lp.reg.u);
+            RegionSummary acc = summary_empty();
+            if (rg.l <= rg.u && rg.u - rg.l + 1 <= b) {
+              for (uint32_t sl = rg.l; sl <= rg.u; ++sl) {
+                uint32_t gp_c, mm_c;
+                if (verify_candidate<NW>(sv, si, n_chrom, sv.ent[sl].pos, sd, lr.len, lr.rd, mk, gp_c, mm_c))
+                  acc = summary_merge(acc, summary_one(mm_c, gp_c));
+              }
+            }
+            if (fi) sum_m = acc; else sum_p = acc;
+          }
+        }
+      }
+      if (__ballot(big_p || big_m)) {  // both strands' large regions become work items: one atomic for the two (map_items.h item_append2)
+        const bool big2[2] = {big_p, big_m};
+        const bool dense2[2] = {big_p && dr_p.hi > dr_p.lo, big_m && dr_m.hi > dr_m.lo};
+        const uint32_t id2[2] = {j, j | (1u << 31)}, l2[2] = {lp.reg.l, lm.reg.l}, size2[2] = {size_p, size_m};
+        const uint32_t rec2[2] = {dense2[0] ? (uint32_t)dr_p.rec : kItemDenseNone, dense2[1] ? (uint32_t)dr_m.rec : kItemDenseNone};
+        const bool tail2[2] = {defer_p, defer_m};
+        item_append2<NW>(big2, dense2, id2, l2, size2, rec2, lr.len, sd, lr.rd, mk, q, tail2);
+        if (big_p) { ++ctr.big; pend_p = true; }
+        if (big_m) { ++ctr.big; pend_m = true; }
+      }
+      // ---- the seed is done, or the read waits for the verifier
+      bool blocked = false;
+      if (active) {
+        // this seed's '-' summary: the lane's own now, an item's when k_se_verify has run
+        if (!pend_m) hs.sums[(uint64_t)(1 + seed_i) * hcap + j] = make_uint4(sum_m.min_mm, sum_m.count, sum_m.first, sum_m.last);
+        if (pend_p || pend_m) {
+          if (!pend_p) hs.sums[j] = make_uint4(sum_p.min_mm, sum_p.count, sum_p.first, sum_p.last);
+          hs.st[j] = make_uint4(best.genome_pos, best.times, best.mismatch, minus_lb);
+          blocked = true;
+          active = false;
+        } else {
+          fold_region(best, sum_p, '+');  // empty when the '+' probe was not needed
+          if (sum_m.count && sum_m.min_mm < minus_lb) minus_lb = sum_m.min_mm;
+          ++seed_i;
+          if (seed_i == kPat) { fin = true; active = false; }
+        }
+      }
+      wavelist_append(wl, blocked, stage_entry(j, seed_i), &hs.ctl[4], hs.list_out);
+    }
+    wave_append(deferred, r | (defer_iter << kDeferShift), defer_count, defer_list);
+    // ---- finished reads: the '-' strand's summaries folded in reference order under the exact exit conditions
+    if (__ballot(fin)) {
+      uint4 ng[kPat];
+#pragma unroll
+      for (uint32_t k = 0; k < kPat; ++k) {
+        ng[k] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        if (fin && k < seed_i) ng[k] = load_global(hs.sums + (uint64_t)(1 + k) * hcap + j);
+      }
+      bool go = true;
+#pragma unroll
+      for (uint32_t k = 0; k < kPat; ++k) {
+        go = go && seed_needed(best.mismatch, k);
+        RegionSummary a; a.min_mm = ng[k].x; a.count = ng[k].y; a.first = ng[k].z; a.last = ng[k].w;
+        if (go) fold_region(best, a, '-');
+      }
+      if (fin) out[r] = best;
+    }
+  }
+  if (hs.list_out != nullptr) wavelist_flush(wl, &hs.ctl[4], hs.list_out);
+  flush_counters(ctr, 0u, stats);
 }
 
 // ---------------------------------------------------------------------------
@@ -967,7 +1242,8 @@ __device__ __forceinline__ uint4 lane_best_reduce(const LaneBest& a) {
   const unsigned long long fm = __ballot(eq && a.f_k == fk), lm = __ballot(eq && a.l_k == lk);
   return make_uint4(mn, cnt, bcast(a.f_gp, (int)__ffsll((long long)fm) - 1), bcast(a.l_gp, (int)__ffsll((long long)lm) - 1));
 }
-// item id = chunk position j | strand << 31; the summary goes to sums[(2 * seed + strand) * hcap + j]
+// item id = chunk position j | strand << 31; the summary goes to row 0 ('+': the seed the read is blocked at) or row
+// 1 + seed ('-') of HeavyStage::sums
 struct SummarySink {
   uint4* sums;
   uint32_t hcap;
@@ -991,7 +1267,7 @@ struct SummarySink {
   __device__ __forceinline__ void end() {
     uint4 res = lane_best_reduce(acc);
     if (tail && wave_sum_u32(in_region) > b) res = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // (uniform) the narrowed region exceeds -b
-    if ((threadIdx.x & 63) == 0) sums[(uint64_t)(2 * seed_i + (id >> 31)) * hcap + (id & 0x7FFFFFFFu)] = res;
+    if ((threadIdx.x & 63) == 0) sums[(uint64_t)((id >> 31) ? 1u + seed_i : 0u) * hcap + (id & 0x7FFFFFFFu)] = res;
   }
 };
 
@@ -1000,7 +1276,7 @@ template <int NW>
 __global__ __launch_bounds__(kBlock) void k_se_tail_narrow(IndexView iv, uint32_t strand_base, HeavyStage hs, uint32_t b) {
   if constexpr (NW <= 10 && long_seed_nw<NW>()) {
     ItemQueue q;
-    q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
+    q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap; q.ovf = nullptr;
     q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
     uint32_t n_big = *q.big_n;
     n_big = n_big < q.big_cap ? n_big : q.big_cap;
@@ -1013,11 +1289,12 @@ __global__ __launch_bounds__(kBlock) void k_se_tail_narrow(IndexView iv, uint32_
 
 template <int NW, bool DENSE, int G = 1>
 __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : (NW <= 10 ? 2 : 1))) void k_se_verify(
-    IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs, uint32_t b) {
+    IndexView iv, uint32_t strand_base, unsigned long long* __restrict__ stats, HeavyStage hs, uint32_t b, uint32_t* __restrict__ err) {
   static_assert(item_quads<NW>() <= 64, "an item header is fetched by one wavefront load");
   ItemQueue q;
-  q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap;
+  q.items = hs.items; q.ctl = hs.ctl; q.cap = 2 * hs.hcap; q.ovf = err + 2;
   q.bigs = hs.giants; q.big_n = hs.ctl + 5; q.big_cap = hs.hcap / 8;
+  if (DENSE && blockIdx.x == 0 && threadIdx.x == 0) items_overflow_check(q);
   uint32_t n_big = DENSE ? *q.big_n : 0u;
   n_big = n_big < q.big_cap ? n_big : q.big_cap;
   const uint32_t n_items = q.ctl[DENSE ? 0 : 1] + n_big;
@@ -1086,67 +1363,89 @@ __global__ __launch_bounds__(kBlock, NW <= 8 ? 5 : 1) void k_map_se_literal(Inde
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
-// staged heavy pass: reads per chunk of the heavy list and the bytes of its state behind the dense read array:
-// [control words] then per state slot [flag][kPat - 1 stage lists][2 kPat summaries][2 x 2 item words][giants].
-// Round 3: the list is mapped in two halves on two streams (launch_map_se), each with its own state slot: chunks of an
-// eighth of the batch (the heavy reads of an hg19-like genome, a sixth of all, make one chunk per half), cut evenly on
-// the device (heavy_chunk_span).  WALT_AMD_SE_PIPE=0: one stream, one slot, chunks of a quarter (rounds 2's schedule).
-constexpr uint32_t kHeavyCtlWords = 64 * kPat + 64;  // 8 words per (chunk, stage): up to 8 chunks x kPat stages; then the literal side launch's 64
-static int se_pipe_mode() {
-  static const int mode = [] { const char* e = getenv("WALT_AMD_SE_PIPE"); return e ? atoi(e) : 1; }();
-  return mode;
-}
-static uint32_t se_heavy_chunk(uint32_t n) {
-  const uint64_t share = ((uint64_t)n + (se_pipe_mode() ? 7 : 3)) / (se_pipe_mode() ? 8 : 4);
-  if (const char* e = getenv("WALT_AMD_HEAVY_CHUNK")) {  // test hook: several chunks on a small batch (at most 8 are made)
-    const uint64_t v = (uint64_t)atol(e);
-    if (v * 8 >= n && v > 0) return (uint32_t)align_up(v, 64);
-  }
-  return (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (share > 65536 ? share : 65536), 64);
-}
-static uint32_t se_heavy_chunks(uint32_t n) {  // <= 8
-  const uint32_t hcap = se_heavy_chunk(n);
-  return (uint32_t)(((uint64_t)n + hcap - 1) / hcap);
-}
-static bool se_heavy_piped(uint32_t n) { return se_pipe_mode() != 0 && se_heavy_chunks(n) > 1; }
+// Staged heavy pass: reads per chunk of the heavy list and the bytes of its state behind the dense read array:
+// [control words] then per state slot [kPat round lists][st][packed reads][kPat + 1 summaries][2 x hcap items][giants].
+// The list is mapped in two halves on two streams (launch_map_se), each with its own state slot: chunks of an eighth
+// of the batch (the heavy reads of an hg19-like genome, a sixth of all, make one chunk per half), cut evenly on the
+// device (heavy_chunk_span).  Option se_pipe = 0: one stream, one slot, chunks of a quarter.
+// The geometry a call uses follows from (n, read length, the index's options); the workspace a caller must provide
+// (walt_se_workspace_bytes, which knows no index) is that of the DEFAULT options, and no option may need more: an
+// option value that would is not applied (se_geometry).
+constexpr uint32_t kHeavyCtlWords = 64 * kPat + 64;  // 8 words per (chunk, round): up to 8 chunks x kPat rounds; then the literal side launch's 64
+struct SeGeometry {
+  uint32_t hcap;     // reads per chunk
+  uint32_t chunks;   // launched chunks (<= 8; even when piped)
+  bool piped;
+  uint64_t slot_bytes, heavy_bytes;
+};
 static uint64_t se_heavy_slot_bytes(uint64_t hcap, int nw) {
-  const uint64_t quads = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
-  return kPat * hcap * 4 + hcap * 2 * kPat * 16 + (2 * hcap + hcap / 8) * quads * 16;  // flag + kPat - 1 stage lists; summaries; items + giants
+  const uint64_t item_q = 2 + (2 * (uint64_t)nw + 3) / 4;  // item_quads<NW>()
+  const uint64_t rd_q = ((uint64_t)nw + 1 + 3) / 4;         // rd_quads<NW>()
+  return kPat * hcap * 4 + hcap * (1 + rd_q + kPat + 1) * 16 + (2 * hcap + hcap / 8) * item_q * 16;
 }
+static SeGeometry se_geometry_for(uint32_t n, int nw, bool pipe, uint64_t chunk_hook) {
+  SeGeometry g;
+  const uint64_t share = ((uint64_t)n + (pipe ? 7 : 3)) / (pipe ? 8 : 4);
+  g.hcap = (uint32_t)align_up(n <= 65536 ? (n ? n : 1) : (share > 65536 ? share : 65536), 64);
+  if (chunk_hook > 0 && chunk_hook * 8 >= n) g.hcap = (uint32_t)align_up(chunk_hook, 64);  // at most 8 chunks are launched
+  const uint32_t k = (uint32_t)(((uint64_t)n + g.hcap - 1) / g.hcap);
+  g.piped = pipe && k > 1;
+  g.chunks = g.piped ? (k + 1u) & ~1u : k;
+  g.slot_bytes = se_heavy_slot_bytes(g.hcap, nw);
+  g.heavy_bytes = 16 + kHeavyCtlWords * 4 + (g.piped ? 2 : 1) * g.slot_bytes;
+  return g;
+}
+// bytes of the staged state a caller's workspace holds: the larger of the two default schedules
 static uint64_t se_heavy_bytes(uint32_t n, int nw) {
-  return 16 + kHeavyCtlWords * 4 + (se_heavy_piped(n) ? 2 : 1) * se_heavy_slot_bytes(se_heavy_chunk(n), nw);
+  const uint64_t a = se_geometry_for(n, nw, true, 0).heavy_bytes, c = se_geometry_for(n, nw, false, 0).heavy_bytes;
+  return a > c ? a : c;
 }
+static SeGeometry se_geometry(uint32_t n, int nw, const walt_options& opt) {
+  SeGeometry g = se_geometry_for(n, nw, opt.se_pipe != 0, opt.se_heavy_chunk > 0 ? (uint64_t)opt.se_heavy_chunk : 0);
+  if (g.heavy_bytes > se_heavy_bytes(n, nw) || g.hcap > (1u << kStageJBits)) g = se_geometry_for(n, nw, opt.se_pipe != 0, 0);
+  return g;
+}
+// what pass 1 hands to the staged rounds (SeCarry): kPat 16-byte words per read of the batch
+static uint64_t se_carry_bytes(uint32_t n) { return (uint64_t)kPat * se_stride(n) * 16; }
 
-// WALT_AMD_ABLATE (diagnostic builds of the measurement only; results are WRONG when
-// it is set): bit 0 skips verification, bit 1 stops after the directory lookup,
-// bit 2 skips the lookup.  Used to attribute HBM requests to the phases.
-static uint32_t g_ablate = 0;
-static unsigned long long* g_stamps = nullptr;  // WALT_AMD_STAMPS=1: device buffer of kStampPhases sums (diagnostic)
 constexpr unsigned kLiteralGrid = 2048;  // blocks of the deferred-read pass (grid-stride)
 
-// WALT_AMD_SYNC_DEBUG=1 (diagnostic): wait after every launch of the single-end path and say which one returned
+#if defined(WALT_DIAG)
+// Diagnostic build only (make diag: libwalt_amd_diag.so).  WALT_AMD_ABLATE (results are WRONG when bits other than 8
+// are set): bit 0 skips verification, bit 1 stops after the directory lookup, bit 2 skips the lookup, bit 3 checks the
+// danger filter against the exact test (results stay valid).  WALT_AMD_STAMPS=1: in-kernel phase times.
+// WALT_AMD_SYNC_DEBUG=1: wait after every launch of the single-end path and say which one returned.
+static uint32_t g_ablate = 0;
+static unsigned long long* g_stamps = nullptr;
 static void debug_sync(const char* what, hipStream_t stream) {
   static const bool on = getenv("WALT_AMD_SYNC_DEBUG") != nullptr;
   if (!on) return;
   const hipError_t e = hipStreamSynchronize(stream);
   fprintf(stderr, "[walt_amd sync] %s: %s\n", what, hipGetErrorString(e));
 }
+#else
+static void debug_sync(const char*, hipStream_t) {}
+#endif
+
+unsigned persistent_grid(const walt_index* idx) {
+  return idx->opt.grid > 0 ? (unsigned)idx->opt.grid : (unsigned)idx->n_cu * 8u;
+}
 
 template <int NW>
 static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t* codes2, const uint64_t* offsets, uint32_t* err,
                          uint32_t n, uint32_t strand_base, uint32_t max_mm, uint32_t b, BestMatch* out,
                          unsigned long long* stats, uint32_t* defer_count, uint32_t* defer_list, uint64_t stride,
-                         uint32_t* heavy_area, hipStream_t stream) {
-  unsigned pg = kPersistentGrid;
-  if (const char* e = getenv("WALT_AMD_GRID")) pg = atoi(e) > 0 ? (unsigned)atoi(e) : grid_for(n);  // diagnostic knob
+                         uint32_t* heavy_area, uint4* carry_area, hipStream_t stream) {
+  const walt_options& opt = idx->opt;
+  const unsigned pg = persistent_grid(idx);
   const unsigned g1 = grid_for(n) < pg ? grid_for(n) : pg;
-  const bool diag = g_ablate != 0 || g_stamps != nullptr;  // diagnostic instantiation (stamps / ablation)
   uint32_t* heavy_count = defer_count + 24;   // control block word (zeroed with it)
   uint32_t* heavy_list = defer_list + 2 * stride;
-  // WALT_AMD_STAMPS=2: phase stamps of the heavy pass only, 3: of pass 1 only (1: both, summed)
-  const char* sm = getenv("WALT_AMD_STAMPS");
-  const int stamp_mode = sm ? atoi(sm) : 0;
-  const bool diag1 = diag && stamp_mode != 2, diag2 = diag && stamp_mode != 3;
+  const bool mono = opt.se_heavy_mono != 0;
+  SeCarry carry;
+  carry.st = (opt.se_carry && !mono) ? carry_area : nullptr;
+  carry.neg = carry_area + stride;
+  carry.stride = stride;
   // walt_profile_detail: an event after every kernel group (profiling on: bench.py)
   idx->n_detail = 0;
   auto mark = [&](unsigned char kind) {
@@ -1157,77 +1456,97 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     idx->ev_kind[idx->n_detail++] = kind;
   };
   mark(255);  // start
+#if defined(WALT_DIAG)
+  const bool diag = g_ablate != 0 || g_stamps != nullptr;  // diagnostic instantiation (stamps / ablation)
+  // WALT_AMD_STAMPS=2: phase stamps of the (one-kernel) heavy pass only, 3: of pass 1 only (1: both, summed)
+  const char* sm = getenv("WALT_AMD_STAMPS");
+  const int stamp_mode = sm ? atoi(sm) : 0;
+  const bool diag1 = diag && stamp_mode != 2, diag2 = diag && stamp_mode != 3;
   if (diag1)
     hipLaunchKernelGGL((k_map_se<NW, true, false>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                       heavy_list, g_ablate, g_stamps);
+                       heavy_list, g_ablate, g_stamps, carry);
   else
+#else
+  const bool diag = false;
+#endif
     hipLaunchKernelGGL((k_map_se<NW, false, false>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                       heavy_list, 0u, nullptr);
+                       heavy_list, 0u, nullptr, carry);
   debug_sync("pass 1", stream);
   mark(0);
-  // WALT_AMD_HEAVY=mono: the one-kernel heavy pass (large regions verified by the whole wavefront of their read's
-  // lane) instead of the staged one (large regions streamed by k_se_verify); same results, kept for comparison
-  const char* heavy_mode = getenv("WALT_AMD_HEAVY");
-  const bool mono = heavy_mode && !strcmp(heavy_mode, "mono");
   bool lit_side = false;
-  if (diag2 && mono)
-    hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
-                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                       heavy_list, g_ablate, g_stamps);
-  else if (mono)
-    hipLaunchKernelGGL((k_map_se<NW, false, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
-                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                       heavy_list, 0u, nullptr);
-  else {
-    const uint32_t hcap = se_heavy_chunk(n);
-    // two halves on two streams (se_heavy_chunk): odd chunks on idx->se_pipe with the second state slot.  Every launch
-    // is a set of persistent blocks that fill the device by their registers, so two launches do not share a SIMD for
-    // long; what the second stream buys is that one half's launch starts into the other's tail (41.3 against 42.3 ms
-    // per 50 M reads; holding the second half back by one stage to pair look-up stages with verifier launches: 42.7).
-    // Diagnostic runs (stamps, ablation) keep one stream.
-    const bool piped = se_heavy_piped(n) && !diag;
-    const uint32_t chunks = piped ? (se_heavy_chunks(n) + 1u) & ~1u : se_heavy_chunks(n);  // <= 8
+  bool forked = false;  // work is queued on the index's own streams: an error return must not leave it running
+  auto unwind = [&]() {
+    if (!forked) return;
+    if (idx->se_pipe) (void)hipStreamSynchronize(idx->se_pipe);
+    if (idx->se_side) (void)hipStreamSynchronize(idx->se_side);
+  };
+#define WALT_HIP_FORKED(expr)                                                                \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      unwind();                                                                              \
+      return walt::fail(WALT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    }                                                                                        \
+  } while (0)
+  if (mono) {
+    // the one-kernel heavy pass (large regions verified by the whole wavefront of their read's lane) instead of the
+    // staged one (large regions streamed by k_se_verify); same results, kept for comparison
+#if defined(WALT_DIAG)
+    if (diag2)
+      hipLaunchKernelGGL((k_map_se<NW, true, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
+                         strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                         heavy_list, g_ablate, g_stamps, SeCarry());
+    else
+#endif
+      hipLaunchKernelGGL((k_map_se<NW, false, true>), dim3(g1), dim3(kBlock), 0, stream, view, codes2, offsets, err, n,
+                         strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                         heavy_list, 0u, nullptr, SeCarry());
+  } else {
+    const SeGeometry geo = se_geometry(n, NW, opt);
+    const uint32_t hcap = geo.hcap;
+    // two halves on two streams: odd chunks on idx->se_pipe with the second state slot.  Every launch is a set of
+    // persistent blocks that fill the device by their registers, so two launches do not share a SIMD for long; what
+    // the second stream buys is that one half's launch starts into the other's tail.  Diagnostic runs keep one stream.
+    const bool piped = geo.piped && !diag;
+    const uint32_t chunks = geo.chunks;  // <= 8
     HeavyStage hs;
     hs.ctl = heavy_area;
     hs.hcap = hcap;
     hs.even = piped ? 1u : 0u;
-    const uint64_t slot_words = se_heavy_slot_bytes(hcap, NW) / 4;
+    const uint64_t slot_words = geo.slot_bytes / 4;
     auto use_slot = [&](uint32_t k, uint32_t*& lists) {
-      hs.flag = heavy_area + kHeavyCtlWords + k * slot_words;
-      lists = hs.flag + hcap;  // [kPat - 1][hcap]: what stage k hands to stage k + 1
-      hs.sums = reinterpret_cast<uint4*>(lists + (kPat - 1) * (uint64_t)hcap);
-      hs.items = hs.sums + (uint64_t)(2 * kPat) * hcap;  // 2 * hcap items of item_quads<NW>() quads
+      lists = heavy_area + kHeavyCtlWords + k * slot_words;  // [kPat][hcap]: what round k hands to round k + 1
+      hs.st = reinterpret_cast<uint4*>(lists + (uint64_t)kPat * hcap);
+      hs.rdq = hs.st + hcap;
+      hs.sums = hs.rdq + (uint64_t)rd_quads<NW>() * hcap;
+      hs.items = hs.sums + (uint64_t)(kPat + 1) * hcap;  // 2 * hcap items of item_quads<NW>() quads
       hs.giants = hs.items + (uint64_t)2 * hcap * item_quads<NW>();
     };
-    static const uint32_t defer_min = [] {  // WALT_AMD_DEFER=0: never (A/B); =n: ranges of more than n slots (n >= the in-lane limit)
-      const char* e = getenv("WALT_AMD_DEFER");
-      if (!e) return (uint32_t)kSmallRegion;  // (measured: 4 / 8 / 16 -> 32.5 / 33.2 / 34.2 ms per 25 M 150-base reads)
-      const long v = atol(e);
-      return v <= 0 ? 0xFFFFFFFFu : (uint32_t)(v < (long)kSmallRegion ? (long)kSmallRegion : v);
-    }();
-    hs.defer_min = defer_min;  // WALT_AMD_DEFER=0 (A/B): every range narrowed by lit_region in the stage kernel, as before round 3
+    // long seeds: key-equal ranges of more slots than this go to the verifier unnarrowed (option se_defer_min: 0 = never
+    // (A/B: every range narrowed by lit_region in the stage kernel); measured 4 / 8 / 16 -> 32.5 / 33.2 / 34.2 ms per 25 M 150-base reads)
+    hs.defer_min = opt.se_defer_min < 0 ? (uint32_t)kSmallRegion
+                 : opt.se_defer_min == 0 ? 0xFFFFFFFFu
+                 : (uint32_t)(opt.se_defer_min < (long long)kSmallRegion ? (long long)kSmallRegion : opt.se_defer_min);
     uint32_t* const ctl0 = heavy_area;
-    static const unsigned vg_dense = [] {
+    static const int vb_dense = [] {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, NW <= 10>, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
-      return (unsigned)nb * 256u;
+      return nb;
     }();
-    static const unsigned vg_gather = [] {
+    static const int vb_gather = [] {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_se_verify<NW, false>, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
-      return (unsigned)nb * 256u;
+      return nb;
     }();
-    static const int stage_occ = [] { const char* e = getenv("WALT_AMD_STAGE_OCC"); return e ? atoi(e) : 0; }();
-    // The literal pass beside the end of the heavy pass (round 3): after the last look-up stage of the first chunk (of
-    // each half) the list of reads with a truly dangerous probe is complete but for what later chunks add (nothing,
-    // when the heavy list fits these chunks); those reads are sorted and mapped on a side stream while the main streams
-    // run the last verifier launches and the final folds.  The literal kernel is a chain of dependent loads with a few
-    // thousand wavefronts; the verifier is bound by HBM bandwidth, the fold is short.  What later chunks defer is mapped
-    // at the end as before.  WALT_AMD_LIT_SIDE=0: the whole literal pass at the end.
-    static const bool lit_side_on = [] { const char* e = getenv("WALT_AMD_LIT_SIDE"); return !(e && atoi(e) == 0); }();
-    lit_side = lit_side_on && !diag && n <= kDeferMask;
+    const unsigned vg_dense = (unsigned)vb_dense * (unsigned)idx->n_cu, vg_gather = (unsigned)vb_gather * (unsigned)idx->n_cu;
+    // The literal pass beside the end of the heavy pass: after the last look-up round of the first chunk (of each half)
+    // the list of reads with a truly dangerous probe is complete but for what later chunks add (nothing, when the heavy
+    // list fits these chunks); those reads are sorted and mapped on a side stream while the main streams run the last
+    // verifier launches and the last round.  The literal kernel is a chain of dependent loads with a few thousand
+    // wavefronts; the verifier is bound by HBM bandwidth.  What later chunks defer is mapped at the end as before.
+    lit_side = opt.se_lit_side != 0 && !diag && n <= kDeferMask;
     uint32_t* const ctl2 = ctl0 + 64 * kPat + 8;  // [0] count of the side launch, [8..23] its bins
     uint32_t* const rng = ctl2 + 32;              // {entries the side launch took, the list's final length}
     if (lit_side && !idx->se_side) {
@@ -1248,58 +1567,56 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     for (uint32_t c = 0; c < chunks; ++c) {
       const bool odd = piped && (c & 1u);
       hipStream_t cs = odd ? idx->se_pipe : stream;
+      forked = forked || odd;
       uint32_t* lists = nullptr;
       use_slot(odd ? 1u : 0u, lists);
       hs.first = c * hcap;
       hs.chunk = c;
       // chunks behind the first pair append to the deferred list: not while the side launch's share is being fixed
-      if (piped && lit_side && c == 2) WALT_HIP(hipStreamWaitEvent(stream, idx->se_fork, 0));
+      if (piped && lit_side && c == 2) WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_fork, 0));
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
-      for (uint32_t stage = 0; stage <= kPat; ++stage) {
-        hs.stage = stage;
-        hs.ctl = ctl0 + 8 * (kPat * c + (stage < kPat ? stage : 0));
-        const bool listed = stage >= 1 && stage < kPat;
-        hs.list_in = listed ? lists + (uint64_t)(stage - 1) * hcap : nullptr;
-        hs.count_in = listed ? ctl0 + 8 * (kPat * c + stage - 1) : nullptr;
-        hs.list_out = stage + 1 < kPat ? lists + (uint64_t)stage * hcap : nullptr;
-        if (diag2)
-          hipLaunchKernelGGL((k_map_se<NW, true, true, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
-                             n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                             heavy_list, g_ablate, g_stamps, hs);
-        else if (NW <= 10 && stage_occ == (NW <= 8 ? 3 : 2))  // A/B knob (WALT_AMD_STAGE_OCC): one wavefront per SIMD fewer, more registers
-          hipLaunchKernelGGL((k_map_se<NW, false, true, true, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
-                             n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                             heavy_list, 0u, nullptr, hs);
+      for (uint32_t round = 0; round <= kPat; ++round) {
+        hs.round = round;
+        hs.ctl = ctl0 + 8 * (kPat * c + (round < kPat ? round : 0));
+        hs.list_in = round ? lists + (uint64_t)(round - 1) * hcap : nullptr;
+        hs.count_in = round ? ctl0 + 8 * (kPat * c + round - 1) : nullptr;
+        hs.list_out = round < kPat ? lists + (uint64_t)round * hcap : nullptr;
+        if (NW <= 10 && opt.se_stage_occ == (NW <= 8 ? 3 : 2))  // A/B (option se_stage_occ): one wavefront per SIMD fewer, more registers
+          hipLaunchKernelGGL((k_se_stage<NW, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
+                             strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                             heavy_list, hs, carry);
         else
-          hipLaunchKernelGGL((k_map_se<NW, false, true, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
-                             n, strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                             heavy_list, 0u, nullptr, hs);
+          hipLaunchKernelGGL((k_se_stage<NW>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
+                             strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
+                             heavy_list, hs, carry);
         if (!odd) mark(1);
-        if (stage == kPat) break;
-        if (piped && c == 0 && stage == kPat - 1) WALT_HIP(hipEventRecord(idx->se_pipe_ev[1], stream));
-        if (lit_side && c == (piped ? 1u : 0u) && stage == kPat - 1) {
-          if (piped) WALT_HIP(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));  // both halves' first chunks have made their last deferrals
+        if (round == kPat) break;
+        if (piped && c == 0 && round == kPat - 1) WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[1], stream));
+        if (lit_side && c == (piped ? 1u : 0u) && round == kPat - 1) {
+          // (round kPat probes nothing: both halves' first chunks have made their last deferrals)
+          if (piped) WALT_HIP_FORKED(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));
           hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, cs, defer_count, ctl2, rng);
-          WALT_HIP(hipEventRecord(idx->se_fork, cs));
-          WALT_HIP(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
+          WALT_HIP_FORKED(hipEventRecord(idx->se_fork, cs));
+          WALT_HIP_FORKED(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
+          forked = true;
           launch_bin_deferred(ctl2, defer_list, defer_list + stride, idx->se_side);
           const unsigned g_lit = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
           hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g_lit), dim3(kBlock), 0, idx->se_side, view, codes2, offsets, err,
                              strand_base, max_mm, b, idx->d_mask_table, out, stats, ctl2, defer_list + stride, 0u);
-          WALT_HIP(hipEventRecord(idx->se_join, idx->se_side));
+          WALT_HIP_FORKED(hipEventRecord(idx->se_join, idx->se_side));
         }
         if constexpr (NW <= 10 && long_seed_nw<NW>())
-          hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(256 * 8), dim3(kBlock), 0, cs, view, strand_base, hs, b);
+          hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(pg), dim3(kBlock), 0, cs, view, strand_base, hs, b);
         if constexpr (NW <= 10) {
-          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b);
+          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b, err);
         }
-        hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b);
+        hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b, err);
         if (!odd) mark(2);
       }
     }
     if (piped) {  // the second half joins
-      WALT_HIP(hipEventRecord(idx->se_pipe_ev[2], idx->se_pipe));
-      WALT_HIP(hipStreamWaitEvent(stream, idx->se_pipe_ev[2], 0));
+      WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[2], idx->se_pipe));
+      WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_pipe_ev[2], 0));
     }
   }
   debug_sync("heavy pass", stream);
@@ -1310,10 +1627,11 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     unsigned g3 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
     hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g3), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, rng);
-    WALT_HIP(hipStreamWaitEvent(stream, idx->se_join, 0));
+    WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_join, 0));
     mark(3);
     return WALT_OK;
   }
+#undef WALT_HIP_FORKED
   uint32_t* defer_sorted = defer_list + stride;
   if (n <= kDeferMask) launch_bin_deferred(defer_count, defer_list, defer_sorted, stream);
   else defer_sorted = defer_list;
@@ -1328,13 +1646,17 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
 
 int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n, uint32_t max_read_len,
                   int ag, uint32_t max_mm, uint32_t b, void* d_out, void* d_stats, void* d_workspace,
-                  hipStream_t stream) {
+                  size_t workspace_bytes, hipStream_t stream) {
   if (!idx) return fail(WALT_EINVAL, "null index");
   const unsigned need = ag ? WALT_STRANDS_GA : WALT_STRANDS_CT;
   if ((idx->strand_mask & need) != need)
     return fail(WALT_EINVAL, ag ? "index opened without the _GA10/_GA11 strands" : "index opened without the _CT00/_CT01 strands");
   if (n == 0) return WALT_OK;
   if (n > kDeferMask + 1) return fail(WALT_EINVAL, "more than 2^28 reads in one batch (the reference's -N limit is 10^8, walt.cpp:236-239)");
+  // One single-end call at a time per index: the call's side streams and events belong to the index (include/walt_amd.h)
+  std::unique_lock<std::mutex> busy(idx->se_busy, std::try_to_lock);
+  if (!busy.owns_lock()) return fail(WALT_EINVAL, "walt_map_se_batch: another single-end call is running on this index (an index is not re-entrant)");
+#if defined(WALT_DIAG)
   {
     const char* ab = getenv("WALT_AMD_ABLATE");
     g_ablate = ab ? (uint32_t)atoi(ab) : 0u;
@@ -1344,15 +1666,19 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
       WALT_HIP(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
     }
   }
+#endif
   const int nw = nw_for_len(max_read_len);
   if (!nw) return fail(WALT_EINVAL, "read length above 1024 is not supported (reference line limit is 1000, util.hpp:43)");
   if (max_read_len > kMaxReadLen)
     return fail(WALT_EINVAL, "reads longer than " + std::to_string(kMaxReadLen) + " bases are outside the tables of seed pattern " +
                                  std::to_string(kPat) + " (seedpattern.hpp)");
+  if (workspace_bytes < walt_se_workspace_bytes(n, max_read_len))
+    return fail(WALT_EINVAL, "walt_map_se_batch_device: the workspace holds " + std::to_string(workspace_bytes) + " bytes, the call needs " +
+                                 std::to_string(walt_se_workspace_bytes(n, max_read_len)) + " (walt_se_workspace_bytes)");
   WALT_HIP(hipSetDevice(idx->device));
   const uint64_t stride = se_stride(n);
   // workspace: [64 words: read errors, deferral control] [statistic shards] [deferred list] [sorted deferred
-  // list] [heavy list] [dense 2-bit reads]
+  // list] [heavy list] [dense 2-bit reads] [state of the staged heavy pass] [what pass 1 hands over]
   uint32_t* err = reinterpret_cast<uint32_t*>(d_workspace);
   unsigned long long* shards = reinterpret_cast<unsigned long long*>(err + 64);
   uint32_t* defer_count = err + 32;  // control block: [0] count, [8..15] bin counts, [16..23] bin cursors
@@ -1361,6 +1687,7 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   // state of the staged heavy pass behind the dense reads, 16-byte aligned
   uint32_t* heavy_area = reinterpret_cast<uint32_t*>(
       align_up(reinterpret_cast<uint64_t>(codes2 + codes2_words((uint64_t)n * max_read_len)), 16));
+  uint4* carry_area = reinterpret_cast<uint4*>(align_up(reinterpret_cast<uint64_t>(heavy_area) + se_heavy_bytes(n, nw), 16));
   WALT_HIP(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t) + kStatShardBytes, stream));
   WALT_HIP(hipMemsetAsync(heavy_area, 0, kHeavyCtlWords * sizeof(uint32_t), stream));
   const uint8_t* bases = reinterpret_cast<const uint8_t*>(d_bases);
@@ -1374,18 +1701,25 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
   BestMatch* out = reinterpret_cast<BestMatch*>(d_out);
   const uint32_t sb = ag ? 2u : 0u;
   int rc;
-  switch (nw) {
-    case 7: rc = launch_map_se<7>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
-    case 8: rc = launch_map_se<8>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
-#if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
-    case 10: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
-    case 16: rc = launch_map_se<16>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
-    case 32: rc = launch_map_se<32>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
-    default: rc = launch_map_se<64>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
+#define WALT_SE_CASE(NWV) rc = launch_map_se<NWV>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, carry_area, stream)
+#if defined(WALT_ONLY_NW)  // (development: one kernel instance, for quick resource checks -- tools/kernel_resources.sh)
+  WALT_SE_CASE(WALT_ONLY_NW);
+  (void)nw;
 #else
-    default: rc = launch_map_se<10>(idx, view, codes2, offsets, err, n, sb, max_mm, b, out, shards, defer_count, defer_list, stride, heavy_area, stream); break;
+  switch (nw) {
+    case 7: WALT_SE_CASE(7); break;
+    case 8: WALT_SE_CASE(8); break;
+#if WALT_SEEDPATTERN == 3  // patterns 5 / 7 stop at kMaxReadLen = 148 / 152 bases
+    case 10: WALT_SE_CASE(10); break;
+    case 16: WALT_SE_CASE(16); break;
+    case 32: WALT_SE_CASE(32); break;
+    default: WALT_SE_CASE(64); break;
+#else
+    default: WALT_SE_CASE(10); break;
 #endif
   }
+#endif
+#undef WALT_SE_CASE
   if (rc) return rc;
   launch_reduce_stats(shards, reinterpret_cast<unsigned long long*>(d_stats), stream);
   if (idx->profile) {
@@ -1398,9 +1732,10 @@ int map_se_device(walt_index* idx, const void* d_bases, const void* d_offsets, u
 
 // err[0] / err[1] (non-ACGT reads / over-long reads) live at the start of the workspace
 int check_read_errors(const void* d_workspace, hipStream_t stream) {
-  uint32_t herr[2] = {0, 0};
+  uint32_t herr[3] = {0, 0, 0};
   WALT_HIP(hipMemcpyAsync(herr, d_workspace, sizeof(herr), hipMemcpyDeviceToHost, stream));
   WALT_HIP(hipStreamSynchronize(stream));
+  if (herr[2]) return fail(WALT_EHIP, "internal: a work-item queue of the heavy pass overflowed (" + std::to_string(herr[2]) + " items dropped); results are incomplete");
   if (herr[1]) return fail(WALT_EINVAL, "reads longer than max_read_len, or more bases than n x max_read_len (" + std::to_string(herr[1]) + " refusals)");
   if (herr[0]) return fail(WALT_EBASE, "the batch holds non-ACGT nucleotides (in " + std::to_string(herr[0]) + " of its 16-base words)");
   return WALT_OK;
@@ -1429,11 +1764,16 @@ int walt_profile_enable(walt_index* idx, int on) {
 
 // diagnostic: read and clear the WALT_AMD_STAMPS phase sums (cycles summed over waves)
 int walt_profile_stamps(unsigned long long* out16) {
+#if defined(WALT_DIAG)
   if (!g_stamps) return fail(WALT_EINVAL, "WALT_AMD_STAMPS is not enabled");
   WALT_HIP(hipDeviceSynchronize());
   WALT_HIP(hipMemcpy(out16, g_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   WALT_HIP(hipMemset(g_stamps, 0, 16 * sizeof(unsigned long long)));
   return WALT_OK;
+#else
+  (void)out16;
+  return fail(WALT_EINVAL, "phase stamps exist in the diagnostic build only (make diag: libwalt_amd_diag.so)");
+#endif
 }
 
 int walt_profile_detail(walt_index* idx, float* out4) {
@@ -1463,14 +1803,14 @@ size_t walt_se_workspace_bytes(uint32_t n, uint32_t max_read_len) {
   int nw = nw_for_len(max_read_len);
   if (!nw) nw = 64;
   return 64 * sizeof(uint32_t) + kStatShardBytes + 3 * se_stride(n) * sizeof(uint32_t) +
-         codes2_words((uint64_t)n * max_read_len) * sizeof(uint32_t) + se_heavy_bytes(n, nw);
+         codes2_words((uint64_t)n * max_read_len) * sizeof(uint32_t) + 16 + se_heavy_bytes(n, nw) + 16 + se_carry_bytes(n);
 }
 
 int walt_map_se_batch_device(walt_index* idx, const void* d_bases, const void* d_offsets, uint32_t n,
                              uint32_t max_read_len, int ag_wildcard, uint32_t max_mismatches, uint32_t b,
-                             void* d_out, void* d_stats, void* d_workspace, void* stream) {
+                             void* d_out, void* d_stats, void* d_workspace, size_t workspace_bytes, void* stream) {
   return map_se_device(idx, d_bases, d_offsets, n, max_read_len, ag_wildcard, max_mismatches, b, d_out, d_stats,
-                       d_workspace, reinterpret_cast<hipStream_t>(stream));
+                       d_workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offsets, uint32_t n, int ag_wildcard,
@@ -1509,7 +1849,8 @@ int walt_map_se_batch(walt_index* idx, const char* bases, const uint64_t* offset
       (e = hipMemcpyAsync(d_off, off_src, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr)) != hipSuccess ||
       (e = hipMemsetAsync(d_stats, 0, sizeof(walt_batch_stats), nullptr)) != hipSuccess)
     return fail(WALT_EHIP, std::string("upload failed: ") + hipGetErrorString(e));
-  rc = map_se_device(idx, d_bases, d_off, n, max_len, ag_wildcard, max_mismatches, b, d_out, d_stats, d_ws, nullptr);
+  rc = map_se_device(idx, d_bases, d_off, n, max_len, ag_wildcard, max_mismatches, b, d_out, d_stats, d_ws,
+                     walt_se_workspace_bytes(n, max_len), nullptr);
   if (!rc) rc = check_read_errors(d_ws, nullptr);
   if (!rc) {
     if ((e = hipMemcpy(out, d_out, (size_t)n * sizeof(walt_best_match), hipMemcpyDeviceToHost)) != hipSuccess)
