@@ -99,6 +99,8 @@ def parse_args(argv):
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_lines legs (configs[2], configs[4])")
     ap.add_argument("--extra-pairs", type=int, default=0, help="pairs of the extra paired-end legs (default: --reads, 150 bp: half)")
     ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--extra-contigs", type=int, default=3000,
+                    help="sequences of the many-contigs extra leg (the headline genome cut into that many; 0: no such leg)")
     ap.add_argument("--ref-sample", type=int, default=2_000_000,
                     help="reads the real reference binary (oracle/_ref/walt) maps beside the oracle port at N=1 "
                          "(0 = skip; needs ~35 GB of RAM-backed scratch for the index copy)")
@@ -329,15 +331,38 @@ def se_report(cx, args, leg, job, n, read_len, max_mm, b, sel_all, n_uniform, tr
         vb = rec_bytes * C_big * n
         by_kernel["k_se_verify"].update({"algorithmic_bytes": vb, "achieved": vb / (dms[2] / 1e3) / 1e9, "unit": "GB/s",
                                          "frac": vb / (dms[2] / 1e3) / HBM_PEAK})
-    roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": traffic, "by_kernel": by_kernel,
-            "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
+    # `frac` / `achieved`: STRICT algorithmic bytes (what the search needs byte by byte: `useful`); `frac_lines` /
+    # `achieved_lines`: the same work priced at one 128-byte line per dependent gather (what HBM has to deliver for it).
+    # Scalars first: the driver's record keeps scalars only.
+    strict = useful * n / kern_s
+    names = ("k_map_se pass 1", "k_se_stage heavy stages", "k_se_verify", "k_map_se_literal (+ sort)")
+    dom = int(np.argmax(dms)) if max(dms) > 0 else 0
+    vb = rec_bytes * C_big * n                          # the verifier's bytes: its dense records, nothing else
+    look_ms = dms[0] + dms[1] + dms[3]                  # every kernel that is not the verifier: dependent gathers
+    look_lines = lines * n                              # 128-byte lines those kernels need (2 per probe, 1 per candidate outside the windows)
+    look_bytes = bytes_per_read * n - vb
+    dom_frac = None
+    if dms[dom] > 0:
+        dom_frac = (vb / (dms[2] / 1e3) / HBM_PEAK) if dom == 2 else (look_bytes / (look_ms / 1e3) / HBM_PEAK)
+    roof = {"bound": "hbm", "achieved": strict / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": strict / HBM_PEAK, "frac_lines": achieved / HBM_PEAK, "achieved_lines": achieved / 1e9,
+            "traffic": traffic, "traffic_frac": (traffic / kern_s / HBM_PEAK) if traffic else None,
             "kernel": kernel_name, "kernel_ms_median": kern_s * 1e3, "kernel_ms_min": float(np.min(leg["map_ms"])),
-            "algorithmic_bytes_per_read": bytes_per_read,
-            "granularity": "128-byte line per dependent gather (%d per probe, 1 per candidate outside the dense windows) + "
-                           "12-byte entry / %d-byte dense record per candidate + streamed read/result bytes" % (
-                               1 if table else 2, int(rec_bytes)),
-            "useful_bytes_per_read": useful,
+            "algorithmic_bytes_per_read": useful, "line_bytes_per_read": bytes_per_read,
+            "dominant_kernel": names[dom], "dominant_kernel_ms": dms[dom], "dominant_kernel_frac": dom_frac,
+            "dominant_kernel_frac_is": "dense-record bytes / its time" if dom == 2 else
+                                       "line bytes of all look-up kernels (pass 1 + stages + literal) / their time",
+            "pass1_ms": dms[0], "stage_ms": dms[1], "verify_ms": dms[2], "literal_ms": dms[3],
+            "verify_frac": (vb / (dms[2] / 1e3) / HBM_PEAK) if dms[2] > 0 else None,
+            "lookup_frac_lines": (look_bytes / (look_ms / 1e3) / HBM_PEAK) if look_ms > 0 else None,
+            "gather_lines_per_s": (look_lines / (look_ms / 1e3)) if look_ms > 0 else None,
+            "gather_ceiling_lines_per_s": None,  # filled in by the caller (tools/gather_calib in the same run)
+            "probes_per_read": P, "candidates_per_read": C, "candidates_in_regions_gt16_per_read": C_big,
+            "granularity": "frac: bytes (%d B/read: read + result + 20 B per probe + 45 B per candidate); frac_lines: 128-byte line "
+                           "per dependent gather (%d per probe, 1 per candidate outside the dense windows) + 12-byte entry / "
+                           "%d-byte dense record per candidate + streamed read/result bytes" % (
+                               int(useful), 1 if table else 2, int(rec_bytes)),
+            "by_kernel": by_kernel,
             "per_read": {"probes": P, "search_steps": S, "candidates": C, "candidates_in_regions_gt16": C_big},
             "per_read_source": "oracle counters on this run's uniform sample",
             "survey_8d": {"bytes_per_read": survey, "achieved": survey * n / kern_s / 1e9,
@@ -603,6 +628,26 @@ def calibration_leg(cx, local, cores, n=100_000, read_len=100, max_mm=6, b=5000)
         shutil.rmtree(scratch, ignore_errors=True)
 
 
+def gather_ceiling(table_gb=64.0):
+    """The device's random-line ceiling, measured in this run: tools/gather_calib (a diagnostic micro-benchmark, built by
+    __graft_entry__.build) gathers 12-byte elements at random over a table of `table_gb` GB, one independent gather after
+    the other per lane -- every gather is one 128-byte line from HBM.  Run as a child process while the bench holds no
+    index (the table needs the memory).  Returns lines per second or a dict with the reason it could not run."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "gather_calib")
+    if not os.path.exists(exe):
+        return {"skipped": "tools/gather_calib is not built"}
+    try:
+        pr = subprocess.run([exe, str(table_gb), "3", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    except Exception as e:
+        return {"skipped": "%s: %s" % (type(e).__name__, e)}
+    mt = re.search(r"([0-9.]+) G gathers/s", pr.stdout)
+    if pr.returncode != 0 or not mt:
+        return {"skipped": "gather_calib: " + pr.stdout[-200:]}
+    return float(mt.group(1)) * 1e9
+
+
 # ------------------------------------------------------------------------------------------------ paired-end
 def pe_leg(cx, idx, d1, d2, d_off, n, read_len, max_mm, b, top_k, frag_range, steps, warmup, timed_barrier=True):
     torch, walt_amd = cx.torch, cx.walt_amd
@@ -750,15 +795,21 @@ def pe_report(cx, args, leg, job, n, read_len, sel_all, nu, traffic_key):
     if t and t.get("pairs_per_step") == n and t.get("genome") == args.genome and t.get("genome_bp") == cx.genome_bp \
             and args.pattern == 3 and not args.contigs:
         traffic = t.get("hbm_bytes_per_step")
-    roof = {"bound": "hbm", "achieved": bytes_per_pair * n / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": bytes_per_pair * n / step_s / HBM_PEAK, "traffic": traffic,
+    # strict bytes (as the single-end line's `frac`): reads + pair record + 20 B per probe + (12-byte entry + window + 8) per
+    # candidate + the ranked lists written and read back (12 bytes per kept candidate and mate, at most top_k)
+    top_k = job["top_k"]
+    useful = 2 * read_len / 4.0 + 64 + P * (8 + 12) + C * (12 + read_len / 4.0 + 8) + 2 * 2 * 12.0 * min(C / 2.0, float(top_k))
+    roof = {"bound": "hbm", "achieved": useful * n / step_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": useful * n / step_s / HBM_PEAK, "frac_lines": bytes_per_pair * n / step_s / HBM_PEAK,
+            "achieved_lines": bytes_per_pair * n / step_s / 1e9, "traffic": traffic,
             "traffic_frac": (traffic / step_s / HBM_PEAK) if traffic else None,
             "kernel": "whole paired-end step (k_pe_topk_dual, staged k_pe_stage / k_pe_verify / k_pe_push of both mates, k_pe_merge)",
             "step_ms_median": step_s * 1e3, "step_ms_min": float(np.min(leg["per_step"])) * 1e3,
-            "algorithmic_bytes_per_pair": bytes_per_pair,
-            "granularity": "128-byte line per dependent gather (2 per probe, 1 per candidate outside the dense windows, 2 per "
-                           "mate for the ranked list) + 12-byte entry / %d-byte dense record per candidate + streamed reads / "
-                           "pair record" % int(rec_bytes),
+            "algorithmic_bytes_per_pair": useful, "useful_bytes_per_pair": useful, "line_bytes_per_pair": bytes_per_pair,
+            "probes_per_pair": P, "candidates_per_pair": C, "candidates_in_regions_gt16_per_pair": C_big,
+            "granularity": "frac: bytes; frac_lines: 128-byte line per dependent gather (2 per probe, 1 per candidate outside the "
+                           "dense windows, 2 per mate for the ranked list) + 12-byte entry / %d-byte dense record per candidate + "
+                           "streamed reads / pair record" % int(rec_bytes),
             "per_pair": {"probes": P, "candidates": C, "candidates_in_regions_gt16": C_big}}
     return cpu, roof
 
@@ -1001,11 +1052,26 @@ def worker(args):
         del jobs, leg, leg150, d_bases, d_off
         idx.close()
         torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and out is not None and "roofline" in out and not args.no_extra:
+            g = gather_ceiling()
+            out["roofline"]["gather_ceiling_lines_per_s"] = g if isinstance(g, float) else None
+            if not isinstance(g, float):
+                out["roofline"]["gather_ceiling_skipped"] = g["skipped"]
+            elif out["roofline"].get("gather_lines_per_s"):
+                out["roofline"]["gather_frac_of_ceiling"] = out["roofline"]["gather_lines_per_s"] / g
+        if rank == 0 and out is not None and "cpu_baseline" in out:
+            rb = out["cpu_baseline"].get("reference_binary") or {}
+            out["cpu_baseline"]["reference_reads_per_s"] = rb.get("value")   # the real `walt -t N` on this box in this run
+            out["cpu_baseline"]["reference_cores"] = rb.get("cores")
+            out["cpu_baseline"]["reference_mapstats_equal_gpu"] = rb.get("mapstats_equal_gpu")
         if "scratch" in e2e_keep:  # the GPU is free now: the command-line binary opens its own index
             import shutil
             try:
                 extra.append(e2e_leg(cx, e2e_keep["scratch"], e2e_keep["dbi"], e2e_keep["bases"], e2e_keep["times"], args.read_len,
                                      e2e_keep["n"], args.max_mismatches, args.bucket, e2e_keep["cores"], args.e2e_batch))
+                out["e2e_reads_per_s"] = extra[-1].get("value")
+                out["cpu_baseline"]["e2e_reads_per_s"] = extra[-1].get("value")
+                out["cpu_baseline"]["e2e_reads_per_s_whole_wall"] = extra[-1].get("reads_per_s_whole_wall")
             except Exception as e:
                 extra.append({"metric": "reads/s end to end", "skipped": "%s: %s" % (type(e).__name__, e)})
             finally:
@@ -1130,10 +1196,68 @@ def worker(args):
                 j["target"]["roofline"] = roof
                 j["target"]["cpu_baseline"] = cpu
         idx.close()
+    # ---------------------------------------------------------------- many sequences: the same genome cut into 3,000 contigs
+    # (an assembly like hg38's analysis set has 3,366 sequences; every chromosome end adds entries the key search may
+    # not trust): the single-end leg on it, every round
+    if rank == 0 and world == 1 and not args.no_extra and args.pattern == 3 and args.mode == "se" and not args.contigs \
+            and not args.ag and args.extra_contigs > 0 and out is not None:
+        import gc
+        genome_ascii = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            t0 = time.perf_counter()
+            g3, lens3, names3 = synth.make_genome(torch, dev, scale, seed=2, kind=args.genome, contigs=args.extra_contigs)
+            idx = walt_amd.Index.build_device(g3.data_ptr(), lens3, names3, device=local, strands=walt_amd.STRANDS_CT,
+                                              dir_bits=args.dir_bits)
+            apply_opts(idx, args)
+            b3, o3 = synth.make_reads(torch, dev, g3, n, args.read_len, seed=5000, lowq=lowq)
+            torch.cuda.synchronize()
+            log("contigs leg: %d sequences, index %.1f GB, outliers %d/%d (%.1f s)" % (
+                len(lens3), idx.device_bytes / 1e9, idx.outliers(0), idx.outliers(1), time.perf_counter() - t0))
+            leg3 = se_leg(cx, idx, b3, o3, n, args.read_len, args.max_mismatches, args.bucket, False, args.extra_steps, 1,
+                          timed_barrier=False)
+            log("contigs leg: heavy pass %d reads, literal pass %d reads; map %.2f ms (median), groups %s" % (
+                leg3["n_heavy"], leg3["n_deferred"], float(np.median(leg3["map_ms"])), [round(x, 2) for x in leg3["detail_ms"]]))
+            line3 = {"metric": "mapped reads/sec (%d bp single-end, hg19-scale genome in %d sequences, -m %d -b %d)" % (
+                         args.read_len, len(lens3), args.max_mismatches, args.bucket),
+                     "value": n * args.extra_steps / leg3["elapsed"], "unit": "reads/s", "n_gpus": 1, "steps": args.extra_steps,
+                     "warmup": 1, "ms_per_step": 1e3 * leg3["elapsed"] / args.extra_steps, "dtype": "u32", "data": "synthetic",
+                     "config": {"workload": "contigs%d: the headline genome cut into %d equal sequences, %d x %d bp single-end "
+                                            "reads, -m %d -b %d" % (args.extra_contigs, len(lens3), n, args.read_len,
+                                                                    args.max_mismatches, args.bucket),
+                                "sequences": len(lens3), "outliers": [int(idx.outliers(0)), int(idx.outliers(1))]},
+                     "kernel_ms": {"map_se": float(np.median(leg3["map_ms"])),
+                                   "by_group": dict(zip(("pass1", "heavy_stages", "se_verify", "literal"), leg3["detail_ms"]))},
+                     "heavy_pass_reads": int(leg3["n_heavy"]), "deferred_to_literal_pass": int(leg3["n_deferred"])}
+            if run_cpu:
+                uni, hard = se_sample(cx, leg3, n, max(1, args.cpu_sample // 5), max(1, args.hard_sample // 5))
+                sel = torch.cat([uni, hard])
+                j3 = {"bases": b3.view(n, args.read_len)[sel].cpu().numpy().reshape(-1), "m": int(sel.numel()),
+                      "read_len": args.read_len, "max_mm": args.max_mismatches, "b": args.bucket, "ag": False,
+                      "timed_first": int(uni.numel())}
+                oracle_se_jobs(cx, idx, [j3], lens3, (0, 1))
+                cx_bp, cx.genome_bp = cx.genome_bp, -1  # (no filed PMC traffic belongs to this genome)
+                cpu3, roof3 = se_report(cx, args, leg3, j3, n, args.read_len, args.max_mismatches, args.bucket, sel,
+                                        int(uni.numel()), "se%d_contigs" % args.read_len,
+                                        "single-end mapping kernels on %d sequences" % len(lens3))
+                cx.genome_bp = cx_bp
+                line3["roofline"], line3["cpu_baseline"] = roof3, cpu3
+                del j3
+            extra.append(line3)
+            out["contigs%d_ms_per_step" % args.extra_contigs] = line3["ms_per_step"]
+            if "roofline" in out:
+                out["roofline"]["contigs%d_ms_per_step" % args.extra_contigs] = line3["ms_per_step"]
+                out["roofline"]["contigs%d_bit_exact" % args.extra_contigs] = (line3.get("cpu_baseline") or {}).get("bit_exact_vs_gpu")
+            del leg3, b3, o3, g3
+            idx.close()
+            torch.cuda.empty_cache()
+        except Exception as e:  # never let the extra leg break the bench line
+            extra.append({"metric": "contigs leg", "skipped": "%s: %s" % (type(e).__name__, e)})
     if rank == 0 and world == 1 and run_cpu and not args.no_calibration and not args.no_extra and args.pattern == 3 \
             and out is not None and "cpu_baseline" in out:
         try:
-            del genome_ascii
+            genome_ascii = None
             torch.cuda.empty_cache()
             out["cpu_baseline"]["calibration"] = calibration_leg(cx, local, walt_amd.effective_cpus())
         except Exception as e:  # never let the extra leg break the bench line
@@ -1141,6 +1265,19 @@ def worker(args):
     if rank == 0:
         if extra:
             out["extra_lines"] = extra
+            # the other legs' headline figures as scalars of the main line's roofline object (the driver's record keeps
+            # scalars; the full lines are in extra_lines)
+            if "roofline" in out:
+                for ln in extra:
+                    m = ln.get("metric", "")
+                    tag = ("pe100" if "2 x 100" in m else "pe150" if "2 x 150" in m else "se150ag" if "150 bp single-end -A" in m
+                           else "se150" if "150 bp single-end" in m else None)
+                    if tag is None or "ms_per_step" not in ln:
+                        continue
+                    out["roofline"][tag + "_ms_per_step"] = ln["ms_per_step"]
+                    out["roofline"][tag + "_frac"] = (ln.get("roofline") or {}).get("frac")
+                    out["roofline"][tag + "_frac_lines"] = (ln.get("roofline") or {}).get("frac_lines")
+                    out["roofline"][tag + "_bit_exact"] = (ln.get("cpu_baseline") or {}).get("bit_exact_vs_gpu")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()  # ranks > 0 wait for rank 0 before tearing the group down

@@ -97,7 +97,7 @@ def test_gpu_pe_ranked_lists_and_pairs_equal_oracle(wa, g1_db, g1_dev, pe_chunk,
         assert_best_equal(got["m2"], want["m2"], "m2")
 
 
-@pytest.mark.parametrize("seed,n_chrom", [(11, 80), (12, 300), (13, 10), (14, 1500)])  # 1500 > LDS chromosome table
+@pytest.mark.parametrize("seed,n_chrom", [(11, 80), (12, 300), (13, 10), (14, 1500), (15, 2500), (16, 4500)])  # above 1,023 sequences the LDS table holds every 2nd, 4th, 8th start (map_common.h ChromTab)
 def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
     seqs, db = make_random_case(seed, n_chrom, scratch)
     rng = random.Random(seed * 31)

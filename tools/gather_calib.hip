@@ -34,7 +34,39 @@ __global__ void k_gather(const uint32_t* __restrict__ tab, uint64_t n_elems, int
   out[tid] = acc;
 }
 
+// one configuration, one line (bench.py runs this beside its own kernels: the device's random-line ceiling, measured in
+// the same run):  gather_calib <table GB> <words per element: 1 | 3> <dependent gathers per chain>
+static int one(double gb, int words, int chain) {
+  const int threads = 256, blocks = 256 * 20 * 4;
+  uint32_t* out;
+  if (hipMalloc(&out, (size_t)threads * blocks * 4) != hipSuccess) return 1;
+  const uint64_t bytes = (uint64_t)(gb * (1ull << 30));
+  uint32_t* tab;
+  if (hipMalloc(&tab, bytes) != hipSuccess) { printf("alloc %.1f GB failed\n", gb); return 1; }
+  hipMemset(tab, 1, bytes);
+  const uint64_t n_elems = bytes / (4 * words);
+  const int iters = chain == 1 ? 64 : 8;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    if (words == 1) hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(threads), 0, 0, tab, n_elems, iters, chain, out);
+    else hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(threads), 0, 0, tab, n_elems, iters, chain, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  const double n = (double)threads * blocks * iters * chain;
+  printf("table %6.2f GB  elem %2d B  chain %d : %8.3f ms  %7.2f G gathers/s  (%.0f gathers)\n", gb, 4 * words, chain, best,
+         n / best / 1e6, n);
+  hipFree(tab); hipFree(out);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4) return one(atof(argv[1]), atoi(argv[2]), atoi(argv[3]));
   double gbs[] = {0.25, 1, 4, 16, 40, 80};
   int threads = 256, blocks = 256 * 20 * 4;  // 5 waves/SIMD worth of lanes x4
   uint32_t* out;

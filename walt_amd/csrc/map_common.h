@@ -19,8 +19,87 @@ struct BlockShared {
   uint16_t pcode4[256];            // prefix code of 4 care chars: bits | len << 8 (core.h pcode_*)
 };
 
-// Stage the compare-mask table and the chromosome starts in LDS.  Returns the
-// pointer the lanes use for start_index lookups (LDS when it fits, else HBM).
+// getChromID (reference.cpp:43-60) with a fixed number of steps: largest l with
+// si[l] <= pos.  top_step = largest power of two <= n_chrom (wave-uniform).
+__device__ __forceinline__ uint32_t chrom_id_steps(const uint32_t* si, uint32_t n_chrom, uint32_t top_step,
+                                                   uint32_t pos) {
+  uint32_t l = 0;
+  for (uint32_t step = top_step; step; step >>= 1) {
+    const uint32_t c = l + step;
+    const uint32_t v = si[c <= n_chrom ? c : n_chrom];
+    l = (c <= n_chrom && pos >= v) ? c : l;
+  }
+  return l;
+}
+__device__ __forceinline__ uint32_t top_step_of(uint32_t n_chrom) {
+  return n_chrom ? 1u << (31 - __clz((int)n_chrom)) : 0u;
+}
+
+// Chromosome starts for ANY number of sequences (round 4; an assembly like hg38's analysis set has 3,366).  Up to
+// kLdsChroms sequences the LDS array holds every start.  Beyond that it holds every 2^shift-th start (shift the
+// smallest that fits) plus the genome's end: getChromID (reference.cpp:43-60: the largest l with start[l] <= pos) is a
+// search over the sampled starts in LDS, then over the at most 2^shift starts between two samples -- for shift <= 2
+// (up to 4,092 sequences) five neighbouring words of the device array fetched together, no search.  Before, every
+// candidate of such an assembly paid a bisection of log2(n) DEPENDENT loads over the device array in every kernel
+// (3,000 contigs: pass 1 18.9 against 10.7 ms, stage kernels 38 against 16, verifier 27 against 13).
+struct ChromTab {
+  uint32_t n_chrom, shift, m, top;  // m = sampled intervals = ceil(n_chrom / 2^shift) <= kLdsChroms, top = top_step_of(m)
+};
+__device__ __forceinline__ ChromTab chrom_tab_of(uint32_t n_chrom) {
+  ChromTab t;
+  t.n_chrom = n_chrom;
+  uint32_t sh = 0;
+  while (((n_chrom + (1u << sh) - 1u) >> sh) > kLdsChroms) ++sh;  // (uniform: scalar)
+  t.shift = sh;
+  t.m = (n_chrom + (1u << sh) - 1u) >> sh;
+  t.top = top_step_of(t.m);
+  return t;
+}
+// fills lds[0 .. m] (kLdsChroms + 1 words); the caller's barrier follows
+__device__ __forceinline__ void chrom_tab_stage(uint32_t* lds, const uint32_t* __restrict__ gs, const ChromTab& t) {
+  for (uint32_t i = threadIdx.x; i <= t.m; i += blockDim.x) {
+    const uint32_t c = i << t.shift;
+    lds[i] = gs[c < t.n_chrom ? c : t.n_chrom];
+  }
+}
+// chr = getChromID(pos); c_lo / c_hi = its first base and the next chromosome's (lds: the staged samples, gs: the device array)
+__device__ __forceinline__ void chrom_find(const uint32_t* lds, const uint32_t* __restrict__ gs, const ChromTab& t, uint32_t pos,
+                                           uint32_t& chr, uint32_t& c_lo, uint32_t& c_hi) {
+  uint32_t ci = chrom_id_steps(lds, t.m, t.top, pos);
+  ci = ci < t.m ? ci : (t.m ? t.m - 1u : 0u);  // (a position at or beyond the genome's end: the last interval)
+  if (t.shift == 0) {  // (uniform)
+    chr = ci; c_lo = lds[ci]; c_hi = lds[ci + 1];
+    return;
+  }
+  const uint32_t base = ci << t.shift;
+  if (t.shift <= 2) {
+    uint32_t w[5];
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) w[k] = gs[base + k < t.n_chrom ? base + k : t.n_chrom];  // independent loads, one or two lines
+    uint32_t off = 0;
+    c_lo = w[0]; c_hi = w[1];
+#pragma unroll
+    for (uint32_t k = 1; k < 4; ++k) {
+      const bool take = k < (1u << t.shift) && base + k < t.n_chrom && pos >= w[k];
+      off = take ? k : off;
+      c_lo = take ? w[k] : c_lo;
+      c_hi = take ? w[k + 1] : c_hi;
+    }
+    chr = base + off;
+    return;
+  }
+  const uint32_t nsub = t.n_chrom - base < (1u << t.shift) ? t.n_chrom - base : (1u << t.shift);
+  const uint32_t off = chrom_id_steps(gs + base, nsub, 1u << t.shift, pos);
+  chr = base + off; c_lo = gs[base + off]; c_hi = gs[base + off + 1];
+}
+__device__ __forceinline__ void chrom_bounds(const uint32_t* lds, const uint32_t* __restrict__ gs, const ChromTab& t, uint32_t pos,
+                                             uint32_t& c_lo, uint32_t& c_hi) {
+  uint32_t chr;
+  chrom_find(lds, gs, t, pos, chr, c_lo, c_hi);
+}
+
+// Stage the compare-mask table and the chromosome starts in LDS (ChromTab: all of them, or every 2^shift-th).
+// Returns the LDS array; the lookups take it together with the device array (chrom_find).
 __device__ __forceinline__ const uint32_t* block_prologue(BlockShared& sh, const IndexView& iv,
                                                           const uint32_t* __restrict__ mask_table,
                                                           uint32_t strand_base) {
@@ -34,11 +113,9 @@ __device__ __forceinline__ const uint32_t* block_prologue(BlockShared& sh, const
     }
     sh.pcode4[i] = (uint16_t)(bits | (len << 8));
   }
-  const bool fits = iv.n_chrom <= kLdsChroms;
-  if (fits)
-    for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) sh.start_index[i] = iv.start_index[i];
+  chrom_tab_stage(sh.start_index, iv.start_index, chrom_tab_of(iv.n_chrom));  // every start, or every 2^shift-th (ChromTab)
   __syncthreads();
-  return fits ? sh.start_index : iv.start_index;
+  return sh.start_index;
 }
 
 // LDS copy of the two strands' Bloom prefilters (core.h pre_hash); filled before block_prologue's barrier
@@ -238,22 +315,6 @@ __device__ __forceinline__ void seed_query(const uint32_t* rd, uint32_t seed_len
   slot = seed_len ? dir_top(Bd) - (nb_seed < Bd ? (v_lo >> (Bd - nb_seed)) << (Bd - nb_seed) : v_lo) : 0u;
 }
 
-// getChromID (reference.cpp:43-60) with a fixed number of steps: largest l with
-// si[l] <= pos.  top_step = largest power of two <= n_chrom (wave-uniform).
-__device__ __forceinline__ uint32_t chrom_id_steps(const uint32_t* si, uint32_t n_chrom, uint32_t top_step,
-                                                   uint32_t pos) {
-  uint32_t l = 0;
-  for (uint32_t step = top_step; step; step >>= 1) {
-    const uint32_t c = l + step;
-    const uint32_t v = si[c <= n_chrom ? c : n_chrom];
-    l = (c <= n_chrom && pos >= v) ? c : l;
-  }
-  return l;
-}
-__device__ __forceinline__ uint32_t top_step_of(uint32_t n_chrom) {
-  return n_chrom ? 1u << (31 - __clz((int)n_chrom)) : 0u;
-}
-
 template <int NW>
 __device__ __forceinline__ void make_masks(uint32_t* mk, const uint32_t* mask_table_lds, uint32_t seed_i,
                                            uint32_t repeats, uint32_t len) {
@@ -265,14 +326,15 @@ __device__ __forceinline__ void make_masks(uint32_t* mk, const uint32_t* mask_ta
 // shift seed_i.  Edge filters of mapping.cpp:280-286; returns false when the
 // candidate is skipped.  gp_out = genome_pos - seed_i.
 template <int NW>
-__device__ __forceinline__ bool verify_candidate(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
-                                                 uint32_t slot_pos, uint32_t seed_i, uint32_t len,
+__device__ __forceinline__ bool verify_candidate(const StrandView& sv, const uint32_t* si, const uint32_t* __restrict__ gs,
+                                                 uint32_t n_chrom, uint32_t slot_pos, uint32_t seed_i, uint32_t len,
                                                  const uint32_t* rd, const uint32_t* mk, uint32_t& gp_out,
                                                  uint32_t& mm_out) {
-  uint32_t chr = chrom_id(si, n_chrom, slot_pos);
-  if (slot_pos - si[chr] < seed_i) return false;
+  uint32_t c_lo, c_hi;
+  chrom_bounds(si, gs, chrom_tab_of(n_chrom), slot_pos, c_lo, c_hi);
+  if (slot_pos - c_lo < seed_i) return false;
   uint32_t gp = slot_pos - seed_i;
-  if (gp + len >= si[chr + 1]) return false;
+  if (gp + len >= c_hi) return false;
   gp_out = gp;
   mm_out = count_mismatch<NW>(sv.g2, gp, rd, mk);
   return true;
@@ -689,18 +751,13 @@ __device__ __forceinline__ bool tail_care_ok(const StrandView& sv, uint32_t slot
 // 0 when the edge filters of mapping.cpp:280-286 reject the candidate)
 template <int NW>
 __device__ __forceinline__ void verify_nobranch(const StrandView& sv, const BlockShared& sh, const uint32_t* si,
-                                                uint32_t n_chrom, uint32_t top_step, bool active, uint32_t slot_pos,
+                                                const uint32_t* __restrict__ gs, uint32_t n_chrom, uint32_t top_step, bool active, uint32_t slot_pos,
                                                 uint32_t seed_i, uint32_t len, const uint32_t* rd,
                                                 const uint32_t* mk, bool& ok, uint32_t& gp, uint32_t& mm) {
   // chromosome starts from LDS when they fit (ds_read), else from HBM; uniform branch
   uint32_t c_lo, c_hi;
-  if (n_chrom <= kLdsChroms) {
-    const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, slot_pos);
-    c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
-  } else {
-    const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, slot_pos);
-    c_lo = si[chr]; c_hi = si[chr + 1];
-  }
+  (void)top_step; (void)si;
+  chrom_bounds(sh.start_index, gs, chrom_tab_of(n_chrom), slot_pos, c_lo, c_hi);
   const uint32_t g = slot_pos - seed_i;
   ok = active && (slot_pos - c_lo >= seed_i) && (g + len < c_hi);
   gp = ok ? g : 0u;
@@ -727,18 +784,13 @@ __device__ __forceinline__ void count_mismatch_regs_tail(const uint32_t* g, uint
 // tail_care_ok's two words): tail_ok = they all equal the read's
 template <int NW>
 __device__ __forceinline__ void verify_nobranch_tail(const StrandView& sv, const BlockShared& sh, const uint32_t* si,
-                                                     uint32_t n_chrom, uint32_t top_step, bool active, uint32_t slot_pos,
+                                                     const uint32_t* __restrict__ gs, uint32_t n_chrom, uint32_t top_step, bool active, uint32_t slot_pos,
                                                      uint32_t seed_i, uint32_t len, const uint32_t* rd,
                                                      const uint32_t* mk, uint32_t cut, bool& ok, uint32_t& gp, uint32_t& mm,
                                                      bool& tail_ok) {
   uint32_t c_lo, c_hi;
-  if (n_chrom <= kLdsChroms) {
-    const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, slot_pos);
-    c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
-  } else {
-    const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, slot_pos);
-    c_lo = si[chr]; c_hi = si[chr + 1];
-  }
+  (void)top_step; (void)si;
+  chrom_bounds(sh.start_index, gs, chrom_tab_of(n_chrom), slot_pos, c_lo, c_hi);
   const uint32_t g = slot_pos - seed_i;
   ok = active && (slot_pos - c_lo >= seed_i) && (g + len < c_hi);
   gp = ok ? g : 0u;
@@ -761,11 +813,11 @@ __device__ __forceinline__ bool win_usable(const StrandView& sv, uint32_t len) {
   return NW <= 10 && sv.wbits != nullptr && len <= (NW <= 7 ? kWinMaxLen1 : kWinMaxLen2);
 }
 template <int NW, int G>
-__device__ __forceinline__ void coop_verify_groups(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
-                                                   uint32_t l, uint32_t size, uint32_t base, uint32_t seed_i,
+__device__ __forceinline__ void coop_verify_groups(const StrandView& sv, const uint32_t* si, const uint32_t* __restrict__ gs,
+                                                   uint32_t n_chrom, uint32_t l, uint32_t size, uint32_t base, uint32_t seed_i,
                                                    uint32_t len, const uint32_t* rd, const uint32_t* mk,
                                                    uint32_t lane, const DenseRange& dr, uint32_t* gp, uint32_t* mm) {
-  const uint32_t top_step = top_step_of(n_chrom);
+  const ChromTab ct = chrom_tab_of(n_chrom);
   if constexpr (NW <= 10) {
     // EVERY lane issues EVERY load of a round (a lane without work reads the first words of g2: one broadcast
     // line).  A load under `if (lane has work)` sits in a divergent branch whose results are copied out before
@@ -793,8 +845,8 @@ __device__ __forceinline__ void coop_verify_groups(const StrandView& sv, const u
     for (int u = 0; u < G; ++u) {
       const uint32_t k = base + 64 * u + lane;
       pos[u] = dense[u] ? ra[u].x : epos[u];
-      const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos[u]);  // fixed trip count: the G chains interleave
-      const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+      uint32_t c_lo, c_hi;
+      chrom_bounds(si, gs, ct, pos[u], c_lo, c_hi);  // fixed trip count: the G chains interleave
       g[u] = pos[u] - seed_i;
       ok[u] = k < size && (pos[u] - c_lo >= seed_i) && (g[u] + len < c_hi);  // mapping.cpp:280-286
       gp[u] = ok[u] ? g[u] : 0u;
@@ -836,8 +888,8 @@ __device__ __forceinline__ void coop_verify_groups(const StrandView& sv, const u
     for (int u = 0; u < G; ++u) {
       const uint32_t k = base + 64 * u + lane;
       const uint32_t pos = sv.ent[l + (k < size ? k : size - 1)].pos;
-      const uint32_t chr = chrom_id_steps(si, n_chrom, top_step, pos);
-      const uint32_t c_lo = si[chr], c_hi = si[chr + 1];
+      uint32_t c_lo, c_hi;
+      chrom_bounds(si, gs, ct, pos, c_lo, c_hi);
       const uint32_t g = pos - seed_i;
       const bool ok = k < size && (pos - c_lo >= seed_i) && (g + len < c_hi);
       gp[u] = ok ? g : 0u;

@@ -363,9 +363,8 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
     if constexpr (FITS) {  // through the LDS array itself: through a pointer that may be either, the reads would be FLAT loads
       const uint32_t chr = chrom_id_steps(s_start, n_chrom, top_step, pos);
       c_lo = s_start[chr]; c_hi = s_start[chr + 1];
-    } else {
-      const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
-      c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
+    } else {  // more sequences than the LDS array holds: its samples, then the starts between two of them (map_common.h ChromTab)
+      walt::chrom_bounds(s_start, iv.start_index, chrom_tab_of(n_chrom), pos, c_lo, c_hi);
     }
   };
   // (the statically dealt items of a wavefront are n_waves apart: the largest come first in the numbering and are
@@ -529,7 +528,7 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
       if (done) break;
     }
   } else {
-    const uint32_t* si = FITS ? s_start : iv.start_index;
+    const uint32_t* si = s_start;
     for (;;) {
       const StrandView& sv = iv.s[strand_base + Sink::strand(id)];
       DenseRange none;
@@ -537,7 +536,7 @@ __device__ __forceinline__ void item_stream(const IndexView& iv, uint32_t strand
       none.rec = 0;
       for (uint32_t base = 0; base < size; base += 64) {
         uint32_t gp[1], mm[1];
-        coop_verify_groups<NW, 1>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, none, gp, mm);
+        coop_verify_groups<NW, 1>(sv, si, iv.start_index, n_chrom, l, size, base, seed_i, len, rd, mk, lane, none, gp, mm);
         sink.add(base + lane, gp[0], mm[0], base + lane < size);
         sink.step();
       }

@@ -128,7 +128,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         for (uint32_t k = 0; k < kSmallRegion; ++k) {  // static k: lk.pos[] stays in registers
           if (k < size) {
             uint32_t pos = k < lk.npos ? lk.pos[k] : sv.ent[reg.l + k].pos, gp, mm;
-            if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
+            if (verify_candidate<NW>(sv, si, iv.start_index, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
               ++n_verified;
               if (mm <= max_mm) {  // paired.cpp:192-195
                 HeapEnt e; e.pos = gp; e.mms = mm | (fi << 31);
@@ -156,7 +156,7 @@ __device__ __forceinline__ void pe_process(const IndexView& iv, BlockShared& sh,
         const DenseRange rb = dense_range(sv, o_l, o_size, win_usable<NW>(sv, o_len));
         for (uint32_t base = 0; base < o_size; base += 64 * kCoopUnroll) {
           uint32_t cgp[kCoopUnroll], cmm[kCoopUnroll];
-          coop_verify_groups<NW, (int)kCoopUnroll>(sv, si, n_chrom, o_l, o_size, base, seed_i, o_len, o_rd, o_mk, lane, rb,
+          coop_verify_groups<NW, (int)kCoopUnroll>(sv, si, iv.start_index, n_chrom, o_l, o_size, base, seed_i, o_len, o_rd, o_mk, lane, rb,
                                                    cgp, cmm);  // paired.cpp:166-190
 #pragma unroll
           for (uint32_t u = 0; u < kCoopUnroll; ++u) n_verified += cmm[u] != 0xFFFFFFFFu ? 1u : 0u;
@@ -309,8 +309,8 @@ __device__ __forceinline__ void pe_process_dual(const IndexView& iv, BlockShared
       if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
       bool ok_p, ok_m;
       uint32_t gp_p, gp_m, mm_p, mm_m;
-      verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
-      verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+      verify_nobranch<NW>(svp, sh, si, iv.start_index, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+      verify_nobranch<NW>(svm, sh, si, iv.start_index, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
       if (NW > 8) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
         // inactive lanes carry no valid position: read from 0 like verify_nobranch does
         const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, lr.repeats), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, lr.repeats);
@@ -583,8 +583,8 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
         if (act_m && k >= lm.npos) pos_m = svm.ent[lm.reg.l + k].pos;
         bool ok_p, ok_m;
         uint32_t gp_p, gp_m, mm_p, mm_m;
-        verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
-        verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+        verify_nobranch<NW>(svp, sh, si, iv.start_index, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+        verify_nobranch<NW>(svm, sh, si, iv.start_index, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
         if (NW > 8) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
           const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, lr.repeats), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, lr.repeats);
           ok_p = ok_p && (!tail_p || t_p);
@@ -624,13 +624,7 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
 #pragma unroll
             for (uint32_t k = jj; k < kPeMidRegion; k += 4) pos = (k == k0 + jj) ? posb[k] : pos;
             uint32_t c_lo, c_hi;
-            if (n_chrom <= kLdsChroms) {
-              const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, pos);
-              c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
-            } else {
-              const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
-              c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
-            }
+            chrom_bounds(sh.start_index, iv.start_index, chrom_tab_of(n_chrom), pos, c_lo, c_hi);
             const uint32_t g = pos - seed_i;
             ok[jj] = k0 + jj < nmid && (pos - c_lo >= seed_i) && (g + lr.len < c_hi);  // paired.cpp:166-171
             gpv[jj] = ok[jj] ? g : 0u;
@@ -826,9 +820,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? (NW <= 8 ? 6 : 4) : (NW <= 8 ? 4 : 
   __shared__ uint32_t s_start[kLdsChroms + 1];
   __shared__ uint32_t s_hist[kBlock / 64][64];
   __shared__ uint32_t s_edge[DENSE ? kEdgeWords : 1];  // (the dense verifier: core.h edge bitmap)
-  const bool fits = iv.n_chrom <= kLdsChroms;
-  if (fits)
-    for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  const bool fits = iv.n_chrom <= kLdsChroms;  // every chromosome start is in LDS (else every 2^shift-th: ChromTab)
+  chrom_tab_stage(s_start, iv.start_index, chrom_tab_of(iv.n_chrom));
   if (DENSE && iv.edge_bits != nullptr)
     for (uint32_t i = threadIdx.x; i < kEdgeWords; i += blockDim.x) s_edge[i] = iv.edge_bits[i];
   __syncthreads();

@@ -76,8 +76,8 @@ void launch_ascii_to_2bit(const uint8_t* d_bases, const uint64_t* d_offsets, uin
 // ---------------------------------------------------------------------------
 constexpr int kCoopGroupsSe = 2;  // 128 candidates per step (map_common.h coop_verify_groups)
 template <int NW>
-__device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const uint32_t* si, uint32_t n_chrom,
-                                                     uint32_t l, uint32_t size, uint32_t seed_i, uint32_t len,
+__device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const uint32_t* si, const uint32_t* __restrict__ gs,
+                                                     uint32_t n_chrom, uint32_t l, uint32_t size, uint32_t seed_i, uint32_t len,
                                                      const uint32_t* rd, const uint32_t* mk, uint32_t lane,
                                                      uint32_t& n_verified, const DenseRange* known = nullptr,
                                                      uint32_t abl = 0) {
@@ -90,7 +90,7 @@ __device__ __forceinline__ RegionSummary coop_region(const StrandView& sv, const
 #pragma unroll
       for (int u = 0; u < kCoopGroupsSe; ++u) { gp[u] = base + lane; mm[u] = (base + 64 * u + lane) < size ? (lane & 7u) : 0xFFFFFFFFu; }
     } else {
-      coop_verify_groups<NW, kCoopGroupsSe>(sv, si, n_chrom, l, size, base, seed_i, len, rd, mk, lane, rb, gp, mm);
+      coop_verify_groups<NW, kCoopGroupsSe>(sv, si, gs, n_chrom, l, size, base, seed_i, len, rd, mk, lane, rb, gp, mm);
     }
     if (abl & 32u) {  // diagnostic: loads and counts, no reduction
       uint32_t x = 0;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         for (uint32_t k = 0; k < kSmallRegion; ++k) {  // static k: lk.pos[] stays in registers
           if (k < size) {
             uint32_t pos = k < lk.npos ? lk.pos[k] : sv.ent[reg.l + k].pos, gp, mm;
-            if (verify_candidate<NW>(sv, si, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
+            if (verify_candidate<NW>(sv, si, iv.start_index, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
               sum = summary_merge(sum, summary_one(mm, gp));
               ++ctr.verified;
             }
@@ -268,7 +268,7 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
         }
         const uint32_t o_l = bcast(reg.l, owner), o_size = bcast(size, owner), o_len = bcast(lr.len, owner);
         uint32_t nv = 0;
-        RegionSummary s = coop_region<NW>(sv, si, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv);
+        RegionSummary s = coop_region<NW>(sv, si, iv.start_index, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv);
         ctr.verified += nv;
         if ((int)lane == owner) {
           fold_region(best, s, strand_char);
@@ -386,6 +386,7 @@ __device__ __forceinline__ void se_mid_regions(const IndexView& iv, const BlockS
 #pragma unroll
     for (uint32_t k = 0; k < kMidRegion; ++k) posb[k] = ent[k < nmid ? my_l + k : 0u].pos;  // (what a lane does not have: entry 0, one broadcast access)
     RegionSummary acc = summary_empty();
+    const ChromTab ct = chrom_tab_of(n_chrom);
 #pragma unroll 1
     for (uint32_t k0 = 0; k0 < kMidRegion; k0 += 4) {
       if (!__ballot(k0 < nmid)) break;
@@ -398,13 +399,8 @@ __device__ __forceinline__ void se_mid_regions(const IndexView& iv, const BlockS
 #pragma unroll
         for (uint32_t k = jj; k < kMidRegion; k += 4) pos = (k == k0 + jj) ? posb[k] : pos;
         uint32_t c_lo, c_hi;
-        if (n_chrom <= kLdsChroms) {
-          const uint32_t chr = chrom_id_steps(sh.start_index, n_chrom, top_step, pos);
-          c_lo = sh.start_index[chr]; c_hi = sh.start_index[chr + 1];
-        } else {
-          const uint32_t chr = chrom_id_steps(iv.start_index, n_chrom, top_step, pos);
-          c_lo = iv.start_index[chr]; c_hi = iv.start_index[chr + 1];
-        }
+        (void)top_step;
+        chrom_bounds(sh.start_index, iv.start_index, ct, pos, c_lo, c_hi);
         const uint32_t g = pos - seed_i;
         ok[jj] = k0 + jj < nmid && (pos - c_lo >= seed_i) && (g + len < c_hi);  // mapping.cpp:280-286
         if constexpr (MULTI) {
@@ -613,13 +609,13 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         if constexpr (kLong && kPat != 3) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
           bool t_p, t_m;
           const uint32_t cut = tail_care_cut(seed_i, seed_len);
-          verify_nobranch_tail<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, cut, ok_p, gp_p, mm_p, t_p);
-          verify_nobranch_tail<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, cut, ok_m, gp_m, mm_m, t_m);
+          verify_nobranch_tail<NW>(svp, sh, si, iv.start_index, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, cut, ok_p, gp_p, mm_p, t_p);
+          verify_nobranch_tail<NW>(svm, sh, si, iv.start_index, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, cut, ok_m, gp_m, mm_m, t_m);
           ok_p = ok_p && (!tail_p || t_p);
           ok_m = ok_m && (!tail_m || t_m);
         } else {
-        verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
-        verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+        verify_nobranch<NW>(svp, sh, si, iv.start_index, n_chrom, top_step, act_p, pos_p, seed_i, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+        verify_nobranch<NW>(svm, sh, si, iv.start_index, n_chrom, top_step, act_m, pos_m, seed_i, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
         if (kLong) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
           // inactive lanes carry no valid position: read from 0 like verify_nobranch does
           const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, seed_len), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, seed_len);
@@ -667,7 +663,7 @@ __device__ __forceinline__ void se_process_dual(const IndexView& iv, BlockShared
         o_dr.hi = bcast(fi ? dr_m.hi : dr_p.hi, owner);
         o_dr.rec = bcast((uint32_t)(fi ? dr_m.rec : dr_p.rec), owner);  // record numbers stay below 2^32 (build_windows)
         uint32_t nv = 0;
-        RegionSummary s = coop_region<NW>(sv, si, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv, &o_dr, ablate);
+        RegionSummary s = coop_region<NW>(sv, si, iv.start_index, n_chrom, o_l, o_size, seed_i, o_len, o_rd, o_mk, lane, nv, &o_dr, ablate);
         ctr_out.verified += nv;  // candidates of the OWNER's region that this lane verified
         if ((int)lane == owner) {
           if (fi) sum_m = s; else sum_p = s;
@@ -1103,8 +1099,8 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 
           uint32_t gp_p, gp_m, mm_p, mm_m;
           if constexpr (kLong && kPat != 3) {  // long seeds: a key-equal candidate still owes its care chars >= 44 (probe_resolve)
             bool t_p, t_m;
-            verify_nobranch_tail<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, sd, lr.len, lr.rd, mk, tail_cut, ok_p, gp_p, mm_p, t_p);
-            verify_nobranch_tail<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, sd, lr.len, lr.rd, mk, tail_cut, ok_m, gp_m, mm_m, t_m);
+            verify_nobranch_tail<NW>(svp, sh, si, iv.start_index, n_chrom, top_step, act_p, pos_p, sd, lr.len, lr.rd, mk, tail_cut, ok_p, gp_p, mm_p, t_p);
+            verify_nobranch_tail<NW>(svm, sh, si, iv.start_index, n_chrom, top_step, act_m, pos_m, sd, lr.len, lr.rd, mk, tail_cut, ok_m, gp_m, mm_m, t_m);
             mt.fb_p = mt.fb_p || (mt.multi_p && act_p && !ok_p);
             mt.fb_m = mt.fb_m || (mt.multi_m && act_m && !ok_m);
             mt.nin_p += (mt.multi_p && ok_p && t_p) ? 1u : 0u;
@@ -1112,8 +1108,8 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 
             ok_p = ok_p && (!tail_p || t_p);
             ok_m = ok_m && (!tail_m || t_m);
           } else {
-            verify_nobranch<NW>(svp, sh, si, n_chrom, top_step, act_p, pos_p, sd, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
-            verify_nobranch<NW>(svm, sh, si, n_chrom, top_step, act_m, pos_m, sd, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
+            verify_nobranch<NW>(svp, sh, si, iv.start_index, n_chrom, top_step, act_p, pos_p, sd, lr.len, lr.rd, mk, ok_p, gp_p, mm_p);
+            verify_nobranch<NW>(svm, sh, si, iv.start_index, n_chrom, top_step, act_m, pos_m, sd, lr.len, lr.rd, mk, ok_m, gp_m, mm_m);
             if (kLong) {  // long seeds: a single key-equal candidate still owes its care chars >= 44 (probe_resolve)
               // inactive lanes carry no valid position: read from 0 like verify_nobranch does
               const bool t_p = tail_care_ok(svp, act_p ? pos_p : 0u, care, seed_len), t_m = tail_care_ok(svm, act_m ? pos_m : 0u, care, seed_len);
@@ -1154,7 +1150,7 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 
             if (rg.l <= rg.u && rg.u - rg.l + 1 <= b) {
               for (uint32_t sl = rg.l; sl <= rg.u; ++sl) {
                 uint32_t gp_c, mm_c;
-                if (verify_candidate<NW>(sv, si, n_chrom, sv.ent[sl].pos, sd, lr.len, lr.rd, mk, gp_c, mm_c))
+                if (verify_candidate<NW>(sv, si, iv.start_index, n_chrom, sv.ent[sl].pos, sd, lr.len, lr.rd, mk, gp_c, mm_c))
                   acc = summary_merge(acc, summary_one(mm_c, gp_c));
               }
             }
@@ -1301,9 +1297,8 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
   if (n_items == 0) return;
   __shared__ uint32_t s_start[kLdsChroms + 1];
   __shared__ uint32_t s_edge[DENSE ? kEdgeWords : 1];  // (the dense verifier: core.h edge bitmap)
-  const bool fits = iv.n_chrom <= kLdsChroms;
-  if (fits)
-    for (uint32_t i = threadIdx.x; i <= iv.n_chrom; i += blockDim.x) s_start[i] = iv.start_index[i];
+  const bool fits = iv.n_chrom <= kLdsChroms;  // every chromosome start is in LDS (else every 2^shift-th: ChromTab)
+  chrom_tab_stage(s_start, iv.start_index, chrom_tab_of(iv.n_chrom));
   if (DENSE && iv.edge_bits != nullptr)
     for (uint32_t i = threadIdx.x; i < kEdgeWords; i += blockDim.x) s_edge[i] = iv.edge_bits[i];
   __syncthreads();
