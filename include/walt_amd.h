@@ -216,6 +216,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
  *   se_pipe        1  staged heavy pass in two halves on two streams
  *   se_heavy_chunk 0  reads per chunk of the heavy list (0: default; a test hook for several chunks on a small batch)
  *   se_lit_side    1  literal pass on a side stream beside the end of the heavy pass
+ *   se_lit_staged  0  reads with a truly dangerous probe go through staged rounds with the reference's search on instead
  *   se_defer_min  -1  long seeds: key-equal ranges of more slots than this go to the verifier unnarrowed (-1: default 4, 0: never)
  *   se_stage_occ   0  wavefronts per SIMD the stage kernel is built for (0: default, 3)
  *   se_carry       1  pass 1 hands its state to the staged rounds (0: they start over at seed 0)
@@ -224,7 +225,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
  *   pe_mode        0  0: staged path, 1: list kernels only
  *   pe_chunk       0  pairs per pass (0: default)          pe_rounds    0  rounds of a staged list (0: default, 1, 2, 4)
  *   pe_stage_cap   0  staged reads per round (0: default)  pe_small_heaps 0  force the 8-slot heaps of long literal lists
- *   pe_serial      0  mates and passes on one stream (profiling)
+ *   pe_serial      0  mates and passes on one stream (profiling)   pe_push_wide 0  4-byte heap entries in the push kernel (A/B)
  *   pe_defer_min  -1  as se_defer_min                      pe_roomy    -1  -1: by the workspace's size, 0 / 1: forced
  * Set between calls, not during one.  WALT_EINVAL for an unknown name. */
 int walt_index_set_option(walt_index* idx, const char* name, long long value);

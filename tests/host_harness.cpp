@@ -23,6 +23,7 @@ struct HStrand {
   std::vector<Ent> ent;
   std::vector<Outlier> outl;
   std::vector<uint32_t> outl_dir;
+  std::vector<OlevEnt> olev;
   std::vector<uint32_t> fen[kFenceLevels];
   StrandView view;
 };
@@ -59,6 +60,24 @@ static long tail_mask_words_differ(uint32_t seed_i, uint32_t seed_len) {
   }
 }
 
+// entry reads of the reference's bisection over the whole bucket (mapping.cpp:166-222): what lit_region loads
+static unsigned long long lit_region_steps(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
+  const uint32_t h = care[0] >> 8;
+  uint32_t l = sv.cnt[h], u = sv.cnt[h + 1];
+  if (l == u) return 0;
+  --u;
+  unsigned long long n = 0;
+  for (uint32_t p = kKeyWeight; p < seed_len; ++p) {
+    const int ch = (int)care_char(care, p);
+    uint32_t low = l, high = u;
+    while (low < high) { const uint32_t mid = low + (high - low) / 2; ++n; if (ent_char(sv, mid, p) >= ch) high = mid; else low = mid + 1; }
+    l = low; high = u;
+    while (low < high) { const uint32_t mid = low + (high - low + 1) / 2; ++n; if (ent_char(sv, mid, p) <= ch) low = mid; else high = mid - 1; }
+    u = low;
+    if (l == u) { ++n; if (ch != ent_char(sv, l, p)) break; }
+  }
+  return n;
+}
 extern "C" {
 
 void* hh_index_new(uint32_t n_chrom, const uint32_t* chrom_len, int dir_bits) {
@@ -105,7 +124,12 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
       s.outl.push_back(o);
     }
   }
-  std::sort(s.outl.begin(), s.outl.end(), [](const Outlier& x, const Outlier& y) { return x.h < y.h; });
+  std::sort(s.outl.begin(), s.outl.end(), [](const Outlier& x, const Outlier& y) {
+    if (x.h != y.h) return x.h < y.h;
+    if (x.q != y.q) return x.q < y.q;
+    if (x.key_hi != y.key_hi) return x.key_hi < y.key_hi;
+    return x.key_lo < y.key_lo;
+  });
   for (uint32_t j = 1; j < index_size; ++j) {
     const Ent a = s.ent[j - 1], b = s.ent[j];
     if (ent_key(a) > ent_key(b)) {
@@ -134,6 +158,15 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
   s.view.bloom = nullptr; s.view.bloom_mask = 0; s.view.outl = s.outl.data(); s.view.n_outl = (uint32_t)s.outl.size();
   s.view.outl_dir_mask = build_outlier_dir(s.outl.data(), s.view.n_outl, s.outl_dir) - 1;
   s.view.outl_dir = s.outl_dir.data();
+  // the level table (core.h StrandView::olev); WALT_AMD_TEST_NO_OLEV=1: the walk over the bucket's outliers instead
+  {
+    std::vector<uint32_t> collided;
+    const uint32_t ents = build_outlier_levels(s.outl.data(), s.view.n_outl, s.olev, collided);
+    for (uint32_t hb : collided) s.bad[hb >> 5] |= 1u << (hb & 31);
+    const bool off = getenv("WALT_AMD_TEST_NO_OLEV") != nullptr;
+    s.view.olev = off ? nullptr : s.olev.data();
+    s.view.olev_mask = ents - 1;
+  }
   s.view.wbits = nullptr; s.view.wrank = nullptr; s.view.win = nullptr; s.view.win2 = nullptr; s.view.wcap = 0;
   // fence keys (core.h StrandView::fen; device_index.hip k_make_fences); WALT_AMD_FENCE=0: the k-ary search instead
   {
@@ -316,14 +349,29 @@ int hh_region_check(void* hp, const char* bases, const uint64_t* offsets, uint32
         if (probe_is_dangerous(sv, care, seed_len)) {
           // the literal route: from the level the danger starts at (core.h probe_danger_level) against the whole bucket
           ++out4[2];
-          Lookup from_level, whole;
+          // ... and the memoised search (core.h lit_region_memo: the product's route) against both, from the level and
+          // over the whole bucket
+          Lookup from_level, whole, memo_level, memo_whole, inferred;
+          unsigned long long* const keep = memo_stats();
+          memo_stats() = nullptr;  // (counted once: the product's route below)
+          literal_mode_flag() = 0;
           literal_from_level_flag() = true;
           seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, from_level, false);
           literal_from_level_flag() = false;
           seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, whole, false);
+          literal_mode_flag() = 1;
+          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, memo_whole, false);
           literal_from_level_flag() = true;
-          const bool e1 = from_level.reg.l > from_level.reg.u, e2 = whole.reg.l > whole.reg.u;
-          if (e1 != e2 || (!e1 && (from_level.reg.l != whole.reg.l || from_level.reg.u != whole.reg.u))) ++out4[1];
+          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, memo_level, false);
+          literal_mode_flag() = 2;
+          memo_stats() = keep;
+          seed_lookup_ex(iv, sv, care, care[kCareWords], care[kCareWords + 1], seed_len, inferred, false);
+          if (keep) keep[5] += lit_region_steps(sv, care, seed_len);  // entry reads of the reference's own search
+          const bool e2 = whole.reg.l > whole.reg.u;
+          for (const Lookup* x : {&from_level, &memo_level, &memo_whole, &inferred}) {
+            const bool e1 = x->reg.l > x->reg.u;
+            if (e1 != e2 || (!e1 && (x->reg.l != whole.reg.l || x->reg.u != whole.reg.u))) { ++out4[1]; break; }
+          }
           continue;
         }
         Lookup fast;
@@ -347,6 +395,17 @@ int hh_region_check(void* hp, const char* bases, const uint64_t* offsets, uint32
     }
   }
   return 0;
+}
+
+// counters of the memoised literal searches made since the last call (core.h memo_stats): [0] dangerous probes searched,
+// [1] of them through the memo, [2] entry loads they made, [3] bytes the reference's bisection reads in them
+// counters since the last call (core.h memo_stats): [0] dangerous probes searched, [1] of them by the inferred search,
+// [2] entries it loaded, [3] key searches it made, [4] steps it simulated, [5] entry reads of the reference's search
+// [6 + c], c < 64: inferred searches that made c key searches + entry loads (63: that many or more)
+void hh_memo_stats(uint64_t* out70) {
+  static unsigned long long acc[70] = {};
+  for (int i = 0; i < 70; ++i) { out70[i] = acc[i]; acc[i] = 0; }
+  memo_stats() = acc;
 }
 
 // Care characters >= 44 narrowed by the verifier against IndexRegion: for every safe probe of a

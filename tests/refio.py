@@ -158,6 +158,7 @@ def harness():
         L.hh_get_nocare.argtypes = [vp]
         L.hh_region_check.argtypes = [vp, vp, vp, u32, ci, vp]
         L.hh_tail_check.argtypes = [vp, vp, vp, u32, ci, vp]
+        L.hh_memo_stats.argtypes = [vp]
         L.hh_kary_check.argtypes = [u32, u32]
         L.hh_kary_check.restype = ctypes.c_long
         L.hh_fence_check.argtypes = [u32, u32]
@@ -332,6 +333,14 @@ class HarnessIndex:
         rc = harness().hh_region_check(self.h, bases.ctypes.data, offsets.ctypes.data, len(seqs), int(ag),
                                        out.ctypes.data)
         assert rc == 0, rc
+        return [int(v) for v in out]
+
+    @staticmethod
+    def memo_stats():
+        """counters of the memoised literal searches since the last call (host_harness.cpp hh_memo_stats): dangerous probes
+        searched, of them through the memo, entry loads they made, bytes the reference's bisection reads in them"""
+        out = np.zeros(70, dtype=np.uint64)
+        harness().hh_memo_stats(out.ctypes.data)
         return [int(v) for v in out]
 
     def tail_check(self, seqs, ag=False):

@@ -53,12 +53,12 @@ def test_cli_output_files_identical_to_reference(cli_index, scratch, case):
 
 
 @pytest.mark.parametrize("env", [{"se_pipe": "0"}, {"se_pipe": "0", "se_heavy_chunk": "64"},
-                                 {"se_heavy_chunk": "64"}, {"se_lit_side": "0"}, {"se_carry": "0", "se_heavy_chunk": "64"}])
+                                 {"se_heavy_chunk": "64"}, {"se_lit_side": "0"}, {"se_lit_staged": "1"}, {"se_carry": "0", "se_heavy_chunk": "64"}])
 @pytest.mark.parametrize("case", ["se_sam_au", "se150_ag_sam_au_m10"])
 def test_cli_single_end_schedules_give_the_same_files(cli_index, scratch, case, env):
     """The staged heavy pass has two schedules -- two halves of the heavy list on two streams, each with its own state
     slot and the list cut evenly on the device (default), or one stream in chunks (option se_pipe = 0) -- the literal
-    pass runs beside its end or after it (se_lit_side = 0), and the staged rounds go on from pass 1's state or start over
+    pass runs beside its end, after it (se_lit_side = 0) or as staged rounds (se_lit_staged = 1), and the staged rounds go on from pass 1's state or start over
     (se_carry = 0).  Each combination through the command line (-X name=value), with chunks of 64 reads so that several
     chunks, both slots and the later chunks' wait for the literal snapshot are all exercised; the files must be the
     reference's."""

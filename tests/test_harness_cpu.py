@@ -255,6 +255,54 @@ def test_harness_outlier_stress_low_entropy(scratch, seed):
         h.close()
 
 
+@pytest.mark.parametrize("n_contigs,genome_bp", [(400, 1_500_000), (3000, 400_000)])
+def test_harness_inferred_literal_search(scratch, n_contigs, genome_bp):
+    """The literal search of a dangerous probe, inferred (core.h lit_region_inferred, the product's route): the reference's
+    bisection is followed mid by mid, but an entry is loaded only where its byte cannot be known from the key search's
+    boundaries.  On a low-entropy genome (large buckets) with hundreds / thousands of contig ends -- sparse and crowded
+    outliers -- every dangerous probe must get the region of the plain search over the whole bucket (and of the memoised
+    and from-the-level routes), with a fraction of its entry reads."""
+    rng = random.Random(4242 + n_contigs)
+    long_seq = "".join(rng.choice("TTTTTTCCAGAG") for _ in range(genome_bp))
+    seqs = [("long", long_seq)]
+    for i in range(n_contigs):
+        L = rng.choice([60, 90, 150, 300, 500])
+        a = rng.randrange(0, len(long_seq) - L)
+        s = list(long_seq[a:a + L])
+        for _ in range(rng.randrange(0, 4)):
+            s[rng.randrange(L)] = rng.choice("ACGT")
+        seqs.append(("c%d" % i, "".join(s)))
+    fa = os.path.join(scratch, "inf_%d.fa" % n_contigs)
+    with open(fa, "w") as f:
+        for nm, s in seqs:
+            f.write(">%s\n%s\n" % (nm, s))
+    idxp = os.path.join(scratch, "inf_%d.dbindex" % n_contigs)
+    assert refio.harness().walt_makedb(fa.encode(), idxp.encode(), 4) == 0
+    db = refio.DbIndex(idxp)
+    reads = []
+    for _ in range(3000):
+        L = rng.choice([60, 100, 100, 100, 150])
+        a = rng.randrange(0, len(long_seq) - L)
+        s = long_seq[a:a + L]
+        if rng.random() < 0.5:
+            s = refio.revcomp(s)
+        s = "".join("T" if (c == "C" and rng.random() < 0.95) else c for c in s)
+        s = "".join(rng.choice("ACGT") if rng.random() < 0.01 else c for c in s)
+        reads.append(s)
+    h = refio.HarnessIndex(db, 24)
+    refio.HarnessIndex.memo_stats()  # (switches the counters on)
+    probes, differ, dangerous, _ = h.region_check(reads)
+    searched, inferred, loads, searches, steps, ref_reads = refio.HarnessIndex.memo_stats()[:6]
+    assert differ == 0, "%d of %d probes: the routes of the literal search disagree" % (differ, probes)
+    assert dangerous > 300 and inferred == dangerous, (dangerous, inferred)
+    assert ref_reads > 30 * dangerous, (ref_reads, dangerous)                        # the reference's bisection: tens of reads per probe
+    assert loads < 2 * dangerous and searches < 8 * dangerous, (loads, searches, dangerous)  # inferred: a few searches, hardly a load
+    want, _ = refio.oracle_se(db, reads, max_mm=6, b=5000)
+    got, _ = h.map_se(reads, False, 6, 5000)
+    assert_best_equal(got, want, "inferred literal search")
+    h.close()
+
+
 def test_round_based_kary_search_equals_the_two_sided_search():
     """core.h kary_round (heavy stages: both strands' slots advanced in one loop, eight pivots per round, shared by
     the lower- and the upper-bound search while their ranges coincide) must return the equal range that

@@ -37,6 +37,10 @@
 #define WALT_AMD_CORE_H_
 
 #include <stdint.h>
+#if !defined(__HIPCC__)
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #if defined(__HIPCC__)
 #define WALT_HD __host__ __device__ __forceinline__
@@ -111,6 +115,16 @@ struct StrandView {
   const struct Outlier* outl;  // chromosome-end entries, sorted by bucket (see probe_is_dangerous)
   const uint32_t* outl_dir;    // open-addressing table bucket -> first outlier: pairs {bucket + 1 (0 = free), index}
   uint32_t outl_dir_mask;      // pairs - 1 (power of two); outl_dir == nullptr: binary search
+  // Outlier levels (DERIVED, round 4): which outliers does a probe share its characters 12..q-1 with?  The walk over all
+  // outliers of the probe's bucket answered that with one DEPENDENT load per outlier -- hundreds in the T-rich buckets of
+  // an assembly of thousands of contigs, and the slowest lane of a wavefront decides.  olev is a hash table keyed by
+  // (bucket, q, the outliers' characters 12..q-1): value = how many outliers have that key, and the largest real byte
+  // any of them holds at character q (bits 30..31); plus one entry per bucket under the pseudo-level kOlevBucket whose
+  // value is the set of q that occur in the bucket.  A probe looks its own characters up level by level: independent
+  // loads, four at a time.  nullptr: the walk.
+  const struct OlevEnt* olev;
+  uint32_t olev_mask;          // entries - 1 (a power of two)
+  uint32_t olev_pad_;
   // Dense candidate windows (DERIVED).  A region of thousands of candidates (satellites,
   // young SINE / LINE copies: 2 % of the reads of an hg19-like genome own 90 % of all candidates) is a run of
   // consecutive index slots, but the genome windows behind them are scattered: one random 128-byte line per
@@ -393,6 +407,162 @@ WALT_HD Region lit_region(const StrandView& sv, const uint32_t* care, uint32_t p
   Region r; r.l = l; r.u = u; return r;
 }
 
+// first care character index (>= 12) of an entry that lies at or beyond the end of
+// its chromosome; room = chromosome end - pos.  kNumCare when every character fits.
+WALT_HD uint32_t first_beyond(uint32_t room) {
+  uint32_t q;
+  if (kPat == 3) {
+    // care_pos(q) = 1 + 3 q >= room  <=>  q >= (room - 1) / 3 rounded up
+    q = room <= 1 ? 0u : (room - 1 + 2) / 3;
+  } else {
+    q = 0;
+    while (q < kNumCare && care_pos(q) < room) ++q;
+  }
+  return q < kKeyWeight ? kKeyWeight : q;
+}
+
+
+WALT_HD uint64_t key_mask_fwd(uint32_t nk) { return nk >= 32 ? ~0ull : ~(~0ull >> (2 * nk)); }  // (= key_mask)
+
+// ---- the literal search with a memo (round 4) ---------------------------------------------------------------------
+// lit_region above loads an entry for every step of every bisection: ~170 dependent loads for a dangerous probe into a
+// bucket of tens of thousands of entries, and an assembly of thousands of contigs sends a fifth of its reads there.
+// This is the SAME procedure -- the reference's mids, character by character (mapping.cpp:166-222) -- but the byte the
+// reference would read at (mid, p) is taken from what is already known whenever that is certain:
+//   * an entry that has been loaded is kept with its whole key (one load gives the characters 12..43 of an entry, the
+//     reference re-reads the entry for every character) and with q, the first of its care characters that lies beyond
+//     its chromosome's end (from its position and the chromosome starts);
+//   * FACT S: let a < mid < b be index slots of one bucket, a and b loaded, their keys equal on the characters 12..p,
+//     and q(a) > p (a's characters through p lie inside its chromosome).  makedb's order (reference.cpp:258-288) is
+//     the order of the strings (real characters ..., then "beyond the chromosome's end", which ranks below every base
+//     and ends the comparison).  a's sort key through p is its real characters.  b cannot carry a "beyond" mark at or
+//     before p: it would share a's characters in front of the mark and rank BELOW a.  So a and b have the same,
+//     mark-free sort key through p, every entry between them has it too, an entry whose sort key through p is free of
+//     marks has real characters there -- the byte at (mid, p) is a's character p.  (A bucket whose order the outliers
+//     do not explain is BAD and never comes here: it is searched by lit_region.)
+//   * anything else is loaded, as before.
+// What comes back is lit_region's result by construction: every comparison uses the byte the reference reads.
+// tests/test_harness_cpu.py compares the two routes for every dangerous probe of the stress genomes.
+constexpr uint32_t kMemoCap = 4;    // loaded entries kept (registers on the device: every access is an unrolled select)
+struct LitMemo {
+  uint32_t idx[kMemoCap], khi[kMemoCap], klo[kMemoCap], pos[kMemoCap], q[kMemoCap];
+  uint32_t n;
+  uint32_t loads, probes;  // (diagnostic: entry loads made / bytes the reference would have read)
+};
+WALT_HD void memo_init(LitMemo& m) {
+  m.n = 0; m.loads = 0; m.probes = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (uint32_t k = 0; k < kMemoCap; ++k) { m.idx[k] = 0; m.khi[k] = 0; m.klo[k] = 0; m.pos[k] = 0; m.q[k] = 0; }
+}
+// q of an entry from the chromosome starts in device / host memory (the kernels pass a functor over their LDS copy)
+struct QOfGlobal {
+  const uint32_t* start_index;
+  uint32_t n_chrom;
+  WALT_HD uint32_t operator()(uint32_t pos) const {
+    uint32_t l = 0, h = n_chrom;
+    while (l < h) {
+      const uint32_t m = (l + h + 1) >> 1;
+      if (pos >= start_index[m]) l = m; else h = m - 1;
+    }
+    return first_beyond(start_index[l + 1] - pos);
+  }
+};
+// keep (j, e); when full, drop an entry outside [l, u] (it can never serve again: it left the range because one of its
+// characters differs from the probe's) -- the one farthest out -- else the one farthest from j
+WALT_HD void memo_insert(LitMemo& m, uint32_t j, const Ent& e, uint32_t qv, uint32_t l, uint32_t u) {
+  uint32_t at = m.n;
+  if (m.n >= kMemoCap) {
+    uint32_t best = 0, best_out = 0, best_far = 0;
+    bool any_out = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < kMemoCap; ++k) {
+      const uint32_t x = m.idx[k];
+      const uint32_t out = x < l ? l - x : (x > u ? x - u : 0u);
+      const uint32_t far = x < j ? j - x : x - j;
+      const bool better = out ? (!any_out || out > best_out) : (!any_out && far > best_far);
+      if (k == 0 || better) { best = k; best_out = out; best_far = far; }
+      any_out = any_out || out != 0;
+    }
+    at = best;
+  } else {
+    ++m.n;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (uint32_t k = 0; k < kMemoCap; ++k)
+    if (k == at) { m.idx[k] = j; m.khi[k] = e.key_hi; m.klo[k] = e.key_lo; m.pos[k] = e.pos; m.q[k] = qv; }
+}
+// genome.sequence[index[j] + F2CAREDPOSITION[p]] (ent_char) for kKeyWeight <= p < kKeyWeight + kKeyChars, through the memo;
+// [l, u] = the reference's current range (for the eviction only)
+template <class QOf>
+WALT_HD int memo_char(const StrandView& sv, LitMemo& m, const QOf& q_of, uint32_t j, uint32_t p, uint32_t l, uint32_t u) {
+  ++m.probes;
+  bool has_a = false, has_b = false;
+  uint32_t a_idx = 0, b_idx = 0, a_hi = 0, a_lo = 0, a_pos = 0, a_q = 0, b_hi = 0, b_lo = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (uint32_t k = 0; k < kMemoCap; ++k) {
+    const bool live = k < m.n;
+    const uint32_t x = m.idx[k];
+    const bool ta = live && x <= j && (!has_a || x > a_idx);
+    const bool tb = live && x >= j && (!has_b || x < b_idx);
+    if (ta) { has_a = true; a_idx = x; a_hi = m.khi[k]; a_lo = m.klo[k]; a_pos = m.pos[k]; a_q = m.q[k]; }
+    if (tb) { has_b = true; b_idx = x; b_hi = m.khi[k]; b_lo = m.klo[k]; }
+  }
+  const uint32_t sh = 2 * (kKeyWeight + kKeyChars - 1 - p);
+  if (has_a && a_idx == j) {  // loaded before: its real byte, as the reference reads it (beyond the genome: below every base)
+    if ((uint64_t)a_pos + care_pos(p) >= sv.genome_len) return -1;
+    return (int)(((((uint64_t)a_hi << 32) | a_lo) >> sh) & 3u);
+  }
+  if (has_a && has_b && a_q > p) {
+    const uint64_t ka = ((uint64_t)a_hi << 32) | a_lo, kb = ((uint64_t)b_hi << 32) | b_lo;
+    if (((ka ^ kb) & key_mask_fwd(p - kKeyWeight + 1)) == 0) return (int)((ka >> sh) & 3u);  // FACT S
+  }
+  const Ent e = sv.ent[j];
+  ++m.loads;
+  memo_insert(m, j, e, q_of(e.pos), l, u);
+  if ((uint64_t)e.pos + care_pos(p) >= sv.genome_len) return -1;
+  return (int)((ent_key(e) >> sh) & 3u);
+}
+// IndexRegion (mapping.cpp:198-222) for the characters [p0, seed_len) on [l, u], the key characters through the memo
+template <class QOf>
+WALT_HD Region lit_region_memo(const StrandView& sv, const uint32_t* care, uint32_t p0, uint32_t seed_len, uint32_t l,
+                               uint32_t u, LitMemo& m, const QOf& q_of) {
+  const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
+  if (l < u && p0 < lim) {  // both ends of the range: two independent loads, usually the anchors of the first characters
+    const Ent el = sv.ent[l], eu = sv.ent[u];
+    m.loads += 2;
+    memo_insert(m, l, el, q_of(el.pos), l, u);
+    memo_insert(m, u, eu, q_of(eu.pos), l, u);
+  }
+  uint32_t p = p0;
+  for (; p < lim; ++p) {
+    const int ch = (int)care_char(care, p);
+    uint32_t low = l, high = u;
+    while (low < high) {  // LowerBound, mapping.cpp:166-180
+      const uint32_t mid = low + (high - low) / 2;
+      if (memo_char(sv, m, q_of, mid, p, l, u) >= ch) high = mid; else low = mid + 1;
+    }
+    l = low;
+    high = u;
+    while (low < high) {  // UpperBound, mapping.cpp:182-196
+      const uint32_t mid = low + (high - low + 1) / 2;
+      if (memo_char(sv, m, q_of, mid, p, l, u) <= ch) low = mid; else high = mid - 1;
+    }
+    u = low;
+    if (l == u && ch != memo_char(sv, m, q_of, l, p, l, u)) return empty_region();
+  }
+  if (p < seed_len) return lit_region(sv, care, p, seed_len, l, u);  // characters >= 44: on the genome itself
+  if (l > u) return empty_region();
+  Region r; r.l = l; r.u = u; return r;
+}
+
 // Target key (care chars 12..43 of the read's care string) and the mask of its
 // first nk chars.
 WALT_HD uint64_t target_key(const uint32_t* care) {
@@ -475,6 +645,82 @@ WALT_HD bool danger_filter_hit(uint64_t block, const uint32_t* care) {
 WALT_HD uint64_t key_mask(uint32_t nk);
 WALT_HD uint64_t target_key(const uint32_t* care);
 
+// ---- outlier levels (StrandView::olev) ------------------------------------------------------------------------------
+struct OlevEnt {
+  uint32_t fp_lo, fp_hi;  // fingerprint of (bucket, q, characters 12..q-1); 0, 0 = free
+  uint32_t value;         // level entry: count (bits 0..29) | largest real byte at character q << 30; bucket entry: the q set, bit q - 12
+  uint32_t pad;
+};
+constexpr uint32_t kOlevBucket = 63;  // pseudo-level of the per-bucket entry
+WALT_HD uint64_t olev_fp(uint32_t h, uint32_t q, uint64_t key_masked) {
+  uint64_t x = key_masked + 0x9E3779B97F4A7C15ull * ((((uint64_t)h) << 6) | q);
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return x | (1ull << 63);  // never (0, 0)
+}
+WALT_HD uint32_t olev_slot(uint64_t fp, uint32_t mask) { return (uint32_t)(fp >> 8) & mask; }
+// value of fingerprint fp, 0 when absent; `first` = the entry at fp's home slot, already loaded
+WALT_HD uint32_t olev_resolve(const StrandView& sv, uint64_t fp, OlevEnt first) {
+  uint32_t slot = olev_slot(fp, sv.olev_mask);
+  OlevEnt e = first;
+  for (;;) {
+    if (e.fp_lo == 0 && e.fp_hi == 0) return 0;
+    if (e.fp_lo == (uint32_t)fp && e.fp_hi == (uint32_t)(fp >> 32)) return e.value;
+    slot = (slot + 1) & sv.olev_mask;
+    e = sv.olev[slot];
+  }
+}
+WALT_HD uint32_t olev_find(const StrandView& sv, uint64_t fp) { return olev_resolve(sv, fp, sv.olev[olev_slot(fp, sv.olev_mask)]); }
+// The outliers a probe shares its characters 12..q-1 with, q < lim: levels = the set of their q (bit q - 12); dangerous =
+// one of them holds, at its character q, a real byte that is not below the probe's (probe_danger_level's rule); q_min.
+// Four independent look-ups per round.  Returns false when the strand has no level table (the caller walks).
+WALT_HD bool olev_relevant(const StrandView& sv, uint32_t h, uint64_t T, uint32_t lim, uint32_t& levels, bool& dangerous,
+                           uint32_t& q_min) {
+  levels = 0; dangerous = false; q_min = 0xFFFFFFFFu;
+  if (sv.olev == nullptr) return false;
+  uint32_t m = olev_find(sv, olev_fp(h, kOlevBucket, 0));  // the q that occur in the bucket at all
+  const uint32_t span = lim > kKeyWeight ? lim - kKeyWeight : 0u;
+  m = span >= 32 ? m : (m & ((1u << span) - 1u));
+  while (m) {
+    uint32_t qs[4];
+    uint64_t fps[4];
+    OlevEnt es[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t t = 0; t < 4; ++t) {
+      uint32_t z = 0;
+      if (m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        z = (uint32_t)__ffs((int)m) - 1u;
+#else
+        z = (uint32_t)__builtin_ctz(m);
+#endif
+        m &= m - 1;
+        qs[t] = kKeyWeight + z;
+      } else {
+        qs[t] = 0;  // (no level: the bucket entry's slot, a load that is certain to hit the cache)
+      }
+      fps[t] = qs[t] ? olev_fp(h, qs[t], T & key_mask_fwd(qs[t] - kKeyWeight)) : olev_fp(h, kOlevBucket, 0);
+      es[t] = sv.olev[olev_slot(fps[t], sv.olev_mask)];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t t = 0; t < 4; ++t) {
+      if (!qs[t]) continue;
+      const uint32_t v = olev_resolve(sv, fps[t], es[t]);
+      if (!v) continue;
+      levels |= 1u << (qs[t] - kKeyWeight);
+      q_min = qs[t] < q_min ? qs[t] : q_min;
+      const uint32_t sh = 2 * (kKeyWeight + kKeyChars - 1 - qs[t]);
+      if (!((uint32_t)((T >> sh) & 3u) > (v >> 30))) dangerous = true;
+    }
+  }
+  return true;
+}
+
 // Does this probe have to take the literal LowerBound/UpperBound search?
 WALT_HD uint32_t outl_dir_hash(uint32_t h) {
   uint32_t x = h * 0x9E3779B1u;
@@ -492,6 +738,12 @@ WALT_HD uint32_t outl_dir_hash(uint32_t h) {
 WALT_HD uint32_t probe_danger_level(const StrandView& sv, const uint32_t* care, uint32_t seed_len) {
   const uint32_t h = care[0] >> 8;
   if (bucket_is_bad(sv, h)) return kKeyWeight;
+  {
+    uint32_t levels, q_first;
+    bool dng;
+    const uint32_t lim_t = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
+    if (olev_relevant(sv, h, target_key(care), lim_t, levels, dng, q_first)) return dng ? q_first : 0u;
+  }
   uint32_t lo = 0, hi = sv.n_outl;  // first outlier of bucket h
   if (sv.outl_dir) {
     // one or two loads instead of log2(n_outl) dependent ones (this test runs for every probe of pass 2)
@@ -559,8 +811,9 @@ constexpr uint32_t kLookupPos = 4;  // == kSmallRegion of the kernels
 // per search with INDEPENDENT loads: ~log4(n) + 1 memory round trips instead of the ~2 log2(n) + 4 of two
 // binary searches (a 4,096-entry slot: 7 instead of 28), which every wavefront with such a lane waits for.
 constexpr uint32_t kKary = 4;
-WALT_HD bool slot_kary_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a,
-                              uint32_t& u) {
+// (bounds: b1 = first index in [lo, hi) whose masked key is >= T, b2 = first whose masked key is > T; hi when there is none)
+WALT_HD void slot_kary_bounds(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& b1,
+                              uint32_t& b2) {
   uint32_t x1 = lo, y1 = hi;  // first index whose masked key is >= T lies in [x1, y1]
   uint32_t x2 = lo, y2 = hi;  // first index whose masked key is >  T lies in [x2, y2]
   while (y1 > x1 || y2 > x2) {
@@ -615,6 +868,12 @@ WALT_HD bool slot_kary_search(const StrandView& sv, uint32_t lo, uint32_t hi, ui
       x2 = nx; y2 = ny;
     }
   }
+  b1 = x1; b2 = x2;
+}
+WALT_HD bool slot_kary_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a,
+                              uint32_t& u) {
+  uint32_t x1, x2;
+  slot_kary_bounds(sv, lo, hi, T, M, x1, x2);
   if (x2 <= x1) return false;
   a = x1;
   u = x2 - 1;
@@ -769,7 +1028,7 @@ WALT_HD uint32_t fence_count4(const FencePlan& p, const uint64_t* k, uint32_t fi
   return c;
 }
 // one lane, one slot, both searches in lock-step (the kernels' dual-strand form is map_common.h fence_round_dual)
-WALT_HD bool slot_fence_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a, uint32_t& u) {
+WALT_HD void slot_fence_bounds(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& o1, uint32_t& o2) {
   uint32_t x1 = lo, y1 = hi, x2 = lo, y2 = hi;
   while (y1 > x1 || y2 > x2) {
     const FencePlan p1 = fence_plan(sv, x1, y1), p2 = fence_plan(sv, x2, y2);
@@ -793,10 +1052,21 @@ WALT_HD bool slot_fence_search(const StrandView& sv, uint32_t lo, uint32_t hi, u
     fence_narrow(p1, 4 * q1 + fence_count4(p1, b1, 4 * q1, 1, 3, T, M, true), x1, y1);
     fence_narrow(p2, 4 * q2 + fence_count4(p2, b2, 4 * q2, 1, 3, T, M, false), x2, y2);
   }
+  o1 = x1; o2 = x2;
+}
+WALT_HD bool slot_fence_search(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& a, uint32_t& u) {
+  uint32_t x1, x2;
+  slot_fence_bounds(sv, lo, hi, T, M, x1, x2);
   if (x2 <= x1) return false;
   a = x1;
   u = x2 - 1;
   return true;
+}
+// [b1, b2) = the entries of [lo, hi) whose masked key equals T (b1 == b2: where it would be) -- [lo, hi) sorted on the masked key
+WALT_HD void masked_bounds(const StrandView& sv, uint32_t lo, uint32_t hi, uint64_t T, uint64_t M, uint32_t& b1, uint32_t& b2) {
+  if (hi <= lo) { b1 = b2 = lo; return; }
+  if (sv.fen[0] != nullptr) slot_fence_bounds(sv, lo, hi, T, M, b1, b2);
+  else slot_kary_bounds(sv, lo, hi, T, M, b1, b2);
 }
 
 // The same narrowing for care chars >= 44 on a key-equal range of at most kLookupPos slots whose
@@ -907,10 +1177,177 @@ WALT_HD void slot_scan_more(const StrandView& sv, uint32_t lo, uint32_t ne, uint
 // (A/B and the harness's cross-check: 0 = every dangerous probe searched literally over its whole bucket, as before round 3)
 #if defined(__HIP_DEVICE_COMPILE__)
 WALT_HD bool literal_from_level() { return true; }
+WALT_HD int literal_mode() { return 2; }
+WALT_HD unsigned long long* memo_stats() { return nullptr; }
 #else
 inline bool& literal_from_level_flag() { static bool on = true; return on; }
 inline bool literal_from_level() { return literal_from_level_flag(); }
+// the memoised literal search (lit_region_memo) on / off, and -- harness only -- its counters: [0] dangerous probes searched,
+// [1] of them with the memo, [2] entry loads the memoised searches made, [3] bytes the reference reads in them
+// 0: lit_region, 1: lit_region_memo, 2: lit_region_inferred (the product's)
+inline int& literal_mode_flag() { static int mode = 2; return mode; }
+inline int literal_mode() { return literal_mode_flag(); }
+inline unsigned long long*& memo_stats() { static unsigned long long* p = nullptr; return p; }
 #endif
+
+// ---- the literal search, inferred (round 4) ---------------------------------------------------------------------------
+// IndexRegion (mapping.cpp:198-222) over a whole bucket [first, second) for a probe the key search may not answer
+// (probe_danger_level), with the reference's own mids -- but an entry is only loaded where its byte cannot be known.
+// Notation: T = the probe's characters; G_p = the index range of the entries whose makedb sort key (reference.cpp:258-288:
+// real characters, then "beyond the chromosome's end", which ranks below every base and ends the comparison) equals T's
+// on the characters 12..p-1; its HEADS = the entries of G_p whose character p lies beyond their chromosome (outliers with
+// q = p that share T's characters in front of it: the outlier table lists them all, their number is k); the rest of G_p,
+// its STRETCH [cl + k, cu), holds entries whose character p is real, in ascending order of it.
+//   * A step p whose range is exactly G_p with no heads is an ordinary bisection over sorted characters: it returns the
+//     entries of G_p whose character p is T's = G_(p+1), or the empty marker.  Runs of such steps are taken at once: the
+//     equal range of T's characters 12..p'-1 inside the stretch (masked_bounds: the masked keys are monotone there -- an
+//     entry with a "beyond" mark among those characters either differs from T in front of the mark, where it is sorted on
+//     real characters, or is a head of one of T's own groups, and p' is chosen as the next level that has heads).
+//   * Any other step -- heads in G_p, or a range that still holds entries from outside G_p (heads of earlier levels, or
+//     entries the reference's bisection was misled to keep) -- is SIMULATED with the reference's mids: a mid inside the
+//     stretch has character p >= T's exactly when it lies at or behind the stretch's first entry with such a character
+//     (LB), <= T's exactly when it lies in front of UB (one equal-range search in the stretch gives both); any other mid
+//     is loaded (through the memo) and its real byte compared, as the reference does.
+// Every comparison therefore has the outcome the reference computes; tests/test_harness_cpu.py compares the result with
+// lit_region over the whole bucket for every dangerous probe.  Diagnostic counters: searches made, entries loaded.
+struct InferStats { uint32_t searches, loads, steps, dirs; };
+// [b1, b2) = the entries of the sorted stretch [lo, hi) whose characters 12..pe equal the probe's.  While the prefix code
+// of the characters 0..pe fits the directory's depth, they are two directory words (independent loads, one round trip
+// however large the bucket): dir gives the first index, over the WHOLE index, of an entry whose real characters are not
+// below the probe's prefix -- inside the stretch every entry is sorted on real characters, behind it every entry is
+// larger, so a value that lies inside [lo, hi] is the stretch's own bound; a value in front of lo was pulled there by
+// an outlier's real bytes (a head of one of the probe's groups) and is not used: the key search over the stretch decides.
+WALT_HD void stretch_bounds(const StrandView& sv, const uint32_t* care, uint32_t Bd, uint64_t T, uint32_t pe, uint32_t lo,
+                            uint32_t hi, uint32_t& b1, uint32_t& b2, InferStats* st) {
+  if (hi <= lo) { b1 = b2 = lo; return; }
+  uint64_t acc = 0;
+  uint32_t nb = 0;
+  for (uint32_t i = 0; i <= pe; ++i) {
+    const uint32_t c = care_char(care, i);
+    const uint32_t len = pcode_len(c, sv.ga);
+    acc = (acc << len) | pcode_bits(c, sv.ga);
+    nb += len;
+  }
+  if (Bd != 0 && nb <= Bd && sv.dir != nullptr) {
+    const uint32_t v_lo = (uint32_t)(acc << (Bd - nb)), span = nb < Bd ? 1u << (Bd - nb) : 1u;
+    const uint32_t slot = dir_top(Bd) - v_lo;
+    const uint32_t d = (sv.dir + (uint32_t)(slot - 1u))[1], e = sv.dir[(uint32_t)(slot - span)];
+    if (st) ++st->dirs;
+    if (d >= lo && e >= d && e <= hi) { b1 = d; b2 = e; return; }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (getenv("WALT_DBG_DIR")) fprintf(stderr, "dir miss: pe %u nb %u Bd %u d %u e %u lo %u hi %u\n", pe, nb, Bd, d, e, lo, hi);
+#endif
+  }
+#if !defined(__HIP_DEVICE_COMPILE__)
+  else if (getenv("WALT_DBG_DIR")) fprintf(stderr, "dir n/a: pe %u nb %u Bd %u\n", pe, nb, Bd);
+#endif
+  const uint64_t M = key_mask_fwd(pe - kKeyWeight + 1);
+  masked_bounds(sv, lo, hi, T & M, M, b1, b2);
+  if (st) ++st->searches;
+}
+template <class QOf>
+WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, uint32_t seed_len, uint32_t first,
+                                   uint32_t second, const QOf& q_of, InferStats* st = nullptr, uint32_t Bd = 0) {
+  const uint32_t h = care[0] >> 8;
+  const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
+  const uint64_t T = target_key(care);
+  // levels with heads: bit q - 12 for every outlier with q < lim that shares T's characters 12..q-1 -- from the level
+  // table (four independent look-ups a round), or by walking the bucket's outliers
+  uint32_t levels = 0, o_lo = 0;
+  bool have_table;
+  {
+    bool dng;
+    uint32_t q_first;
+    have_table = olev_relevant(sv, h, T, lim, levels, dng, q_first);
+  }
+  if (!have_table) {
+    uint32_t hi = sv.n_outl;
+    if (sv.outl_dir) {
+      uint32_t slot_o = outl_dir_hash(h) & sv.outl_dir_mask;
+      for (;;) {
+        const uint32_t tag = sv.outl_dir[2 * slot_o];
+        if (tag == 0) { o_lo = sv.n_outl; break; }
+        if (tag == h + 1) { o_lo = sv.outl_dir[2 * slot_o + 1]; break; }
+        slot_o = (slot_o + 1) & sv.outl_dir_mask;
+      }
+    } else {
+      while (o_lo < hi) {
+        const uint32_t mid = o_lo + ((hi - o_lo) >> 1);
+        if (sv.outl[mid].h < h) o_lo = mid + 1; else hi = mid;
+      }
+    }
+    for (uint32_t i = o_lo; i < sv.n_outl && sv.outl[i].h == h; ++i) {
+      const Outlier o = sv.outl[i];
+      if (o.q >= lim) continue;
+      const uint64_t k = ((uint64_t)o.key_hi << 32) | o.key_lo;
+      if (((T ^ k) & key_mask_fwd(o.q - kKeyWeight)) == 0) levels |= 1u << (o.q - kKeyWeight);
+    }
+  }
+  LitMemo memo;
+  memo_init(memo);
+  uint32_t p = kKeyWeight, l = first, u = second - 1, cl = first, cu = second;  // G_12 = the bucket
+  while (p < lim) {
+    const bool pure = l == cl && u + 1 == cu;
+    if (pure && !((levels >> (p - kKeyWeight)) & 1u)) {
+      // steps p .. pn - 1 have no heads: the range becomes the equal range of T's characters 12 .. pn - 1
+      const uint32_t rest = levels >> (p - kKeyWeight);
+      uint32_t pn = lim;
+      if (rest) {
+        uint32_t z = 0;
+        while (!((rest >> z) & 1u)) ++z;
+        pn = p + z < lim ? p + z : lim;
+      }
+      uint32_t b1, b2;
+      stretch_bounds(sv, care, Bd, T, pn - 1, cl, cu, b1, b2, st);
+      if (b2 <= b1) return empty_region();
+      cl = b1; cu = b2; l = b1; u = b2 - 1;
+      p = pn;
+      continue;
+    }
+    // one simulated step
+    uint32_t k = 0;
+    if (((levels >> (p - kKeyWeight)) & 1u) && have_table) {
+      k = olev_find(sv, olev_fp(h, p, T & key_mask_fwd(p - kKeyWeight))) & 0x3FFFFFFFu;
+    } else if ((levels >> (p - kKeyWeight)) & 1u) {
+      for (uint32_t i = o_lo; i < sv.n_outl && sv.outl[i].h == h; ++i) {
+        const Outlier o = sv.outl[i];
+        if (o.q != p) continue;
+        const uint64_t kk = ((uint64_t)o.key_hi << 32) | o.key_lo;
+        if (((T ^ kk) & key_mask_fwd(p - kKeyWeight)) == 0) ++k;
+      }
+    }
+    const uint32_t s0 = cl + k < cu ? cl + k : cu;  // the stretch [s0, cu)
+    uint32_t LB, UB;
+    stretch_bounds(sv, care, Bd, T, p, s0, cu, LB, UB, st);
+    if (st) ++st->steps;
+    const int ch = (int)care_char(care, p);
+    uint32_t low = l, high = u;
+    while (low < high) {  // LowerBound, mapping.cpp:166-180
+      const uint32_t mid = low + (high - low) / 2;
+      const bool ge = (mid >= s0 && mid < cu) ? mid >= LB : memo_char(sv, memo, q_of, mid, p, l, u) >= ch;
+      if (ge) high = mid; else low = mid + 1;
+    }
+    const uint32_t nl = low;
+    high = u;
+    while (low < high) {  // UpperBound, mapping.cpp:182-196
+      const uint32_t mid = low + (high - low + 1) / 2;
+      const bool le = (mid >= s0 && mid < cu) ? mid < UB : memo_char(sv, memo, q_of, mid, p, nl, u) <= ch;
+      if (le) low = mid; else high = mid - 1;
+    }
+    l = nl;
+    u = low;
+    if (l == u) {  // mapping.cpp:206-211
+      const bool eq = (l >= s0 && l < cu) ? (l >= LB && l < UB) : memo_char(sv, memo, q_of, l, p, l, u) == ch;
+      if (!eq) { if (st) st->loads += memo.loads; return empty_region(); }
+    }
+    cl = LB; cu = UB;  // G_(p+1)
+    ++p;
+  }
+  if (st) st->loads += memo.loads;
+  if (p < seed_len) return lit_region(sv, care, p, seed_len, l, u);  // characters >= 44: on the genome itself
+  if (l > u) return empty_region();
+  Region r; r.l = l; r.u = u; return r;
+}
 
 struct Lookup {
   Region reg;
@@ -918,8 +1355,9 @@ struct Lookup {
   uint32_t pos[kLookupPos];
 };
 
+template <class QOf>
 WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
-                            uint32_t span, uint32_t seed_len, Lookup& out, bool known_good = false) {
+                            uint32_t span, uint32_t seed_len, Lookup& out, bool known_good, const QOf& q_of) {
   out.npos = 0;
   out.reg = empty_region();
   uint32_t h = care[0] >> 8;  // getHashValue, util.hpp:175-182
@@ -931,6 +1369,13 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     if (level) {
       uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
       if (first == second) return;                         // mapping.cpp:271-272
+      if (literal_mode() == 2 && !bucket_is_bad(sv, h)) {  // (a BAD bucket -- disorder no outlier explains -- keeps the plain search)
+        InferStats ist = {0, 0, 0, 0};
+        out.reg = lit_region_inferred(sv, care, seed_len, first, second, q_of, memo_stats() ? &ist : nullptr, iv.dir_bits);
+        if (memo_stats()) { memo_stats()[0] += 1; memo_stats()[1] += 1; memo_stats()[2] += ist.loads; memo_stats()[3] += ist.searches; memo_stats()[4] += ist.steps;
+                            const uint32_t cst = ist.loads + ist.searches + ist.dirs; memo_stats()[6 + (cst < 63 ? cst : 63)] += 1; memo_stats()[5] += 0; memo_stats()[69] += ist.dirs; }
+        return;
+      }
       uint32_t l0 = first, u0 = second - 1, p0 = kKeyWeight;
       if (level > kKeyWeight && literal_from_level()) {
         // the reference's range after the characters in front of `level`: the equal range of the probe's first
@@ -942,7 +1387,12 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
                                                 : slot_kary_search(sv, first, second, Tq, Mq, a0, b0);
         if (found) { l0 = a0; u0 = b0; p0 = level; }
       }
-      out.reg = lit_region(sv, care, p0, seed_len, l0, u0);
+      // (a BAD bucket keeps the plain search: FACT S needs makedb's order)
+      LitMemo memo;
+      memo_init(memo);
+      const bool use_memo = literal_mode() >= 1 && !bucket_is_bad(sv, h);
+      out.reg = use_memo ? lit_region_memo(sv, care, p0, seed_len, l0, u0, memo, q_of) : lit_region(sv, care, p0, seed_len, l0, u0);
+      if (memo_stats()) { memo_stats()[0] += 1; memo_stats()[1] += use_memo ? 1 : 0; memo_stats()[2] += memo.loads; memo_stats()[3] += memo.probes; }
       return;
     }
   }
@@ -1016,6 +1466,13 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     return;
   }
   out.reg.l = a; out.reg.u = u;
+}
+
+WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,
+                            uint32_t span, uint32_t seed_len, Lookup& out, bool known_good = false) {
+  QOfGlobal q_of;
+  q_of.start_index = iv.start_index; q_of.n_chrom = iv.n_chrom;
+  seed_lookup_ex(iv, sv, care, slot, span, seed_len, out, known_good, q_of);
 }
 
 WALT_HD Region seed_lookup(const IndexView& iv, const StrandView& sv, const uint32_t* care, uint32_t slot,

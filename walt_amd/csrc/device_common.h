@@ -27,7 +27,9 @@ struct walt_options {
   // single-end
   int se_pipe = 1;            // the staged heavy pass in two halves on two streams
   long long se_heavy_chunk = 0;  // reads per chunk of the heavy list (0: the default; test hook: several chunks on a small batch)
+  int se_lit_ablate = 0;      // measurement only (results wrong when set)
   int se_lit_side = 1;        // the literal pass on a side stream beside the end of the heavy pass
+  int se_lit_staged = 0;      // the deferred reads through staged rounds with the reference's search on instead of the strand-major kernel
   long long se_defer_min = -1;   // long seeds: key-equal ranges of more slots go to the verifier (-1: default, 0: never)
   int se_stage_occ = 0;       // wavefronts per SIMD the stage kernel is built for (0: default)
   int se_carry = 1;           // pass 1 hands its state to the staged rounds (0: they start over at seed 0)
@@ -40,6 +42,7 @@ struct walt_options {
   long long pe_stage_cap = 0; // reads of a staged round (0: default; test hook)
   int pe_small_heaps = 0;     // force the 8-slot heaps + overflow list of long literal lists
   int pe_serial = 0;          // mates and pipeline slots one after the other (profiling)
+  int pe_push_wide = 0;       // 4-byte heap entries in the push kernel whatever -m is (A/B; 0: 2-byte entries when -m <= 15)
   long long pe_defer_min = -1;
   int pe_roomy = -1;          // -1: decided once per index from the device's free memory
 };
@@ -72,10 +75,8 @@ struct walt_index {
   hipEvent_t ev_detail[kDetailEvents] = {};
   unsigned char ev_kind[kDetailEvents] = {};
   int n_detail = 0;
-  // single-end (created on first use): the side stream the literal pass runs on beside the last verifier launch and
-  // the final fold of the staged heavy pass
   std::mutex se_busy;  // one single-end call at a time per index (the streams and events below are the call's)
-  hipStream_t se_side = nullptr;
+  hipStream_t se_side = nullptr;  // the literal pass beside the end of the heavy pass (created on first use)
   hipEvent_t se_fork = nullptr, se_join = nullptr;
   // single-end staged heavy pass in two halves (map_se.hip launch_map_se): the second half's stream and the events
   // that order the halves: [0] pass 1 done, [1] the first half's last look-up stage done, [2] second half done

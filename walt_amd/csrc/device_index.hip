@@ -429,6 +429,22 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       if (x.key_hi != y.key_hi) return x.key_hi < y.key_hi;
       return x.key_lo < y.key_lo;
     });
+    // the level table (core.h StrandView::olev): which outliers a probe shares its characters with, by look-up
+    std::vector<OlevEnt> lev;
+    std::vector<uint32_t> collided;
+    const uint32_t ents = build_outlier_levels(ho.data(), n_outl, lev, collided);
+    for (uint32_t hb : collided) {  // two keys, one fingerprint: their buckets are searched literally (never seen)
+      uint32_t word = 0;
+      WALT_HIP(hipMemcpy(&word, bad + (hb >> 5), 4, hipMemcpyDeviceToHost));
+      if (!((word >> (hb & 31)) & 1u)) ++nbad;
+      word |= 1u << (hb & 31);
+      WALT_HIP(hipMemcpy(bad + (hb >> 5), &word, 4, hipMemcpyHostToDevice));
+    }
+    OlevEnt* d_lev = nullptr;
+    if ((rc = dev_alloc(idx, &d_lev, (uint64_t)ents))) return rc;
+    WALT_HIP(hipMemcpy(d_lev, lev.data(), (size_t)ents * sizeof(OlevEnt), hipMemcpyHostToDevice));
+    sv.olev = d_lev;
+    sv.olev_mask = ents - 1;
     // filter keys: see core.h; the filter is sized by their number
     std::vector<uint32_t> keys;
     std::vector<std::pair<uint32_t, uint32_t>> keys2;  // (16-character key: block and prefilter, 20-character key: bits)
@@ -1059,11 +1075,11 @@ struct OptionName {
 #define WALT_OPT_I(f, lo, hi) {#f, 0, offsetof(walt_options, f), lo, hi}
 #define WALT_OPT_L(f, lo, hi) {#f, 1, offsetof(walt_options, f), lo, hi}
 const OptionName kOptions[] = {
-    WALT_OPT_I(se_pipe, 0, 1),        WALT_OPT_L(se_heavy_chunk, 0, 1ll << 28), WALT_OPT_I(se_lit_side, 0, 1),
+    WALT_OPT_I(se_pipe, 0, 1),        WALT_OPT_L(se_heavy_chunk, 0, 1ll << 28), WALT_OPT_I(se_lit_staged, 0, 1), WALT_OPT_I(se_lit_side, 0, 1), WALT_OPT_I(se_lit_ablate, 0, 7),
     WALT_OPT_L(se_defer_min, -1, 1ll << 30), WALT_OPT_I(se_stage_occ, 0, 4),   WALT_OPT_I(se_carry, 0, 1),
     WALT_OPT_I(se_heavy_mono, 0, 1),  WALT_OPT_L(grid, 0, 1ll << 20),           WALT_OPT_I(pe_mode, 0, 1),
     WALT_OPT_L(pe_chunk, 0, 1ll << 28), WALT_OPT_L(pe_rounds, 0, 4),            WALT_OPT_L(pe_stage_cap, 0, 1ll << 28),
-    WALT_OPT_I(pe_small_heaps, 0, 1), WALT_OPT_I(pe_serial, 0, 1),              WALT_OPT_L(pe_defer_min, -1, 1ll << 30),
+    WALT_OPT_I(pe_small_heaps, 0, 1), WALT_OPT_I(pe_serial, 0, 1), WALT_OPT_I(pe_push_wide, 0, 1),              WALT_OPT_L(pe_defer_min, -1, 1ll << 30),
     WALT_OPT_I(pe_roomy, -1, 1),
 };
 #undef WALT_OPT_I

@@ -5,6 +5,8 @@
 #ifndef WALT_AMD_INDEX_CORE_H_
 #define WALT_AMD_INDEX_CORE_H_
 
+#include <vector>
+
 #include "core.h"
 
 namespace walt {
@@ -37,19 +39,7 @@ WALT_HD Ent make_ent(const uint32_t* g2, uint32_t genome_len, uint32_t pos, bool
   return e;
 }
 
-// first care character index (>= 12) of an entry that lies at or beyond the end of
-// its chromosome; room = chromosome end - pos.  kNumCare when every character fits.
-WALT_HD uint32_t first_beyond(uint32_t room) {
-  uint32_t q;
-  if (kPat == 3) {
-    // care_pos(q) = 1 + 3 q >= room  <=>  q >= (room - 1) / 3 rounded up
-    q = room <= 1 ? 0u : (room - 1 + 2) / 3;
-  } else {
-    q = 0;
-    while (q < kNumCare && care_pos(q) < room) ++q;
-  }
-  return q < kKeyWeight ? kKeyWeight : q;
-}
+// (first_beyond: core.h)
 
 // Code prefix (first Bd bits, zero padded) of the care characters behind an index
 // entry: characters 0..11 from the genome, 12..43 from the entry key.
@@ -125,6 +115,73 @@ inline uint32_t build_outlier_dir(const Outlier* outl, uint32_t n_outl, Vec& dir
     dir[2 * slot + 1] = i;
   }
   return pairs;
+}
+
+// Host side: the level table of StrandView::olev for outliers sorted by (bucket, q, key).  Returns the number of
+// entries (a power of two, at most half full).  Two different keys with one fingerprint (never, in practice: 63 bits)
+// cannot both be held: their buckets are reported in `collided` and the caller marks them BAD (literal search, no table).
+template <class VecE, class VecU>
+inline uint32_t build_outlier_levels(const Outlier* outl, uint32_t n_outl, VecE& table, VecU& collided) {
+  uint32_t groups = 0, buckets = 0;
+  for (uint32_t i = 0; i < n_outl; ++i) {
+    const Outlier& o = outl[i];
+    const bool nb = i == 0 || outl[i - 1].h != o.h;
+    buckets += nb ? 1u : 0u;
+    const uint64_t km = (((uint64_t)o.key_hi << 32) | o.key_lo) & key_mask_fwd(o.q - kKeyWeight);
+    const bool ng = nb || outl[i - 1].q != o.q ||
+                    ((((uint64_t)outl[i - 1].key_hi << 32) | outl[i - 1].key_lo) & key_mask_fwd(o.q - kKeyWeight)) != km;
+    groups += ng ? 1u : 0u;
+  }
+  uint32_t size = 16;
+  while (size < 2 * (groups + buckets)) size <<= 1;
+  OlevEnt zero; zero.fp_lo = zero.fp_hi = zero.value = zero.pad = 0;
+  table.assign((size_t)size, zero);
+  std::vector<uint32_t> owner((size_t)size, 0xFFFFFFFFu);  // bucket of the key that holds a slot
+  auto put = [&](uint32_t h, uint64_t fp, uint32_t value, bool merge_or) {
+    uint32_t slot = olev_slot(fp, size - 1);
+    for (;;) {
+      OlevEnt& e = table[slot];
+      if (e.fp_lo == 0 && e.fp_hi == 0) {
+        e.fp_lo = (uint32_t)fp; e.fp_hi = (uint32_t)(fp >> 32); e.value = value;
+        owner[slot] = h;
+        return;
+      }
+      if (e.fp_lo == (uint32_t)fp && e.fp_hi == (uint32_t)(fp >> 32)) {  // the callers insert every key once: a clash of two keys
+        (void)merge_or;
+        collided.push_back(h);
+        collided.push_back(owner[slot]);
+        return;
+      }
+      slot = (slot + 1) & (size - 1);
+    }
+  };
+  uint32_t i = 0;
+  while (i < n_outl) {
+    const uint32_t h = outl[i].h;
+    uint32_t qmask = 0;
+    uint32_t j = i;
+    while (j < n_outl && outl[j].h == h) {
+      const uint32_t q = outl[j].q;
+      const uint64_t M = key_mask_fwd(q - kKeyWeight);
+      const uint64_t km = (((uint64_t)outl[j].key_hi << 32) | outl[j].key_lo) & M;
+      uint32_t cnt = 0, maxx = 0, k = j;
+      const uint32_t sh = 2 * (kKeyWeight + kKeyChars - 1 - (q < kKeyWeight + kKeyChars ? q : kKeyWeight + kKeyChars - 1));
+      while (k < n_outl && outl[k].h == h && outl[k].q == q && ((((uint64_t)outl[k].key_hi << 32) | outl[k].key_lo) & M) == km) {
+        const uint32_t x = (uint32_t)(((((uint64_t)outl[k].key_hi << 32) | outl[k].key_lo) >> sh) & 3u);
+        maxx = x > maxx ? x : maxx;
+        ++cnt;
+        ++k;
+      }
+      if (q < kKeyWeight + kKeyChars) {
+        put(h, olev_fp(h, q, km), (cnt & 0x3FFFFFFFu) | (maxx << 30), false);
+        if (q - kKeyWeight < 32) qmask |= 1u << (q - kKeyWeight);
+      }
+      j = k;
+    }
+    if (qmask) put(h, olev_fp(h, kOlevBucket, 0), qmask, false);
+    i = j;
+  }
+  return size;
 }
 
 }  // namespace walt

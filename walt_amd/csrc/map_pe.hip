@@ -31,6 +31,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "map_common.h"
 #include "map_items.h"
 
@@ -911,23 +913,26 @@ static_assert(kPeChunks * kPeChunkEnts <= 512 && kPeMidRegion <= 512, "a survivo
 #define WALT_PUSH_BIG_SLOTS 1536
 #endif
 constexpr uint32_t kPushBigSlots = WALT_PUSH_BIG_SLOTS;  // 4-byte heap slots per wavefront of the second launch
-struct Heap4 {
-  uint32_t* w;
+// W = uint32_t, MB = 11: the layout above.  W = uint16_t, MB = 4 (round 4): mismatches in bits 0..3, the place in bits
+// 4..15 -- for -m up to 15, i.e. every default run: twice the reads per wavefront again (61 of 64 lanes at -k 50).
+template <class W, int MB>
+struct HeapPacked {
+  W* w;
   struct Ref {
-    uint32_t* p;
+    W* p;
     __device__ __forceinline__ operator HeapEnt() const {
       const uint32_t v = *p;
       HeapEnt e;
-      e.pos = v >> 11;                                            // place: probe << 9 | number
-      e.mms = (v & 0x7FFu) | ((v >> 20) >= 3u ? 0x80000000u : 0u);  // probes 3..5 are the '-' strand's
+      e.pos = v >> MB;                                                          // place: probe << 9 | number
+      e.mms = (v & ((1u << MB) - 1u)) | ((v >> (MB + 9)) >= 3u ? 0x80000000u : 0u);  // probes 3..5 are the '-' strand's
       return e;
     }
-    __device__ __forceinline__ Ref& operator=(const HeapEnt& e) { *p = (e.mms & 0x7FFu) | (e.pos << 11); return *this; }
+    __device__ __forceinline__ Ref& operator=(const HeapEnt& e) { *p = (W)((e.mms & ((1u << MB) - 1u)) | (e.pos << MB)); return *this; }
     __device__ __forceinline__ Ref& operator=(const Ref& o) { *p = *o.p; return *this; }
   };
   __device__ __forceinline__ Ref operator[](uint32_t i) const { return Ref{w + i}; }
 };
-template <bool SMALL>
+template <bool SMALL, int EB = 4>  // EB: bytes of a heap entry of the second launch (4, or 2 when -m <= 15)
 __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ list,
                                                     PeStage ps, uint32_t top_k, Candidate* __restrict__ ranked,
                                                     uint32_t* __restrict__ heap_n, uint32_t* __restrict__ fb_count,
@@ -949,13 +954,15 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
   const uint32_t total_waves = gridDim.x * waves_per_block;
   const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
   const uint32_t cap = SMALL ? kPushSmall : top_k;
-  constexpr uint32_t kSlots = SMALL ? kListHeapSlots : kPushBigSlots;
+  constexpr uint32_t kSlots = SMALL ? kListHeapSlots : kPushBigSlots * (4 / EB);
+  constexpr int MB = EB == 2 ? 4 : 11;  // mismatch bits of a packed entry
+  using PackedW = typename std::conditional<EB == 2, uint16_t, uint32_t>::type;
   const uint32_t rpw_max = kSlots / cap < 64 ? kSlots / cap : 64;  // top_k <= 300: at least 2
   uint32_t rpw = (count + total_waves - 1) / total_waves;
   rpw = rpw < 1 ? 1 : (rpw > rpw_max ? rpw_max : rpw);
   HeapEnt* heap = &s_heap[threadIdx.x >> 6][(lane < rpw ? lane : 0) * (SMALL ? cap : 0u)];
-  Heap4 heap4;
-  heap4.w = reinterpret_cast<uint32_t*>(&s_heap[threadIdx.x >> 6][0]) + (lane < rpw ? lane : 0) * cap;
+  HeapPacked<PackedW, MB> heap4;
+  heap4.w = reinterpret_cast<PackedW*>(&s_heap[threadIdx.x >> 6][0]) + (lane < rpw ? lane : 0) * cap;
   const uint64_t ccap = ps.ccap;
   for (uint64_t base = (uint64_t)wave * rpw; base < count; base += (uint64_t)total_waves * rpw) {
     const uint64_t i = base + lane;
@@ -980,7 +987,7 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
       for (uint32_t seed_i = 0; seed_i < kPat; ++seed_i) {
         // paired.cpp:133-149 (top only decreases: per-seed predicates equal the reference's `break`)
         const bool full = hsize >= top_k;
-        const uint32_t top_mm = hsize ? (SMALL ? heap_mm(heap[0]) : (heap4.w[0] & 0x7FFu)) : 0xFFFFFFFFu;
+        const uint32_t top_mm = hsize ? (SMALL ? heap_mm(heap[0]) : ((uint32_t)heap4.w[0] & ((1u << MB) - 1u))) : 0xFFFFFFFFu;
         if ((full && top_mm == 0 && seed_i) || (full && top_mm == 1 && seed_i >= kExitOneMismatch)) continue;
         const uint32_t probe = 3 * fi + seed_i;
         const uint32_t sn = ps.surv_n[(uint64_t)probe * ccap + j];
@@ -1033,23 +1040,23 @@ __global__ __launch_bounds__(kBlock) void k_pe_push(const uint32_t* __restrict__
 #pragma unroll
         for (uint32_t t = 0; t < 8; ++t) {
           v[t] = heap4.w[n_ent - 1 - (i0 + t < n_ent ? i0 + t : n_ent - 1)];
-          sn[t] = ps.surv_n[(uint64_t)(v[t] >> 20) * ccap + j];
+          sn[t] = ps.surv_n[(uint64_t)(v[t] >> (MB + 9)) * ccap + j];
         }
 #pragma unroll
         for (uint32_t t = 0; t < 8; ++t) {
-          const uint32_t probe = v[t] >> 20, k = (v[t] >> 11) & 511u;
+          const uint32_t probe = v[t] >> (MB + 9), k = (v[t] >> MB) & 511u;
           ch[t] = (sn[t] >> 31) ? ps.chunk[((uint64_t)probe * kPeChunks + k / kPeChunkEnts) * ccap + j] : 0u;
         }
 #pragma unroll
         for (uint32_t t = 0; t < 8; ++t) {
-          const uint32_t probe = v[t] >> 20, k = (v[t] >> 11) & 511u;
+          const uint32_t probe = v[t] >> (MB + 9), k = (v[t] >> MB) & 511u;
           c[t] = (sn[t] >> 31) ? ps.pool[(uint64_t)ch[t] * kPeChunkEnts + k % kPeChunkEnts]
                                : ps.inl[((uint64_t)probe * kPeMidRegion + k) * ccap + j];
         }
 #pragma unroll
         for (uint32_t t = 0; t < 8; ++t) {
           if (i0 + t < n_ent) {
-            Candidate cd; cd.genome_pos = c[t].x; cd.strand = (v[t] >> 20) >= 3u ? '-' : '+'; cd.mismatch = v[t] & 0x7FFu;
+            Candidate cd; cd.genome_pos = c[t].x; cd.strand = (v[t] >> (MB + 9)) >= 3u ? '-' : '+'; cd.mismatch = v[t] & ((1u << MB) - 1u);
             out[i0 + t] = cd;
           }
         }
@@ -1421,10 +1428,14 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
              hipMemsetAsync(big_count, 0, 2 * sizeof(uint32_t), stream) == hipSuccess;  // ctl[1], and ctl[2]: the queue's largest-first count
     };
     auto push = [&](const uint32_t* count, const uint32_t* list, uint32_t* over_n, uint32_t* over_l, uint32_t first) {
-      hipLaunchKernelGGL(k_pe_push<true>, dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
+      hipLaunchKernelGGL((k_pe_push<true, 4>), dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
                          first, big_count, big_list);
-      hipLaunchKernelGGL(k_pe_push<false>, dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
-                         first, big_count, big_list);
+      if (max_mm <= 15 && idx->opt.pe_push_wide == 0)  // 2-byte heap entries: 4 mismatch bits
+        hipLaunchKernelGGL((k_pe_push<false, 2>), dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
+                           first, big_count, big_list);
+      else
+        hipLaunchKernelGGL((k_pe_push<false, 4>), dim3(g2), dim3(kBlock), 0, stream, count, list, ps, top_k, ranked, heap_n, over_n, over_l,
+                           first, big_count, big_list);
     };
     auto clear_queue = [&]() {
       return hipMemsetAsync(ctl + 28, 0, 4 * sizeof(uint32_t), stream) == hipSuccess &&

@@ -337,6 +337,7 @@ struct HeavyStage {
   uint32_t even;     // this is chunk number `chunk` of them (heavy_chunk_span; the list's length is known on the device only)
   uint32_t round;    // 0 .. kPat
   uint32_t defer_min;  // long seeds: key-equal ranges of more slots than this are narrowed by the verifier (0xFFFFFFFF: never)
+  uint32_t lit_ablate; // (measurement only, option se_lit_ablate; results are WRONG when set) bit 0: the literal rounds skip the reference's search
 };
 // What pass 1 hands to round 0 for a read it gives up (arrays indexed by the read's number in the batch, nullptr: the
 // heavy pass starts over at seed 0): the heavy-list entry carries the seed shift and best.strand (heavy_entry), st the
@@ -750,7 +751,13 @@ static __global__ void k_lit_snapshot(const uint32_t* __restrict__ count, uint32
   if (threadIdx.x == 0) { ctl2[0] = *count; rng[0] = *count; }
   if (threadIdx.x >= 8 && threadIdx.x < 24) ctl2[threadIdx.x] = 0;
 }
-static __global__ void k_lit_rest(const uint32_t* __restrict__ count, uint32_t* __restrict__ rng) { rng[1] = *count; }
+static __global__ void k_lit_end(const uint32_t* __restrict__ count, uint32_t* __restrict__ rng) { rng[1] = *count; }
+// rng = {first, end}: the entries of the deferred list behind the `done` the literal rounds have mapped
+static __global__ void k_lit_rest(const uint32_t* __restrict__ count, uint32_t* __restrict__ rng, uint32_t done) {
+  const uint32_t c = *count;
+  rng[0] = done < c ? done : c;
+  rng[1] = c;
+}
 static __global__ void k_bin_count(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list) {
   __shared__ uint32_t bins[8];
   if (threadIdx.x < 8) bins[threadIdx.x] = 0;
@@ -888,8 +895,13 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
 // or the read is finished.  What the seed loop does per seed is what pass 1 does, with long slots searched (both
 // strands together: map_common.h probe_resolve_dual) and regions of up to kMidRegion candidates verified in the lane.
 // ---------------------------------------------------------------------------
-template <int NW, int OCC = 0>  // OCC: wavefronts per SIMD the registers are capped for (0: the default)
-__global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_se_stage(
+// LIT (the literal rounds, launch_map_se): the rounds over the reads the ordinary rounds gave up at a truly dangerous probe;
+// here such a probe's region comes from the reference's own search (core.h seed_lookup_ex -> lit_region_inferred: a few
+// key searches, hardly an entry load) and the read goes on like any other.  Until round 4 these reads were mapped from
+// scratch by the strand-major kernel of round 1 (k_map_se_literal: ~12 ns a read whatever its probes cost -- 120 ms for
+// the 9.5 M such reads of an hg19-scale assembly of 3,000 contigs).
+template <int NW, int OCC = 0, bool LIT = false>  // OCC: wavefronts per SIMD the registers are capped for (0: the default)
+__global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1)))) void k_se_stage(
     IndexView iv, const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
     uint32_t strand_base, uint32_t max_mm, uint32_t b, const uint32_t* __restrict__ mask_table, BestMatch* __restrict__ out,
     unsigned long long* __restrict__ stats, uint32_t* __restrict__ defer_count, uint32_t* __restrict__ defer_list,
@@ -1047,10 +1059,14 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 
       probe_issue(svm, need_m, slot, span, pm, hi_m);
       const bool bad_p = need_p && bw_p && danger_filter_hit(bw_p, care);
       const bool bad_m = need_m && bw_m && danger_filter_hit(bw_m, care);
+      bool lit_p = false, lit_m = false;  // LIT: this strand's region comes from the reference's search
       if (bad_p || bad_m) {  // a filter hit is a superset of the dangerous probes: the exact test
         const bool dng_p = bad_p && probe_is_dangerous(svp, care, seed_len);
         const bool dng_m = bad_m && probe_is_dangerous(svm, care, seed_len);
-        if (dng_p || dng_m) {  // the literal pass maps the read from scratch
+        if constexpr (LIT) {
+          lit_p = dng_p;
+          lit_m = dng_m;
+        } else if (dng_p || dng_m) {  // the literal rounds take the read up again
           deferred = true;
           active = false;
           need_p = need_m = false;
@@ -1058,8 +1074,8 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 
           defer_iter = defer_iter < 7u ? defer_iter : 7u;
         }
       }
-      pp.ne = (need_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
-      pm.ne = (need_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
+      pp.ne = (need_p && !lit_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
+      pm.ne = (need_m && !lit_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
       probe_entries(svp, pp);
       probe_entries(svm, pm);
       Lookup lp, lm;
@@ -1070,6 +1086,10 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 
                                        win_usable<NW>(svp, lr.len) && win_usable<NW>(svm, lr.len), kPat != 3 ? kMidRegion : 0u);
       } else {
         probe_resolve_dual<kLong>(svp, svm, pp, pm, care, seed_len, lp, lm, tail_p, tail_m);
+      }
+      if constexpr (LIT) {  // IndexRegion as the reference runs it (positions are fetched with the candidates)
+        if (lit_p && need_p && !(hs.lit_ablate & 1u)) { seed_lookup_ex(iv, svp, care, slot, span, seed_len, lp, false); tail_p = false; defer_p = false; }
+        if (lit_m && need_m && !(hs.lit_ablate & 1u)) { seed_lookup_ex(iv, svm, care, slot, span, seed_len, lm, false); tail_m = false; defer_m = false; }
       }
       uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
       uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
@@ -1312,7 +1332,7 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
 
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
 template <int NW, bool LITERAL = true>
-__global__ __launch_bounds__(kBlock, NW <= 8 ? 5 : 1) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
+__global__ __launch_bounds__(kBlock, NW <= 8 ? 4 : 1) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
                                                             const uint64_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ err, uint32_t strand_base,
                                                             uint32_t max_mm,
@@ -1366,7 +1386,8 @@ uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 // The geometry a call uses follows from (n, read length, the index's options); the workspace a caller must provide
 // (walt_se_workspace_bytes, which knows no index) is that of the DEFAULT options, and no option may need more: an
 // option value that would is not applied (se_geometry).
-constexpr uint32_t kHeavyCtlWords = 64 * kPat + 64;  // 8 words per (chunk, round): up to 8 chunks x kPat rounds; then the literal side launch's 64
+constexpr uint32_t kLitChunks = 2;  // chunks of the deferred list the literal rounds take (launch_map_se)
+constexpr uint32_t kHeavyCtlWords = 64 * kPat + 8 * kPat * kLitChunks + 8;  // 8 words per (chunk, round): up to 8 chunks x kPat rounds, the literal rounds' chunks, the rest launch's range
 struct SeGeometry {
   uint32_t hcap;     // reads per chunk
   uint32_t chunks;   // launched chunks (<= 8; even when piped)
@@ -1470,7 +1491,8 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                        heavy_list, 0u, nullptr, carry);
   debug_sync("pass 1", stream);
   mark(0);
-  bool lit_side = false;
+  bool lit_done = false;  // the literal rounds have mapped the deferred reads (all but what the rest launch below takes)
+  bool lit_side = false;  // the strand-major literal kernel runs on a side stream beside the end of the heavy pass
   bool forked = false;  // work is queued on the index's own streams: an error return must not leave it running
   auto unwind = [&]() {
     if (!forked) return;
@@ -1485,6 +1507,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       return walt::fail(WALT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
     }                                                                                        \
   } while (0)
+  uint32_t* const rng = heavy_area + kHeavyCtlWords - 8;  // {first entry, end} of the deferred list the rest launch maps
   if (mono) {
     // the one-kernel heavy pass (large regions verified by the whole wavefront of their read's lane) instead of the
     // staged one (large regions streamed by k_se_verify); same results, kept for comparison
@@ -1524,6 +1547,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     hs.defer_min = opt.se_defer_min < 0 ? (uint32_t)kSmallRegion
                  : opt.se_defer_min == 0 ? 0xFFFFFFFFu
                  : (uint32_t)(opt.se_defer_min < (long long)kSmallRegion ? (long long)kSmallRegion : opt.se_defer_min);
+    hs.lit_ablate = (uint32_t)opt.se_lit_ablate;
     uint32_t* const ctl0 = heavy_area;
     static const int vb_dense = [] {
       int nb = 0;
@@ -1536,14 +1560,16 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       return nb;
     }();
     const unsigned vg_dense = (unsigned)vb_dense * (unsigned)idx->n_cu, vg_gather = (unsigned)vb_gather * (unsigned)idx->n_cu;
-    // The literal pass beside the end of the heavy pass: after the last look-up round of the first chunk (of each half)
-    // the list of reads with a truly dangerous probe is complete but for what later chunks add (nothing, when the heavy
-    // list fits these chunks); those reads are sorted and mapped on a side stream while the main streams run the last
-    // verifier launches and the last round.  The literal kernel is a chain of dependent loads with a few thousand
-    // wavefronts; the verifier is bound by HBM bandwidth.  What later chunks defer is mapped at the end as before.
-    lit_side = opt.se_lit_side != 0 && !diag && n <= kDeferMask;
-    uint32_t* const ctl2 = ctl0 + 64 * kPat + 8;  // [0] count of the side launch, [8..23] its bins
-    uint32_t* const rng = ctl2 + 32;              // {entries the side launch took, the list's final length}
+    // The reads with a truly dangerous probe.  Default: the strand-major kernel (k_map_se_literal, the reference's search
+    // inferred: core.h lit_region_inferred) on a low-priority side stream: after the last look-up round of the first chunk
+    // (of each half) the list is complete but for what later chunks add (nothing, when the heavy list fits these
+    // chunks); it is sorted and mapped while the main streams run the last verifier launches and the last round; what
+    // later chunks defer is mapped at the end.  Option se_lit_staged = 1: through staged rounds instead (below).
+    const bool lit_staged = opt.se_lit_staged != 0 && !diag;
+    lit_side = !lit_staged && opt.se_lit_side != 0 && !diag && n <= kDeferMask;
+    uint32_t* const ctl2 = ctl0 + 64 * kPat;  // [0] count of the side launch, [8..23] its bins (the literal rounds' words: one or the other)
+    uint32_t* const rng_side = ctl2 + 32;     // {entries the side launch took, the list's final length}
+    static_assert(8 * kPat * kLitChunks >= 34, "the side launch's control words fit the literal rounds' area");
     if (lit_side && !idx->se_side) {
       int lo_pri = 0, hi_pri = 0;
       WALT_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
@@ -1559,46 +1585,41 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       WALT_HIP(hipEventRecord(idx->se_pipe_ev[0], stream));
       WALT_HIP(hipStreamWaitEvent(idx->se_pipe, idx->se_pipe_ev[0], 0));
     }
-    for (uint32_t c = 0; c < chunks; ++c) {
-      const bool odd = piped && (c & 1u);
-      hipStream_t cs = odd ? idx->se_pipe : stream;
-      forked = forked || odd;
-      uint32_t* lists = nullptr;
-      use_slot(odd ? 1u : 0u, lists);
-      hs.first = c * hcap;
-      hs.chunk = c;
-      // chunks behind the first pair append to the deferred list: not while the side launch's share is being fixed
-      if (piped && lit_side && c == 2) WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_fork, 0));
+    // the rounds of one chunk: look-up stage, then the verifiers of its items, kPat times, and the final fold
+    auto run_chunk = [&](hipStream_t cs, uint32_t* ctl_base, uint32_t* lists, bool lit, const uint32_t* count, const uint32_t* list,
+                         const SeCarry& cy, bool marks, uint32_t c_side) -> int {
       const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
       for (uint32_t round = 0; round <= kPat; ++round) {
         hs.round = round;
-        hs.ctl = ctl0 + 8 * (kPat * c + (round < kPat ? round : 0));
+        hs.ctl = ctl_base + 8 * (round < kPat ? round : 0);
         hs.list_in = round ? lists + (uint64_t)(round - 1) * hcap : nullptr;
-        hs.count_in = round ? ctl0 + 8 * (kPat * c + round - 1) : nullptr;
+        hs.count_in = round ? ctl_base + 8 * (round - 1) : nullptr;
         hs.list_out = round < kPat ? lists + (uint64_t)round * hcap : nullptr;
-        if (NW <= 10 && opt.se_stage_occ == (NW <= 8 ? 3 : 2))  // A/B (option se_stage_occ): one wavefront per SIMD fewer, more registers
+        if (lit)
+          hipLaunchKernelGGL((k_se_stage<NW, 0, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
+                             strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
+        else if (NW <= 10 && opt.se_stage_occ == (NW <= 8 ? 3 : 2))  // A/B (option se_stage_occ): one wavefront per SIMD fewer, more registers
           hipLaunchKernelGGL((k_se_stage<NW, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
-                             strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                             heavy_list, hs, carry);
+                             strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
         else
           hipLaunchKernelGGL((k_se_stage<NW>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
-                             strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, heavy_count,
-                             heavy_list, hs, carry);
-        if (!odd) mark(1);
+                             strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
+        if (marks) mark(lit ? 3 : 1);
         if (round == kPat) break;
-        if (piped && c == 0 && round == kPat - 1) WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[1], stream));
-        if (lit_side && c == (piped ? 1u : 0u) && round == kPat - 1) {
-          // (round kPat probes nothing: both halves' first chunks have made their last deferrals)
-          if (piped) WALT_HIP_FORKED(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));
-          hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, cs, defer_count, ctl2, rng);
-          WALT_HIP_FORKED(hipEventRecord(idx->se_fork, cs));
-          WALT_HIP_FORKED(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
-          forked = true;
-          launch_bin_deferred(ctl2, defer_list, defer_list + stride, idx->se_side);
-          const unsigned g_lit = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
-          hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g_lit), dim3(kBlock), 0, idx->se_side, view, codes2, offsets, err,
-                             strand_base, max_mm, b, idx->d_mask_table, out, stats, ctl2, defer_list + stride, 0u);
-          WALT_HIP_FORKED(hipEventRecord(idx->se_join, idx->se_side));
+        if (!lit && round == kPat - 1) {  // (round kPat probes nothing: this chunk has made its last deferrals)
+          if (piped && c_side == 0) WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[1], stream));
+          if (lit_side && c_side == (piped ? 1u : 0u)) {
+            if (piped) WALT_HIP_FORKED(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));
+            hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, cs, defer_count, ctl2, rng_side);
+            WALT_HIP_FORKED(hipEventRecord(idx->se_fork, cs));
+            WALT_HIP_FORKED(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
+            forked = true;
+            launch_bin_deferred(ctl2, defer_list, defer_list + stride, idx->se_side);
+            const unsigned g_lit = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+            hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g_lit), dim3(kBlock), 0, idx->se_side, view, codes2, offsets, err,
+                               strand_base, max_mm, b, idx->d_mask_table, out, stats, ctl2, defer_list + stride, 0u);
+            WALT_HIP_FORKED(hipEventRecord(idx->se_join, idx->se_side));
+          }
         }
         if constexpr (NW <= 10 && long_seed_nw<NW>())
           hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(pg), dim3(kBlock), 0, cs, view, strand_base, hs, b);
@@ -1606,23 +1627,61 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
           hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b, err);
         }
         hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b, err);
-        if (!odd) mark(2);
+        if (marks) mark(lit ? 3 : 2);
       }
+      return WALT_OK;
+    };
+    for (uint32_t c = 0; c < chunks; ++c) {
+      const bool odd = piped && (c & 1u);
+      forked = forked || odd;
+      uint32_t* lists = nullptr;
+      use_slot(odd ? 1u : 0u, lists);
+      hs.first = c * hcap;
+      hs.chunk = c;
+      // chunks behind the first pair append to the deferred list: not while the side launch's share is being fixed
+      if (piped && lit_side && c == 2) WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_fork, 0));
+      const int rc_chunk = run_chunk(odd ? idx->se_pipe : stream, ctl0 + 8 * kPat * c, lists, false, heavy_count, heavy_list, carry, !odd, c);
+      if (rc_chunk) return rc_chunk;
     }
     if (piped) {  // the second half joins
       WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[2], idx->se_pipe));
       WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_pipe_ev[2], 0));
     }
+    // ---- the literal rounds: the reads the rounds above gave up at a truly dangerous probe (0.9 % of the reads of a
+    // 93-sequence genome, a fifth of those of a 3,000-contig assembly) go through the same rounds once more with the
+    // reference's search switched on (k_se_stage<.., LIT>), kLitChunks chunks of the deferred list; what lies behind
+    // them -- nothing, unless more than 2 x hcap reads were deferred -- is left to the strand-major kernel below.
+    if (lit_staged) {
+      hs.even = 0;
+      for (uint32_t c = 0; c < kLitChunks && c < chunks; ++c) {
+        uint32_t* lists = nullptr;
+        use_slot(geo.piped ? (c & 1u) : 0u, lists);
+        hs.first = c * hcap;
+        hs.chunk = c;
+        const int rc_chunk = run_chunk(stream, ctl0 + 64 * kPat + 8 * kPat * c, lists, true, defer_count, defer_list, SeCarry(), true, 0xFFFFFFFFu);
+        if (rc_chunk) return rc_chunk;
+      }
+      hipLaunchKernelGGL(k_lit_rest, dim3(1), dim3(1), 0, stream, defer_count, rng,
+                         (kLitChunks < chunks ? kLitChunks : chunks) * hcap);
+      lit_done = true;
+    }
   }
   debug_sync("heavy pass", stream);
   mark(1);  // (the one-kernel heavy pass, when that is what ran)
   if (lit_side) {  // what the chunks behind the first one deferred (usually nothing), then the side launch ends the call
-    uint32_t* const rng = heavy_area + 64 * kPat + 40;
-    hipLaunchKernelGGL(k_lit_rest, dim3(1), dim3(1), 0, stream, defer_count, rng);
+    uint32_t* const rng_side = heavy_area + 64 * kPat + 32;
+    hipLaunchKernelGGL(k_lit_end, dim3(1), dim3(1), 0, stream, defer_count, rng_side);
+    unsigned g3 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+    hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g3), dim3(kBlock), 0, stream, view, codes2, offsets, err,
+                       strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, rng_side);
+    WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_join, 0));
+    mark(3);
+    return WALT_OK;
+  }
+  if (lit_done) {  // deferred reads behind the literal rounds' chunks (usually none)
     unsigned g3 = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
     hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g3), dim3(kBlock), 0, stream, view, codes2, offsets, err,
                        strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, 0u, rng);
-    WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_join, 0));
     mark(3);
     return WALT_OK;
   }
