@@ -145,14 +145,15 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
     }
   }
   const uint32_t Bd = h->view.dir_bits, slots = h->view.dir_slots;
-  s.dir.assign((size_t)slots + 1, index_size);
+  // dir[S - v] = 1 + the largest index slot whose code prefix is below v (core.h StrandView::dir)
+  s.dir.assign((size_t)slots + 1, 0u);
   for (uint32_t j = 0; j < index_size; ++j) {
     uint32_t v = ent_prefix(s.g2.data(), s.ent[j], ga, Bd);
-    uint32_t& d = s.dir[slots - v];
-    if (j < d) d = j;
+    uint32_t& d = s.dir[slots - 1 - v];
+    if (j + 1 > d) d = j + 1;
   }
-  for (size_t k = 1; k <= slots; ++k)
-    if (s.dir[k - 1] < s.dir[k]) s.dir[k] = s.dir[k - 1];
+  for (size_t k = slots; k-- > 0;)
+    if (s.dir[k + 1] > s.dir[k]) s.dir[k] = s.dir[k + 1];
   s.view.g2 = s.g2.data(); s.view.cnt = s.cnt.data(); s.view.bad = s.bad.data(); s.view.dir = s.dir.data();
   s.view.ent = s.ent.data(); s.view.index_size = index_size; s.view.genome_len = genome_len; s.view.ga = ga;
   s.view.bloom = nullptr; s.view.bloom_mask = 0; s.view.outl = s.outl.data(); s.view.n_outl = (uint32_t)s.outl.size();

@@ -2,10 +2,10 @@
 # Paired-end kernels one at a time (WALT_AMD_PE_SERIAL=1): per-kernel time, HBM bytes read and written per step.
 set -u
 TAG=$1; shift
-export TMPDIR=/tmp WALT_AMD_PE_SERIAL=1
+export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"
 OUT=gpurun_out/pes_$TAG; mkdir -p $OUT
-ARGS="--mode pe --no-extra --no-cpu-baseline --steps 2 --warmup 1 $*"
+ARGS="--mode pe --no-extra --no-cpu-baseline --steps 2 --warmup 1 --opt pe_serial=1 $*"
 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/trace -o t -- python3 bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.log || { tail -5 $OUT/trace.log; exit 1; }
 python3 tools/trace_sum.py $OUT/trace 3 > $OUT/trace_sum.txt
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $R/$OUT/pmc_rd -o p -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_rd.log || { tail -5 $OUT/pmc_rd.log; exit 1; }

@@ -28,9 +28,13 @@
 //          so the code gives that letter one bit and the others two
 //          (C->T: A=00 G=01 T=1;  G->A: A=0 C=10 T=11): code bits of an iid genome
 //          are uniform, slots are evenly filled, and bit-string order equals
-//          the index's lexicographic order.  dir is stored REVERSED:
-//          dir[S - v] = first index slot whose code prefix is >= v (S = 2^Bd),
-//          so that it is the running minimum of a forward scan when built.
+//          the index's lexicographic order.  dir is stored REVERSED (S = 2^Bd):
+//          dir[S - v] = 1 + the last index slot whose code prefix is below v
+//          (round 4; until then: the first slot whose prefix is >= v -- the same
+//          number wherever the index is sorted; they differ at chromosome-end
+//          entries, which makedb sorts in front of where their real characters
+//          belong: those pull "first >= v" down and leave "last < v" alone, which
+//          is what the inferred literal search needs, stretch_bounds).
 //          Replaces the per-character LowerBound/UpperBound narrowing of the
 //          first ~20 care characters by one lookup.
 #ifndef WALT_AMD_CORE_H_
@@ -1212,11 +1216,13 @@ inline unsigned long long*& memo_stats() { static unsigned long long* p = nullpt
 // lit_region over the whole bucket for every dangerous probe.  Diagnostic counters: searches made, entries loaded.
 struct InferStats { uint32_t searches, loads, steps, dirs; };
 // [b1, b2) = the entries of the sorted stretch [lo, hi) whose characters 12..pe equal the probe's.  While the prefix code
-// of the characters 0..pe fits the directory's depth, they are two directory words (independent loads, one round trip
-// however large the bucket): dir gives the first index, over the WHOLE index, of an entry whose real characters are not
-// below the probe's prefix -- inside the stretch every entry is sorted on real characters, behind it every entry is
-// larger, so a value that lies inside [lo, hi] is the stretch's own bound; a value in front of lo was pulled there by
-// an outlier's real bytes (a head of one of the probe's groups) and is not used: the key search over the stretch decides.
+// of the characters 0..pe fits the directory's depth they are two directory words (independent loads, one round trip
+// however large the bucket).  R[v] = 1 + the largest index of an entry whose REAL prefix is below v.  Inside the
+// stretch every entry is sorted on real characters and every entry behind the stretch is larger; the entries an index
+// holds out of place are chromosome-end entries, which makedb puts IN FRONT of where their real characters belong
+// ("beyond the end" ranks lowest) -- they can sit in front of the stretch with a prefix at or above v, which does not
+// raise R[v], or with one below v, and then they lie in front of the stretch anyway.  So R[v] is the stretch's first entry
+// with prefix >= v whenever some entry of the stretch lies in front of that one, and at most lo otherwise: max(R[v], lo).
 WALT_HD void stretch_bounds(const StrandView& sv, const uint32_t* care, uint32_t Bd, uint64_t T, uint32_t pe, uint32_t lo,
                             uint32_t hi, uint32_t& b1, uint32_t& b2, InferStats* st) {
   if (hi <= lo) { b1 = b2 = lo; return; }
@@ -1233,29 +1239,28 @@ WALT_HD void stretch_bounds(const StrandView& sv, const uint32_t* care, uint32_t
     const uint32_t slot = dir_top(Bd) - v_lo;
     const uint32_t d = (sv.dir + (uint32_t)(slot - 1u))[1], e = sv.dir[(uint32_t)(slot - span)];
     if (st) ++st->dirs;
-    if (d >= lo && e >= d && e <= hi) { b1 = d; b2 = e; return; }
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (getenv("WALT_DBG_DIR")) fprintf(stderr, "dir miss: pe %u nb %u Bd %u d %u e %u lo %u hi %u\n", pe, nb, Bd, d, e, lo, hi);
-#endif
+    b1 = d > lo ? d : lo;
+    b2 = e > lo ? e : lo;
+    b1 = b1 < hi ? b1 : hi;
+    b2 = b2 < hi ? b2 : hi;
+    return;
   }
-#if !defined(__HIP_DEVICE_COMPILE__)
-  else if (getenv("WALT_DBG_DIR")) fprintf(stderr, "dir n/a: pe %u nb %u Bd %u\n", pe, nb, Bd);
-#endif
   const uint64_t M = key_mask_fwd(pe - kKeyWeight + 1);
   masked_bounds(sv, lo, hi, T & M, M, b1, b2);
   if (st) ++st->searches;
 }
 template <class QOf>
 WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, uint32_t seed_len, uint32_t first,
-                                   uint32_t second, const QOf& q_of, InferStats* st = nullptr, uint32_t Bd = 0) {
+                                   uint32_t second, const QOf& q_of, InferStats* st = nullptr, uint32_t Bd = 0,
+                                   bool levels_known = false, uint32_t levels_in = 0) {
   const uint32_t h = care[0] >> 8;
   const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
   const uint64_t T = target_key(care);
   // levels with heads: bit q - 12 for every outlier with q < lim that shares T's characters 12..q-1 -- from the level
   // table (four independent look-ups a round), or by walking the bucket's outliers
-  uint32_t levels = 0, o_lo = 0;
-  bool have_table;
-  {
+  uint32_t levels = levels_in, o_lo = 0;
+  bool have_table = levels_known;  // (the caller's danger test has looked the levels up already)
+  if (!levels_known) {
     bool dng;
     uint32_t q_first;
     have_table = olev_relevant(sv, h, T, lim, levels, dng, q_first);
@@ -1285,6 +1290,12 @@ WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, u
   }
   LitMemo memo;
   memo_init(memo);
+  // (the memo serves here as a cache of loaded entries only: an entry is loaded where the stretch's bounds say nothing --
+  // heads, entries from outside the group -- and no such entry is an anchor FACT S could trust.  So q is not worked out:
+  // on the device that is a bisection over the chromosome starts, a dozen dependent loads per loaded entry, and a probe
+  // from a low-complexity stretch loads heads at every step -- round 4: 2.5 ms for the slowest lane of every wavefront)
+  struct QNone { WALT_HD uint32_t operator()(uint32_t) const { return 0u; } } q_none;
+  (void)q_of;
   uint32_t p = kKeyWeight, l = first, u = second - 1, cl = first, cu = second;  // G_12 = the bucket
   while (p < lim) {
     const bool pure = l == cl && u + 1 == cu;
@@ -1324,20 +1335,20 @@ WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, u
     uint32_t low = l, high = u;
     while (low < high) {  // LowerBound, mapping.cpp:166-180
       const uint32_t mid = low + (high - low) / 2;
-      const bool ge = (mid >= s0 && mid < cu) ? mid >= LB : memo_char(sv, memo, q_of, mid, p, l, u) >= ch;
+      const bool ge = (mid >= s0 && mid < cu) ? mid >= LB : memo_char(sv, memo, q_none, mid, p, l, u) >= ch;
       if (ge) high = mid; else low = mid + 1;
     }
     const uint32_t nl = low;
     high = u;
     while (low < high) {  // UpperBound, mapping.cpp:182-196
       const uint32_t mid = low + (high - low + 1) / 2;
-      const bool le = (mid >= s0 && mid < cu) ? mid < UB : memo_char(sv, memo, q_of, mid, p, nl, u) <= ch;
+      const bool le = (mid >= s0 && mid < cu) ? mid < UB : memo_char(sv, memo, q_none, mid, p, nl, u) <= ch;
       if (le) low = mid; else high = mid - 1;
     }
     l = nl;
     u = low;
     if (l == u) {  // mapping.cpp:206-211
-      const bool eq = (l >= s0 && l < cu) ? (l >= LB && l < UB) : memo_char(sv, memo, q_of, l, p, l, u) == ch;
+      const bool eq = (l >= s0 && l < cu) ? (l >= LB && l < UB) : memo_char(sv, memo, q_none, l, p, l, u) == ch;
       if (!eq) { if (st) st->loads += memo.loads; return empty_region(); }
     }
     cl = LB; cu = UB;  // G_(p+1)
@@ -1365,13 +1376,17 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
   // IndexRegion's loop over [F2SEEDKEYWEIGHT, seed_len) is empty there and the region is the whole bucket)
   uint32_t n = seed_len > kKeyWeight ? seed_len - kKeyWeight : 0u;
   if (!known_good) {
-    const uint32_t level = probe_danger_level(sv, care, seed_len);
+    uint32_t lv_mask = 0, q_first = 0;
+    bool dng = false;
+    const uint32_t lim_t = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
+    const bool lv_known = !bucket_is_bad(sv, h) && olev_relevant(sv, h, target_key(care), lim_t, lv_mask, dng, q_first);
+    const uint32_t level = lv_known ? (dng ? q_first : 0u) : probe_danger_level(sv, care, seed_len);
     if (level) {
       uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
       if (first == second) return;                         // mapping.cpp:271-272
       if (literal_mode() == 2 && !bucket_is_bad(sv, h)) {  // (a BAD bucket -- disorder no outlier explains -- keeps the plain search)
         InferStats ist = {0, 0, 0, 0};
-        out.reg = lit_region_inferred(sv, care, seed_len, first, second, q_of, memo_stats() ? &ist : nullptr, iv.dir_bits);
+        out.reg = lit_region_inferred(sv, care, seed_len, first, second, q_of, memo_stats() ? &ist : nullptr, iv.dir_bits, lv_known, lv_mask);
         if (memo_stats()) { memo_stats()[0] += 1; memo_stats()[1] += 1; memo_stats()[2] += ist.loads; memo_stats()[3] += ist.searches; memo_stats()[4] += ist.steps;
                             const uint32_t cst = ist.loads + ist.searches + ist.dirs; memo_stats()[6 + (cst < 63 ? cst : 63)] += 1; memo_stats()[5] += 0; memo_stats()[69] += ist.dirs; }
         return;

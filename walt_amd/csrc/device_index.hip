@@ -211,18 +211,74 @@ __global__ void k_make_table(const uint32_t* __restrict__ dir, const Ent* __rest
     tab[3 * t] = w0; tab[3 * t + 1] = w1; tab[3 * t + 2] = w2;
   }
 }
-__global__ void k_carry_min(uint32_t* __restrict__ p) {  // p[0] = min(p[-1], p[0]): joins two pieces of the running minimum
-  if (p[-1] < p[0]) p[0] = p[-1];
-}
+// Directory (core.h StrandView::dir), reversed: dir[S - v] = R[v] = 1 + the largest index slot whose code prefix is
+// below v (0 when there is none).  Step 1: every entry that ends a run of equal prefixes u writes its index + 1 at R's
+// position u + 1 (atomicMax: an entry out of place -- a chromosome-end entry, a BAD bucket -- must not lower it).
+// Step 2: running maximum over rising v, i.e. over FALLING array index (k_rmax_*).
 __global__ void k_dir_scatter(const uint32_t* __restrict__ g2, const Ent* __restrict__ ent, uint32_t n, uint32_t ga,
                               uint32_t Bd, uint32_t* __restrict__ dir) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const uint32_t v = ent_prefix_dev(g2, ent[j], ga, Bd);
-  // the predecessor's prefix comes from the neighbouring lane (the first lane of a wave computes it)
-  uint32_t pv = __shfl_up(v, 1);
-  if ((threadIdx.x & 63) == 0 && j) pv = ent_prefix_dev(g2, ent[j - 1], ga, Bd);
-  if (j == 0 || pv != v) atomicMin(&dir[(1ull << Bd) - v], j);
+  // the successor's prefix comes from the neighbouring lane (the last lane of a wave computes it)
+  uint32_t nv = __shfl_down(v, 1);
+  if (((threadIdx.x & 63) == 63 || j + 1 == n) && j + 1 < n) nv = ent_prefix_dev(g2, ent[j + 1], ga, Bd);
+  if (j + 1 == n || nv != v) atomicMax(&dir[(1ull << Bd) - 1ull - v], j + 1);
+}
+// running maximum from the array's end towards its start, in segments of kRmaxSeg elements:
+// 1. the maximum of every segment, 2. seg[b] := max of the segments behind b, 3. the scan inside each segment
+constexpr uint32_t kRmaxSeg = 1u << 16;
+__global__ void k_rmax_reduce(const uint32_t* __restrict__ p, uint64_t total, uint32_t* __restrict__ seg) {
+  const uint64_t base = (uint64_t)blockIdx.x * kRmaxSeg;
+  uint32_t m = 0;
+  for (uint64_t i = base + threadIdx.x; i < base + kRmaxSeg && i < total; i += blockDim.x) m = p[i] > m ? p[i] : m;
+  __shared__ uint32_t red[kBlock];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (uint32_t s = kBlock / 2; s; s >>= 1) {
+    if (threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) seg[blockIdx.x] = red[0];
+}
+__global__ void k_rmax_carry(uint32_t* __restrict__ seg, uint32_t n_seg) {  // one thread: a few ten thousand segments
+  uint32_t run = 0;
+  for (uint32_t b = n_seg; b-- > 0;) {
+    const uint32_t own = seg[b];
+    seg[b] = run;
+    run = own > run ? own : run;
+  }
+}
+__global__ void k_rmax_apply(uint32_t* __restrict__ p, uint64_t total, const uint32_t* __restrict__ seg) {
+  // thread t owns the kRmaxSeg / kBlock consecutive elements [lo, hi) of the block's segment
+  constexpr uint32_t kPer = kRmaxSeg / kBlock;
+  const uint64_t base = (uint64_t)blockIdx.x * kRmaxSeg + (uint64_t)threadIdx.x * kPer;
+  uint32_t m = 0;
+  for (uint32_t k = 0; k < kPer; ++k) {
+    const uint64_t i = base + k;
+    if (i < total && p[i] > m) m = p[i];
+  }
+  __shared__ uint32_t part[kBlock];
+  part[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // suffix maxima over the threads' parts (256 of them)
+    uint32_t run = seg[blockIdx.x];
+    for (uint32_t t = kBlock; t-- > 0;) {
+      const uint32_t own = part[t];
+      part[t] = run;
+      run = own > run ? own : run;
+    }
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (uint32_t k = kPer; k-- > 0;) {
+    const uint64_t i = base + k;
+    if (i < total) {
+      const uint32_t own = p[i];
+      run = own > run ? own : run;
+      p[i] = run;
+    }
+  }
 }
 
 __global__ void k_popcount(const uint32_t* __restrict__ words, uint32_t n, unsigned long long* __restrict__ out) {
@@ -358,30 +414,20 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
       hipLaunchKernelGGL(k_mark_unsorted, dim3(grid_for(index_size - 1)), dim3(kBlock), 0, stream, g2, ent,
                          index_size, idx->view.start_index, n_chrom, bad);
   }
-  // reversed directory: fill with "past the end", scatter run starts, running minimum
-  hipLaunchKernelGGL(k_fill_u32, dim3(1u << 16), dim3(kBlock), 0, stream, dir, (uint64_t)slots + 1, index_size);
+  // reversed directory: fill with 0, scatter run ends, running maximum towards the array's start
+  hipLaunchKernelGGL(k_fill_u32, dim3(1u << 16), dim3(kBlock), 0, stream, dir, (uint64_t)slots + 1, 0u);
   if (index_size)
     hipLaunchKernelGGL(k_dir_scatter, dim3(grid_for(index_size)), dim3(kBlock), 0, stream, g2, ent, index_size, ga,
                        Bd, dir);
   {
-    // running minimum in pieces of 2^30 elements (a 2^32-slot directory has more elements than a 32-bit
-    // count holds); a piece starts from the minimum the previous one ended with
-    const uint64_t total = slots + 1, piece = 1ull << 30;
-    size_t tmp_bytes = 0;
-    WALT_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, dir, dir, (size_t)(total < piece ? total : piece),
-                                     rocprim::minimum<uint32_t>(), stream));
-    WALT_HIP(hipMalloc(&tmp_buf.p, tmp_bytes ? tmp_bytes : 16));
-    void* tmp = tmp_buf.p;
-    hipError_t se = hipSuccess;
-    for (uint64_t at = 0; at < total && se == hipSuccess; at += piece) {
-      const uint64_t cnt = total - at < piece ? total - at : piece;
-      if (at) hipLaunchKernelGGL(k_carry_min, dim3(1), dim3(1), 0, stream, dir + at);
-      size_t tb = tmp_bytes;
-      se = rocprim::inclusive_scan(tmp, tb, dir + at, dir + at, (size_t)cnt, rocprim::minimum<uint32_t>(), stream);
-    }
-    hipError_t sy = hipStreamSynchronize(stream);
-    WALT_HIP(se);
-    WALT_HIP(sy);
+    const uint64_t total = slots + 1;
+    const uint32_t n_seg = (uint32_t)((total + kRmaxSeg - 1) / kRmaxSeg);
+    WALT_HIP(hipMalloc(&tmp_buf.p, (size_t)n_seg * 4 + 16));
+    uint32_t* seg = reinterpret_cast<uint32_t*>(tmp_buf.p);
+    hipLaunchKernelGGL(k_rmax_reduce, dim3(n_seg), dim3(kBlock), 0, stream, dir, total, seg);
+    hipLaunchKernelGGL(k_rmax_carry, dim3(1), dim3(1), 0, stream, seg, n_seg);
+    hipLaunchKernelGGL(k_rmax_apply, dim3(n_seg), dim3(kBlock), 0, stream, dir, total, seg);
+    WALT_HIP(hipStreamSynchronize(stream));
   }
   // Slot table (opt-in, WALT_AMD_TABLE=1): measured at hg19 scale with 2^32 slots it takes pass 1 from 11.45
   // to 10.9 ms (+5 % reads/s) for 51.5 GB more per strand -- not enough to be the default; it needs the device

@@ -712,7 +712,8 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
 struct SurvivorSink {
   PeStage ps;
   uint32_t max_mm, top_k;
-  uint32_t* hist;  // 64 LDS words of this wavefront: survivors of the current item by mismatch count (63 = and more)
+  uint32_t* hist;  // (unused since round 4: the histogram lives in registers)
+  uint32_t hreg;   // this lane's bin of the item's survivors by mismatch count: lane t counts t mismatches (63 = and more)
   uint32_t id, cnt, bound;  // bound: candidates with at least this many mismatches can no longer enter the heap
   uint32_t cur;             // number of the chunk that holds survivor cnt - 1 (wave-uniform)
   uint32_t pos, seed;       // the item's place in the queue and its seed shift (static first chunk)
@@ -733,7 +734,7 @@ struct SurvivorSink {
     bound = 0xFFFFFFFFu;
     cur = 0;
     over = false;
-    hist[threadIdx.x & 63] = 0;
+    hreg = 0;
   }
   __device__ __forceinline__ void add(uint32_t, uint32_t gp, uint32_t mm, bool in) { gp_ = gp; mm_ = mm; in_region += in ? 1u : 0u; }
   // the c-th chunk of this probe: a number from the pool, noted in the probe's chunk table (wave-uniform result)
@@ -773,13 +774,20 @@ struct SurvivorSink {
     const uint32_t nxt = c1 != c0 ? take_chunk(c1) : cur;
     if (pass && !over) ps.pool[(uint64_t)(at / kPeChunkEnts == c0 ? cur : nxt) * kPeChunkEnts + at % kPeChunkEnts] = make_uint2(gp_, mm_);
     cur = nxt;
-    if (pass) atomicAdd(&hist[mm_ < 63u ? mm_ : 63u], 1u);
+    // the histogram: one ballot per mismatch count that can pass (0 .. -m), lane t keeps bin t -- no LDS atomics
+    // (64 lanes on seven addresses were serialised there, step after step)
+    {
+      const uint32_t top = max_mm < 63u ? max_mm : 63u;
+      for (uint32_t t = 0; t <= top; ++t) {  // (uniform)
+        const unsigned long long mt = __ballot(pass && (mm_ < 63u ? mm_ : 63u) == t);
+        hreg += lane == t ? (uint32_t)__popcll(mt) : 0u;
+      }
+    }
     cnt += n;
     if (cnt >= top_k) {
       // smallest t with top_k survivors of at most t mismatches: the heap is then full of candidates that good
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       uint32_t total;
-      const uint32_t h = hist[lane];
+      const uint32_t h = hreg;
       const uint32_t before = wave_excl_scan_u32(h, lane, total);
       const unsigned long long ge = __ballot(before + h >= top_k);
       const uint32_t t = ge ? (uint32_t)__ffsll((long long)ge) - 1u : 63u;
@@ -789,9 +797,10 @@ struct SurvivorSink {
   __device__ __forceinline__ void end() {
     const uint32_t j = id & 0xFFFFFFu, probe = (id >> 24) & 7u;
     const bool skip = tail && wave_sum_u32(in_region) > b;  // (uniform) the narrowed region exceeds -b: the probe pushes nothing
+    const uint32_t hv0 = bcast(hreg, 0), hv1 = bcast(hreg, 1);
     if ((threadIdx.x & 63) == 0) {
       ps.surv_n[(uint64_t)probe * ps.ccap + j] = (skip ? 0u : cnt) | 0x80000000u;
-      const uint32_t h0 = skip ? 0u : hist[0], h1 = skip ? 0u : h0 + hist[1];
+      const uint32_t h0 = skip ? 0u : hv0, h1 = skip ? 0u : h0 + hv1;
       ps.cz[(uint64_t)probe * ps.ccap + j] = (h0 < 0xFFFFu ? h0 : 0xFFFFu) | ((h1 < 0xFFFFu ? h1 : 0xFFFFu) << 16);
       if (over) atomicOr(&ps.flag[j], 2u);
     }
