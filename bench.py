@@ -417,34 +417,82 @@ def e2e_leg(cx, scratch, dbi, host_bases, times_host, read_len, n_e2e, max_mm, b
     out = os.path.join(scratch, "e2e.sam")
     cmd = [our_bin, "-i", dbi, "-r", fq, "-o", out, "-m", str(max_mm), "-b", str(b), "-a", "-u", "-sam", "-t", str(cores),
            "-N", str(batch), "-v"]
+    env = dict(os.environ)
+    env["WALT_AMD_HOST_CEILING"] = "1"  # -v then also measures what the host side can copy and store at all (walt_main.cpp host_ceiling)
     t0 = time.perf_counter()
-    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
     wall = time.perf_counter() - t0
     if pr.returncode != 0:
         return {"skipped": "bin/walt failed: " + pr.stdout[-300:]}
-    stages = {}
-    for ln in pr.stdout.splitlines():
-        if ln.startswith("[walt_amd:"):
-            for key, pat in (("index_s", r"index ([0-9.]+) s"), ("ingest_not_hidden_s", r"previous batch ([0-9.]+) s"),
-                             ("map_s", r"map ([0-9.]+) s"), ("format_s", r"format ([0-9.]+) s"), ("write_s", r"write ([0-9.]+) s")):
-                mt = re.search(pat, ln)
-                if mt:
-                    stages[key] = float(mt.group(1))
+
+    def parse_stages(text):
+        st_ = {}
+        for ln in text.splitlines():
+            if ln.startswith("[walt_amd:"):
+                for key, pat in (("index_s", r"index ([0-9.]+) s"), ("ingest_not_hidden_s", r"previous batch ([0-9.]+) s"),
+                                 ("map_s", r"map ([0-9.]+) s"), ("format_s", r"format ([0-9.]+) s"), ("write_s", r"write ([0-9.]+) s"),
+                                 ("since_main_s", r"since main ([0-9.]+) s")):
+                    mt = re.search(pat, ln)
+                    if mt:
+                        st_[key] = float(mt.group(1))
+        return st_
+    stages = parse_stages(pr.stdout)
+    ceiling = {}
+    mt = re.search(r"host ceiling: memcpy ([0-9.]+) GB/s on (\d+) threads, pwrite into one file ([0-9.]+) GB/s", pr.stdout)
+    if mt:
+        ceiling = {"memcpy_gb_per_s": float(mt.group(1)), "threads": int(mt.group(2)), "pwrite_one_file_gb_per_s": float(mt.group(3))}
+        wall -= 0.0  # (the measurement runs after the last output file is closed; its time is inside `wall`, not inside the stages)
     st = read_mapstats(out + ".mapstats")
     t = times_host[:n_e2e]
     mine = {"unique": int((t == 1).sum()), "ambiguous": int((t >= 2).sum()), "unmapped": int((t == 0).sum())}
     key_of = {"unique": "unique_mapped_reads", "ambiguous": "ambiguous_mapped_reads", "unmapped": "unmapped_reads"}
     same = all(int(st.get(key_of[k], st.get(k, -1))) == v for k, v in mine.items())
     sam_bytes = os.path.getsize(out)
-    resident = wall - stages.get("index_s", 0.0)
+    # the binary's own clock ("since main", printed before the ceiling measurement) when it is there: the wall clock of
+    # this process also holds the ceiling measurement and the child's start
+    run_s = stages.get("since_main_s", wall)
+    resident = run_s - stages.get("index_s", 0.0)
+    # several index replicas (-g 0,0: two on this box's one GPU when they fit): the multi-device host path, timed
+    multi = None
+    try:
+        out2 = os.path.join(scratch, "e2e_g00.sam")
+        n2 = min(n_e2e, batch)
+        fq2 = os.path.join(scratch, "e2e_g00.fastq")
+        write_fastq(fq2, host_bases, n2, read_len)
+        cmd2 = [our_bin, "-i", dbi, "-r", fq2, "-o", out2, "-m", str(max_mm), "-b", str(b), "-a", "-u", "-sam", "-t", str(cores),
+                "-N", str(batch), "-v", "-g", "0,0"]
+        t0 = time.perf_counter()
+        pr2 = subprocess.run(cmd2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        w2 = time.perf_counter() - t0
+        if pr2.returncode == 0:
+            st2 = parse_stages(pr2.stdout)
+            r2 = st2.get("since_main_s", w2) - st2.get("index_s", 0.0)
+            multi = {"devices": "0,0", "reads": n2, "wall_s": w2, "stages_s": st2, "reads_per_s_index_load_excluded": n2 / max(1e-9, r2)}
+        else:
+            multi = {"skipped": "bin/walt -g 0,0 failed (two index replicas on one GPU): " + pr2.stdout[-200:]}
+        for f in (fq2, out2, out2 + ".mapstats"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    except Exception as e:
+        multi = {"skipped": "%s: %s" % (type(e).__name__, e)}
     line = {"metric": "reads/s end to end, FASTQ -> SAM through walt_amd/bin/walt (%d bp single-end, -m %d -b %d -a -u -sam), "
                       "index load excluded" % (read_len, max_mm, b),
             "value": n_e2e / resident, "unit": "reads/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "the first %d reads of the headline batch as a FASTQ file (%.1f GB) and the headline index as "
                                    ".dbindex files, both on RAM-backed scratch; -N %d (%d batches), -t %d host threads" % (
                                        n_e2e, os.path.getsize(fq) / 1e9, batch, (n_e2e + batch - 1) // batch, cores)},
-            "wall_s": wall, "reads_per_s_whole_wall": n_e2e / wall, "stages_s": stages, "sam_bytes": sam_bytes,
-            "fastq_write_s": t_fq, "mapstats_equal_gpu_records": bool(same), "host_threads": cores}
+            "wall_s": run_s, "reads_per_s_whole_wall": n_e2e / run_s, "stages_s": stages, "sam_bytes": sam_bytes,
+            "fastq_write_s": t_fq, "mapstats_equal_gpu_records": bool(same), "host_threads": cores,
+            # the host's own limits, measured by the same binary in the same run: the format stage against the threads'
+            # memcpy rate, the write stage against pwrite into one file
+            "host_ceiling": ceiling,
+            "format_gb_per_s": (sam_bytes / stages["format_s"] / 1e9) if stages.get("format_s") else None,
+            "write_gb_per_s": (sam_bytes / stages["write_s"] / 1e9) if stages.get("write_s") else None,
+            "write_frac_of_pwrite_ceiling": (sam_bytes / stages["write_s"] / 1e9 / ceiling["pwrite_one_file_gb_per_s"])
+            if stages.get("write_s") and ceiling.get("pwrite_one_file_gb_per_s") else None,
+            "two_replicas_one_gpu": multi}
     for f in (fq, out):
         try:
             os.remove(f)

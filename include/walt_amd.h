@@ -215,6 +215,8 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
  * changes the schedule of a call, never its results.  Names (value 0 / 1 unless said otherwise):
  *   se_pipe        1  staged heavy pass in two halves on two streams
  *   se_heavy_chunk 0  reads per chunk of the heavy list (0: default; a test hook for several chunks on a small batch)
+ *   se_stage_blocks / se_verify_blocks 0  blocks per compute unit of the stage / dense verifier launches (0: fill the device)
+ *   se_stagger     0  the second half of the heavy pass starts one look-up stage behind the first
  *   se_lit_side    1  literal pass on a side stream beside the end of the heavy pass
  *   se_lit_staged  0  reads with a truly dangerous probe go through staged rounds with the reference's search on instead
  *   se_defer_min  -1  long seeds: key-equal ranges of more slots than this go to the verifier unnarrowed (-1: default 4, 0: never)

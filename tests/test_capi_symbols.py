@@ -49,3 +49,21 @@ def test_no_device_is_a_loud_error_not_a_fallback(g1_index_path):
     with pytest.raises(walt_amd.WaltError) as ei:
         walt_amd.Index.open(g1_index_path)
     assert ei.value.code == -3 and "no CPU fallback" in str(ei.value)
+
+
+def test_comm_init_fails_locally_before_the_collective():
+    """walt_comm_init does everything that can fail on THIS rank (device, stream, buffer) before it enters
+    ncclCommInitRank (csrc/comm.hip): on a box without a GPU a rank of a two-rank world returns an error at once -- it does
+    not sit in the collective waiting for a peer that will never come.  (With a GPU the call would block for the peer: skipped.)"""
+    import time
+
+    import walt_amd
+    if walt_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    L = walt_amd.lib()
+    ident = ctypes.create_string_buffer(128)
+    comm = ctypes.c_void_p()
+    t0 = time.time()
+    rc = L.walt_comm_init(0, 0, 2, ident, ctypes.byref(comm))
+    assert rc != 0 and not comm.value
+    assert time.time() - t0 < 20

@@ -334,6 +334,26 @@ def test_gpu_directory_of_2_pow_32_slots(wa, g1_db, scratch):
     idx.close()
 
 
+def test_gpu_without_fence_keys(wa, scratch, monkeypatch):
+    """WALT_AMD_FENCE=0 (read when an index is opened): no fence keys -- what an index opened on a device with little room
+    to spare looks like -- so long slots and the literal search's group bounds go through the k-ary search over the
+    entries (core.h slot_kary_bounds).  Same records as the oracle on a genome with long slots and many chromosome ends."""
+    monkeypatch.setenv("WALT_AMD_FENCE", "0")
+    seqs, db = make_random_case(31, 400, scratch)
+    rng = random.Random(31 * 31)
+    reads = sample_reads(rng, seqs, 3000, "CT")
+    want, _ = refio.oracle_se(db, reads, ag=False, max_mm=6, b=5000)
+    for D in (24, 28):
+        idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_bits=D)
+        got, _ = idx.map_se_batch(*wa.pack_reads(reads), ag_wildcard=False, max_mismatches=6, b=5000)
+        assert_best_equal(got, want, "no fence keys D=%d" % D)
+        res, _ = idx.map_pe_batch(*wa.pack_reads(reads[:1000]), *wa.pack_reads(reads[:1000]), max_mismatches=6, top_k=50)
+        wantp, _, _ = refio.oracle_pe(db, reads[:1000], reads[:1000], max_mm=6, b=5000, top_k=50, frag_range=1000)
+        for f in ("best_times", "frag_len", "pair_mm"):
+            assert np.array_equal(res[f], wantp[f]), (D, f)
+        idx.close()
+
+
 def test_gpu_slot_table(wa, g1_db, scratch, monkeypatch):
     """WALT_AMD_TABLE=1: the opt-in direct-mapped slot table (single-entry slots inline, core.h
     StrandView::tab) gives the same records as the oracle, single-end and paired-end, at two directory depths."""

@@ -37,8 +37,14 @@ static std::string g_rccl_error;
 static void load_rccl() {
   const char* names[] = {getenv("WALT_AMD_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   std::string tried;
+  // a copy the process holds already (a torch process has loaded its own librccl) is taken first: RTLD_NOLOAD returns
+  // a handle only when the library is resident, so two copies of RCCL never live in one process
   for (const char* nm : names) {
-    if (!nm || !*nm) continue;
+    if (!nm || !*nm || g_rccl.so) continue;
+    g_rccl.so = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  }
+  for (const char* nm : names) {
+    if (!nm || !*nm || g_rccl.so) continue;
     g_rccl.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.so) break;
     const char* why = dlerror();  // may be null
@@ -104,21 +110,30 @@ int walt_comm_init(int device, int rank, int world, const void* id, walt_comm** 
   *out = nullptr;
   int rc = rccl_ready();
   if (rc) return rc;
+  // everything that can fail LOCALLY comes before the collective call: a rank that returns an error from here has not
+  // entered ncclCommInitRank, so its peers are not left blocked inside it by a failure only this rank sees (the caller
+  // agrees on the ranks' status before and after: walt_amd/dist.py c_abi_cross_check)
   WALT_HIP(hipSetDevice(device));
   walt_comm* c = new walt_comm();
   c->device = device; c->rank = rank; c->world = world;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    e = hipMalloc(reinterpret_cast<void**>(&c->d_buf), 4096 * sizeof(uint64_t));
+    if (e == hipSuccess) c->cap = 4096;
+  }
+  if (e != hipSuccess) {
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return fail(WALT_EHIP, std::string("walt_comm_init (local set-up): ") + hipGetErrorString(e));
+  }
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);
   if (r != ncclSuccess) {
+    (void)hipFree(c->d_buf);
+    (void)hipStreamDestroy(c->stream);
     delete c;
     return fail(WALT_EHIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
-  }
-  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    g_rccl.CommDestroy(c->comm);
-    delete c;
-    return fail(WALT_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   }
   *out = c;
   return WALT_OK;

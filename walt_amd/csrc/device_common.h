@@ -27,6 +27,9 @@ struct walt_options {
   // single-end
   int se_pipe = 1;            // the staged heavy pass in two halves on two streams
   long long se_heavy_chunk = 0;  // reads per chunk of the heavy list (0: the default; test hook: several chunks on a small batch)
+  int se_stage_blocks = 0;    // blocks per compute unit of the stage launches (0: fill the device)
+  int se_verify_blocks = 0;   // ... of the dense verifier launches (0: its occupancy)
+  int se_stagger = 0;         // the second half of the heavy pass starts one look-up stage behind the first
   int se_lit_ablate = 0;      // measurement only (results wrong when set)
   int se_lit_side = 1;        // the literal pass on a side stream beside the end of the heavy pass
   int se_lit_staged = 0;      // the deferred reads through staged rounds with the reference's search on instead of the strand-major kernel

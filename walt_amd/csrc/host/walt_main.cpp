@@ -325,16 +325,61 @@ struct Prefetch {
   }
 };
 
+// -v: what this box's host side can move at all, measured where the run's output went -- T threads copying between private
+// buffers (what formatting a line into a buffer costs at least) and T threads storing their buffers with pwrite at
+// prefix-summed offsets into ONE scratch file beside the output (what OutFile does; one inode lock).  The run's format and
+// write stages are to be read against these two figures (bench.py's end-to-end leg carries them).
+static void host_ceiling(const string& out_file, int T) {
+  const size_t per = 64u << 20;  // 64 MiB per thread and round
+  std::vector<std::vector<char>> a((size_t)T), b((size_t)T);
+#pragma omp parallel for num_threads(T) schedule(static)
+  for (int t = 0; t < T; ++t) { a[(size_t)t].assign(per, (char)('A' + t)); b[(size_t)t].assign(per, 'x'); }
+  double t0 = now_s();
+  const int rounds = 4;
+  for (int r = 0; r < rounds; ++r) {
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (int t = 0; t < T; ++t) memcpy(b[(size_t)t].data(), a[(size_t)t].data(), per);
+  }
+  const double copy_gbs = (double)rounds * T * per / (now_s() - t0) / 1e9;
+  const string tmp = out_file + ".ceiling.tmp";
+  double write_gbs = 0.0;
+  const int fd = ::open(tmp.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0600);
+  if (fd >= 0) {
+    t0 = now_s();
+    for (int r = 0; r < rounds; ++r) {
+#pragma omp parallel for num_threads(T) schedule(static)
+      for (int t = 0; t < T; ++t) {
+        size_t done = 0;
+        while (done < per) {
+          const ssize_t w = ::pwrite(fd, b[(size_t)t].data() + done, per - done, (off_t)(((size_t)r * T + (size_t)t) * per + done));
+          if (w <= 0) break;
+          done += (size_t)w;
+        }
+      }
+    }
+    write_gbs = (double)rounds * T * per / (now_s() - t0) / 1e9;
+    ::close(fd);
+    ::unlink(tmp.c_str());
+  }
+  fprintf(stderr, "[walt_amd host ceiling: memcpy %.1f GB/s on %d threads, pwrite into one file %.1f GB/s]\n", copy_gbs, T, write_gbs);
+}
+
 // The last read file is done, every output file closed, the indexes released: leave without unwinding.  What the
 // destructors and the runtime's exit handlers would do -- hand back gigabytes of line buffers, unmap the read file,
 // unload the HIP runtime -- took 0.6 s of a 2 s run, and the operating system does it anyway.
-[[noreturn]] static void leave_now(bool verbose) {
+// Not when something else in the process counts on the exit handlers -- a preloaded tool that writes its trace there
+// (LD_PRELOAD, rocprofv3's ROCP_TOOL_LIBRARIES), or WALT_AMD_FAST_EXIT=0 -- then main returns as usual.  A late failure
+// of the standard streams still changes the exit status.
+static void leave_now(bool verbose) {
   if (verbose) fprintf(stderr, "[walt_amd: %.2f s in main]\n", now_s() - g_t_main);
-  fflush(stdout);
-  fflush(stderr);
+  const char* fe = getenv("WALT_AMD_FAST_EXIT");
+  const char* pre = getenv("LD_PRELOAD");
+  const char* tool = getenv("ROCP_TOOL_LIBRARIES");
+  if ((fe && atoi(fe) == 0) || (pre && *pre) || (tool && *tool)) return;
   std::cout.flush();
   std::cerr.flush();
-  _exit(EXIT_SUCCESS);
+  const bool bad = fflush(stdout) != 0 || fflush(stderr) != 0 || ferror(stdout) || ferror(stderr) || !std::cout || !std::cerr;
+  _exit(bad ? EXIT_FAILURE : EXIT_SUCCESS);
 }
 
 // ProcessSingledEndReads, mapping.cpp:421-526
@@ -458,6 +503,7 @@ static void process_se(const Options& o, const string& reads_file, const string&
     fprintf(stderr, "[walt_amd: %d host threads, %zu GPU(s); index %.2f s, ingest not hidden behind the previous batch %.2f s, map %.2f s, "
             "format %.2f s, write %.2f s; opening the reads %.2f s, closing the index %.2f s, since main %.2f s]\n", T, dev.size(), t_index,
             t_load, t_map, t_out, t_write, t_open_reads, now_s() - t_c0, now_s() - g_t_main);
+  if (o.verbose && last_file && getenv("WALT_AMD_HOST_CEILING")) host_ceiling(out_file, T);
   if (last_file) leave_now(o.verbose);
 }
 

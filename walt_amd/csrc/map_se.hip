@@ -900,7 +900,9 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
 // key searches, hardly an entry load) and the read goes on like any other.  Until round 4 these reads were mapped from
 // scratch by the strand-major kernel of round 1 (k_map_se_literal: ~12 ns a read whatever its probes cost -- 120 ms for
 // the 9.5 M such reads of an hg19-scale assembly of 3,000 contigs).
-template <int NW, int OCC = 0, bool LIT = false>  // OCC: wavefronts per SIMD the registers are capped for (0: the default)
+// MIDS = false (measured in round 4, not instantiated): regions of 5 .. 16 candidates become (gather) work items like the
+// larger ones instead of being verified by their lane: 4 spilled registers fewer, 41.5 -> 43.7 ms per 50 M reads.
+template <int NW, int OCC = 0, bool LIT = false, bool MIDS = true>  // OCC: wavefronts per SIMD the registers are capped for (0: the default)
 __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) : (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1)))) void k_se_stage(
     IndexView iv, const uint32_t* __restrict__ codes2, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ err,
     uint32_t strand_base, uint32_t max_mm, uint32_t b, const uint32_t* __restrict__ mask_table, BestMatch* __restrict__ out,
@@ -1144,12 +1146,14 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
       // larger regions: the dense range of those that become items (two loads, all lanes together); regions of up to
       // kMidRegion candidates stay with their lane (a deferred range -- long seeds -- is an item whatever its size: only
       // the verifier can narrow it)
-      const bool big_p = size_p > kMidRegion || defer_p, big_m = size_m > kMidRegion || defer_m;
+      constexpr uint32_t kLaneMax = (MIDS || kMulti) ? kMidRegion : kSmallRegion;  // largest region a lane verifies itself
+      const bool big_p = size_p > kLaneMax || defer_p, big_m = size_m > kLaneMax || defer_m;
       const DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, big_p && win_usable<NW>(svp, lr.len));
       const DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, big_m && win_usable<NW>(svm, lr.len));
       {
         const uint32_t nmid_p = (size_p > kSmallRegion && !big_p) ? size_p : 0u;
         const uint32_t nmid_m = (size_m > kSmallRegion && !big_m) ? size_m : 0u;
+        if constexpr (MIDS || kMulti)
         if (__ballot(nmid_p | nmid_m))
           se_mid_regions<NW, kMulti>(iv, sh, svp, svm, nmid_p, nmid_m, lp.reg.l, lm.reg.l, sd, lr.len, lr.rd, mk, n_chrom, top_step,
                                      tail_cut, mt, sum_p, sum_m, ctr.verified);
@@ -1588,7 +1592,11 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
     // the rounds of one chunk: look-up stage, then the verifiers of its items, kPat times, and the final fold
     auto run_chunk = [&](hipStream_t cs, uint32_t* ctl_base, uint32_t* lists, bool lit, const uint32_t* count, const uint32_t* list,
                          const SeCarry& cy, bool marks, uint32_t c_side) -> int {
-      const unsigned gh = grid_for(hcap) < pg ? grid_for(hcap) : pg;
+      // (options se_stage_blocks / se_verify_blocks: blocks per compute unit of these launches -- a launch that leaves
+      // wavefront slots free lets the other half's launch of the other kind run beside it; A/B)
+      const unsigned pgs = opt.se_stage_blocks > 0 ? (unsigned)opt.se_stage_blocks * (unsigned)idx->n_cu : pg;
+      const unsigned gh = grid_for(hcap) < pgs ? grid_for(hcap) : pgs;
+      const unsigned vgd = opt.se_verify_blocks > 0 ? (unsigned)opt.se_verify_blocks * (unsigned)idx->n_cu : vg_dense;
       for (uint32_t round = 0; round <= kPat; ++round) {
         hs.round = round;
         hs.ctl = ctl_base + 8 * (round < kPat ? round : 0);
@@ -1598,6 +1606,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
         if (lit)
           hipLaunchKernelGGL((k_se_stage<NW, 0, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
+
         else if (NW <= 10 && opt.se_stage_occ == (NW <= 8 ? 3 : 2))  // A/B (option se_stage_occ): one wavefront per SIMD fewer, more registers
           hipLaunchKernelGGL((k_se_stage<NW, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
@@ -1606,6 +1615,10 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
                              strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
         if (marks) mark(lit ? 3 : 1);
         if (round == kPat) break;
+        if (!lit && round == 0 && piped && c_side == 0 && opt.se_stagger != 0) {  // the other half starts one stage behind (A/B)
+          WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[0], stream));
+          WALT_HIP_FORKED(hipStreamWaitEvent(idx->se_pipe, idx->se_pipe_ev[0], 0));
+        }
         if (!lit && round == kPat - 1) {  // (round kPat probes nothing: this chunk has made its last deferrals)
           if (piped && c_side == 0) WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[1], stream));
           if (lit_side && c_side == (piped ? 1u : 0u)) {
@@ -1624,7 +1637,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
         if constexpr (NW <= 10 && long_seed_nw<NW>())
           hipLaunchKernelGGL((k_se_tail_narrow<NW>), dim3(pg), dim3(kBlock), 0, cs, view, strand_base, hs, b);
         if constexpr (NW <= 10) {
-          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vg_dense), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b, err);
+          hipLaunchKernelGGL((k_se_verify<NW, true>), dim3(vgd), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b, err);
         }
         hipLaunchKernelGGL((k_se_verify<NW, false>), dim3(vg_gather), dim3(kBlock), 0, cs, view, strand_base, stats, hs, b, err);
         if (marks) mark(lit ? 3 : 2);
