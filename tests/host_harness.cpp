@@ -162,7 +162,7 @@ long hh_index_add_strand(void* hp, int strand, const uint8_t* genome, uint32_t g
   // the level table (core.h StrandView::olev); WALT_AMD_TEST_NO_OLEV=1: the walk over the bucket's outliers instead
   {
     std::vector<uint32_t> collided;
-    const uint32_t ents = build_outlier_levels(s.outl.data(), s.view.n_outl, s.olev, collided);
+    const uint32_t ents = build_outlier_levels(s.outl.data(), s.view.n_outl, s.olev, collided, beyond_genome_buckets(s.g2.data(), 0, genome_len));
     for (uint32_t hb : collided) s.bad[hb >> 5] |= 1u << (hb & 31);
     const bool off = getenv("WALT_AMD_TEST_NO_OLEV") != nullptr;
     s.view.olev = off ? nullptr : s.olev.data();

@@ -300,3 +300,32 @@ def test_gpu_bench_refuses_a_world_that_is_not_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert p.returncode != 0 and "--gpus 2" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_gpu_mapping_calls_ignore_the_former_environment_knobs(scratch, monkeypatch):
+    """Until round 4 the mapping calls read a dozen environment variables -- one of them (WALT_AMD_ABLATE) made the product
+    library return wrong mappings.  They are options of an index now (walt_index_set_option) and diagnostics live in
+    libwalt_amd_diag.so only: with every former knob set in the environment the default library gives the oracle's records,
+    single-end and paired-end."""
+    import random
+
+    import walt_amd as wa
+    from test_harness_cpu import assert_best_equal, make_random_case, sample_reads
+    seqs, db = make_random_case(41, 150, scratch)
+    rng = random.Random(41)
+    reads = sample_reads(rng, seqs, 2000, "CT")
+    want, _ = refio.oracle_se(db, reads, ag=False, max_mm=6, b=5000)
+    wantp, _, _ = refio.oracle_pe(db, reads[:800], reads[:800], max_mm=6, b=5000, top_k=50, frag_range=1000)
+    for k, v in (("WALT_AMD_ABLATE", "7"), ("WALT_AMD_STAMPS", "1"), ("WALT_AMD_SYNC_DEBUG", "1"), ("WALT_AMD_HEAVY", "mono"),
+                 ("WALT_AMD_SE_PIPE", "0"), ("WALT_AMD_PE", "list"), ("WALT_AMD_PE_SERIAL", "1"), ("WALT_AMD_SMALL_HEAPS", "1"),
+                 ("WALT_AMD_GRID", "64"), ("WALT_AMD_HEAVY_CHUNK", "64"), ("WALT_AMD_PE_CHUNK", "128"),
+                 ("WALT_AMD_PE_STAGE_CAP", "64"), ("WALT_AMD_DEFER_MIN", "0"), ("WALT_AMD_LIT_SIDE", "0")):
+        monkeypatch.setenv(k, v)
+    idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL)
+    got, _ = idx.map_se_batch(*wa.pack_reads(reads), ag_wildcard=False, max_mismatches=6, b=5000)
+    assert_best_equal(got, want, "environment knobs set")
+    res, _ = idx.map_pe_batch(*wa.pack_reads(reads[:800]), *wa.pack_reads(reads[:800]), max_mismatches=6, top_k=50)
+    for f in ("best_times", "frag_len", "pair_mm"):
+        assert np.array_equal(res[f], wantp[f]), f
+    idx.close()

@@ -11,6 +11,7 @@
 // a process that also runs PyTorch must not end up with two copies of it -- the SONAME lookup returns the
 // copy that is already loaded).
 #include <dlfcn.h>
+#include <link.h>
 #include <stdlib.h>
 #include <string.h>
 #include <rccl/rccl.h>
@@ -37,8 +38,17 @@ static std::string g_rccl_error;
 static void load_rccl() {
   const char* names[] = {getenv("WALT_AMD_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   std::string tried;
-  // a copy the process holds already (a torch process has loaded its own librccl) is taken first: RTLD_NOLOAD returns
-  // a handle only when the library is resident, so two copies of RCCL never live in one process
+  // a copy the process holds already (a torch process has loaded its own librccl, under whatever path and name) is
+  // taken first, so that two copies of RCCL never live in one process: the loaded objects are searched for "librccl",
+  // and RTLD_NOLOAD turns the resident one's path into a handle
+  {
+    std::string resident;
+    dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) -> int {
+      if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) { *static_cast<std::string*>(data) = info->dlpi_name; return 1; }
+      return 0;
+    }, &resident);
+    if (!resident.empty()) g_rccl.so = dlopen(resident.c_str(), RTLD_NOW | RTLD_NOLOAD);
+  }
   for (const char* nm : names) {
     if (!nm || !*nm || g_rccl.so) continue;
     g_rccl.so = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);

@@ -679,11 +679,30 @@ WALT_HD uint32_t olev_find(const StrandView& sv, uint64_t fp) { return olev_reso
 // The outliers a probe shares its characters 12..q-1 with, q < lim: levels = the set of their q (bit q - 12); dangerous =
 // one of them holds, at its character q, a real byte that is not below the probe's (probe_danger_level's rule); q_min.
 // Four independent look-ups per round.  Returns false when the strand has no level table (the caller walks).
+// counts (optional): 4 bits per level q - 12 < 16, the number of outliers of that level the probe shares its characters
+// with (15: that many or more -- look it up); beyond (optional): the bucket holds an entry whose care characters run over the
+// end of the GENOME (the last chromosome's end entries: the only ones whose byte the reference reads as below every base).
 WALT_HD bool olev_relevant(const StrandView& sv, uint32_t h, uint64_t T, uint32_t lim, uint32_t& levels, bool& dangerous,
-                           uint32_t& q_min) {
+                           uint32_t& q_min, uint64_t* counts = nullptr, bool* beyond = nullptr) {
   levels = 0; dangerous = false; q_min = 0xFFFFFFFFu;
+  if (counts) *counts = 0;
+  if (beyond) *beyond = true;
   if (sv.olev == nullptr) return false;
-  uint32_t m = olev_find(sv, olev_fp(h, kOlevBucket, 0));  // the q that occur in the bucket at all
+  uint32_t m;
+  {
+    const uint64_t fpb = olev_fp(h, kOlevBucket, 0);
+    uint32_t slot = olev_slot(fpb, sv.olev_mask);
+    OlevEnt e = sv.olev[slot];
+    m = 0;
+    bool by = false;
+    for (;;) {
+      if (e.fp_lo == 0 && e.fp_hi == 0) break;
+      if (e.fp_lo == (uint32_t)fpb && e.fp_hi == (uint32_t)(fpb >> 32)) { m = e.value; by = e.pad != 0; break; }
+      slot = (slot + 1) & sv.olev_mask;
+      e = sv.olev[slot];
+    }
+    if (beyond) *beyond = by;
+  }  // m: the q that occur in the bucket at all
   const uint32_t span = lim > kKeyWeight ? lim - kKeyWeight : 0u;
   m = span >= 32 ? m : (m & ((1u << span) - 1u));
   while (m) {
@@ -718,6 +737,10 @@ WALT_HD bool olev_relevant(const StrandView& sv, uint32_t h, uint64_t T, uint32_
       if (!v) continue;
       levels |= 1u << (qs[t] - kKeyWeight);
       q_min = qs[t] < q_min ? qs[t] : q_min;
+      if (counts && qs[t] - kKeyWeight < 16) {
+        const uint32_t c = v & 0x3FFFFFFFu;
+        *counts |= (uint64_t)(c < 15u ? c : 15u) << (4 * (qs[t] - kKeyWeight));
+      }
       const uint32_t sh = 2 * (kKeyWeight + kKeyChars - 1 - qs[t]);
       if (!((uint32_t)((T >> sh) & 3u) > (v >> 30))) dangerous = true;
     }
@@ -1252,19 +1275,26 @@ WALT_HD void stretch_bounds(const StrandView& sv, const uint32_t* care, uint32_t
 template <class QOf>
 WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, uint32_t seed_len, uint32_t first,
                                    uint32_t second, const QOf& q_of, InferStats* st = nullptr, uint32_t Bd = 0,
-                                   bool levels_known = false, uint32_t levels_in = 0) {
+                                   bool levels_known = false, uint32_t levels_in = 0, uint64_t counts_in = 0,
+                                   bool beyond_in = true) {
   const uint32_t h = care[0] >> 8;
   const uint32_t lim = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
   const uint64_t T = target_key(care);
   // levels with heads: bit q - 12 for every outlier with q < lim that shares T's characters 12..q-1 -- from the level
   // table (four independent look-ups a round), or by walking the bucket's outliers
   uint32_t levels = levels_in, o_lo = 0;
+  uint64_t counts = counts_in;
+  bool beyond = beyond_in;
   bool have_table = levels_known;  // (the caller's danger test has looked the levels up already)
   if (!levels_known) {
     bool dng;
     uint32_t q_first;
-    have_table = olev_relevant(sv, h, T, lim, levels, dng, q_first);
+    have_table = olev_relevant(sv, h, T, lim, levels, dng, q_first, &counts, &beyond);
+    if (!have_table) beyond = true;
   }
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if (getenv("WALT_DBG_NOBEYOND")) beyond = false;  // (test of the test: without the flag, differences must show)
+#endif
   if (!have_table) {
     uint32_t hi = sv.n_outl;
     if (sv.outl_dir) {
@@ -1318,7 +1348,8 @@ WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, u
     // one simulated step
     uint32_t k = 0;
     if (((levels >> (p - kKeyWeight)) & 1u) && have_table) {
-      k = olev_find(sv, olev_fp(h, p, T & key_mask_fwd(p - kKeyWeight))) & 0x3FFFFFFFu;
+      const uint32_t small = p - kKeyWeight < 16 ? (uint32_t)((counts >> (4 * (p - kKeyWeight))) & 15u) : 15u;
+      k = small < 15u ? small : (olev_find(sv, olev_fp(h, p, T & key_mask_fwd(p - kKeyWeight))) & 0x3FFFFFFFu);
     } else if ((levels >> (p - kKeyWeight)) & 1u) {
       for (uint32_t i = o_lo; i < sv.n_outl && sv.outl[i].h == h; ++i) {
         const Outlier o = sv.outl[i];
@@ -1333,6 +1364,10 @@ WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, u
     if (st) ++st->steps;
     const int ch = (int)care_char(care, p);
     uint32_t low = l, high = u;
+    // (the probe's character is the smallest letter and no entry of this bucket reads beyond the genome's end: every byte
+    // the bisection can meet is >= it, every step goes left, the lower bound stays where it is -- no entry is looked at.
+    // A probe from a low-complexity stretch is in this case level after level, with heads at each.)
+    if (!(ch == 0 && !beyond))
     while (low < high) {  // LowerBound, mapping.cpp:166-180
       const uint32_t mid = low + (high - low) / 2;
       const bool ge = (mid >= s0 && mid < cu) ? mid >= LB : memo_char(sv, memo, q_none, mid, p, l, u) >= ch;
@@ -1379,14 +1414,16 @@ WALT_HD void seed_lookup_ex(const IndexView& iv, const StrandView& sv, const uin
     uint32_t lv_mask = 0, q_first = 0;
     bool dng = false;
     const uint32_t lim_t = seed_len < kKeyWeight + kKeyChars ? seed_len : kKeyWeight + kKeyChars;
-    const bool lv_known = !bucket_is_bad(sv, h) && olev_relevant(sv, h, target_key(care), lim_t, lv_mask, dng, q_first);
+    uint64_t lv_counts = 0;
+    bool lv_beyond = true;
+    const bool lv_known = !bucket_is_bad(sv, h) && olev_relevant(sv, h, target_key(care), lim_t, lv_mask, dng, q_first, &lv_counts, &lv_beyond);
     const uint32_t level = lv_known ? (dng ? q_first : 0u) : probe_danger_level(sv, care, seed_len);
     if (level) {
       uint32_t first = sv.cnt[h], second = sv.cnt[h + 1];
       if (first == second) return;                         // mapping.cpp:271-272
       if (literal_mode() == 2 && !bucket_is_bad(sv, h)) {  // (a BAD bucket -- disorder no outlier explains -- keeps the plain search)
         InferStats ist = {0, 0, 0, 0};
-        out.reg = lit_region_inferred(sv, care, seed_len, first, second, q_of, memo_stats() ? &ist : nullptr, iv.dir_bits, lv_known, lv_mask);
+        out.reg = lit_region_inferred(sv, care, seed_len, first, second, q_of, memo_stats() ? &ist : nullptr, iv.dir_bits, lv_known, lv_mask, lv_counts, lv_beyond);
         if (memo_stats()) { memo_stats()[0] += 1; memo_stats()[1] += 1; memo_stats()[2] += ist.loads; memo_stats()[3] += ist.searches; memo_stats()[4] += ist.steps;
                             const uint32_t cst = ist.loads + ist.searches + ist.dirs; memo_stats()[6 + (cst < 63 ? cst : 63)] += 1; memo_stats()[5] += 0; memo_stats()[69] += ist.dirs; }
         return;

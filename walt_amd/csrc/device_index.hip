@@ -478,7 +478,18 @@ int finish_strand_device(walt_index* idx, int strand, uint32_t* g2, const uint32
     // the level table (core.h StrandView::olev): which outliers a probe shares its characters with, by look-up
     std::vector<OlevEnt> lev;
     std::vector<uint32_t> collided;
-    const uint32_t ents = build_outlier_levels(ho.data(), n_outl, lev, collided);
+    // (the genome's last words on the host: which buckets hold an entry that reads beyond the genome's end)
+    std::vector<uint32_t> tail_words;
+    uint64_t tail_base = 0;
+    {
+      const uint32_t reach = care_pos(kKeyWeight + kKeyChars - 1) + 16;
+      tail_base = genome_len > reach ? ((uint64_t)(genome_len - reach) & ~15ull) : 0;
+      const uint64_t w0 = tail_base >> 4, w1 = ((uint64_t)genome_len + 15) / 16 + 4;  // (+ slack words: g2 carries kG2PadWords)
+      tail_words.resize((size_t)(w1 - w0));
+      WALT_HIP(hipMemcpy(tail_words.data(), g2 + w0, tail_words.size() * 4, hipMemcpyDeviceToHost));
+    }
+    const uint32_t ents = build_outlier_levels(ho.data(), n_outl, lev, collided,
+                                               beyond_genome_buckets(tail_words.data(), tail_base, genome_len));
     for (uint32_t hb : collided) {  // two keys, one fingerprint: their buckets are searched literally (never seen)
       uint32_t word = 0;
       WALT_HIP(hipMemcpy(&word, bad + (hb >> 5), 4, hipMemcpyDeviceToHost));

@@ -120,8 +120,11 @@ inline uint32_t build_outlier_dir(const Outlier* outl, uint32_t n_outl, Vec& dir
 // Host side: the level table of StrandView::olev for outliers sorted by (bucket, q, key).  Returns the number of
 // entries (a power of two, at most half full).  Two different keys with one fingerprint (never, in practice: 63 bits)
 // cannot both be held: their buckets are reported in `collided` and the caller marks them BAD (literal search, no table).
+// beyond_buckets: the buckets of the entries whose care characters (of the 44 a key holds) run over the end of the GENOME
+// -- the last chromosome's end entries; their bucket entries get pad = 1 (core.h olev_relevant)
 template <class VecE, class VecU>
-inline uint32_t build_outlier_levels(const Outlier* outl, uint32_t n_outl, VecE& table, VecU& collided) {
+inline uint32_t build_outlier_levels(const Outlier* outl, uint32_t n_outl, VecE& table, VecU& collided,
+                                     const std::vector<uint32_t>& beyond_buckets = std::vector<uint32_t>()) {
   uint32_t groups = 0, buckets = 0;
   for (uint32_t i = 0; i < n_outl; ++i) {
     const Outlier& o = outl[i];
@@ -181,7 +184,27 @@ inline uint32_t build_outlier_levels(const Outlier* outl, uint32_t n_outl, VecE&
     if (qmask) put(h, olev_fp(h, kOlevBucket, 0), qmask, false);
     i = j;
   }
+  for (uint32_t hb : beyond_buckets) {
+    const uint64_t fp = olev_fp(hb, kOlevBucket, 0);
+    uint32_t slot = olev_slot(fp, size - 1);
+    for (;;) {
+      OlevEnt& e = table[slot];
+      if (e.fp_lo == 0 && e.fp_hi == 0) break;  // (no outlier of that bucket is listed: nothing to flag)
+      if (e.fp_lo == (uint32_t)fp && e.fp_hi == (uint32_t)(fp >> 32)) { e.pad = 1; break; }
+      slot = (slot + 1) & (size - 1);
+    }
+  }
   return size;
+}
+
+// the buckets of the index positions whose key characters reach over the genome's end (g2: the packed genome, or its
+// tail with `base` = the base index of g2[0], a multiple of 16)
+inline std::vector<uint32_t> beyond_genome_buckets(const uint32_t* g2, uint64_t base, uint32_t genome_len) {
+  std::vector<uint32_t> out;
+  const uint32_t reach = care_pos(kKeyWeight + kKeyChars - 1), hash_reach = care_pos(kKeyWeight - 1);
+  for (uint64_t pos = genome_len > reach ? genome_len - reach : 0; pos + hash_reach < genome_len; ++pos)
+    if (pos >= base) out.push_back(hash_at(g2 - (base >> 4), pos));
+  return out;
 }
 
 }  // namespace walt

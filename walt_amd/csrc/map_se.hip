@@ -1334,9 +1334,12 @@ __global__ __launch_bounds__(kBlock, G > 1 ? (NW <= 8 ? 3 : 2) : DENSE ? (NW <= 
   flush_counters({0u, sink.n_verified, 0u}, 0u, stats);
 }
 
+#ifndef WALT_LIT_OCC
+#define WALT_LIT_OCC 5  // wavefronts per SIMD the literal kernel's registers are capped for (measured: see DESIGN.md section 12b)
+#endif
 // pass 2: the deferred reads (grid-stride over the list; count is on the device)
 template <int NW, bool LITERAL = true>
-__global__ __launch_bounds__(kBlock, NW <= 8 ? 4 : 1) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
+__global__ __launch_bounds__(kBlock, NW <= 8 ? WALT_LIT_OCC : 1) void k_map_se_literal(IndexView iv, const uint32_t* __restrict__ codes2,
                                                             const uint64_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ err, uint32_t strand_base,
                                                             uint32_t max_mm,
