@@ -54,16 +54,24 @@ def test_no_device_is_a_loud_error_not_a_fallback(g1_index_path):
 def test_comm_init_fails_locally_before_the_collective():
     """walt_comm_init does everything that can fail on THIS rank (device, stream, buffer) before it enters
     ncclCommInitRank (csrc/comm.hip): on a box without a GPU a rank of a two-rank world returns an error at once -- it does
-    not sit in the collective waiting for a peer that will never come.  (With a GPU the call would block for the peer: skipped.)"""
-    import time
+    not sit in the collective waiting for a peer that will never come.  (With a GPU the call would block for the peer: skipped.)
+    In a child process: the call loads librccl, and a process that later imports torch would then hold two copies of it."""
+    import subprocess
+    import sys
 
     import walt_amd
     if walt_amd.device_count() > 0:
         pytest.skip("GPU present")
-    L = walt_amd.lib()
-    ident = ctypes.create_string_buffer(128)
-    comm = ctypes.c_void_p()
-    t0 = time.time()
-    rc = L.walt_comm_init(0, 0, 2, ident, ctypes.byref(comm))
-    assert rc != 0 and not comm.value
-    assert time.time() - t0 < 20
+    code = ("import ctypes, sys, time\n"
+            "sys.path.insert(0, %r)\n"
+            "import walt_amd\n"
+            "L = walt_amd.lib()\n"
+            "ident = ctypes.create_string_buffer(128)\n"
+            "comm = ctypes.c_void_p()\n"
+            "t0 = time.time()\n"
+            "rc = L.walt_comm_init(0, 0, 2, ident, ctypes.byref(comm))\n"
+            "assert rc != 0 and not comm.value, rc\n"
+            "assert time.time() - t0 < 20\n"
+            "print('ok')\n") % refio.ROOT
+    pr = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert pr.returncode == 0 and "ok" in pr.stdout, pr.stdout[-400:]

@@ -2,10 +2,10 @@
 # SQ counters of the paired-end kernels, serialized (GPU box): bash tools/prof_pe_sq.sh <tag>
 set -u
 TAG=$1; shift
-export TMPDIR=/tmp WALT_AMD_PE_SERIAL=1
+export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"
 OUT=gpurun_out/pesq_$TAG; mkdir -p $OUT
-ARGS="--mode pe --no-extra --no-cpu-baseline --steps 1 --warmup 1 $*"
+ARGS="--mode pe --no-extra --no-cpu-baseline --steps 1 --warmup 1 --opt pe_serial=1 $*"
 i=0
 for PMC in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
