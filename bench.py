@@ -973,8 +973,22 @@ def worker(args):
         d_bases, d_off = synth.make_reads(torch, dev, genome_ascii, n, args.read_len, seed=1000 + rank + args.seed_offset, ag=args.ag, lowq=lowq)
         torch.cuda.synchronize()
         log("reads: %d x %d bp (%.1f s)" % (n, args.read_len, time.perf_counter() - t0))
+        if os.environ.get("WALT_AMD_TWICE"):  # diagnostic library only: parts of k_se_stage run twice (bit mask)
+            walt_amd.lib().walt_profile_stage_stamps(int(os.environ["WALT_AMD_TWICE"]) << 8, None)
+        if os.environ.get("WALT_AMD_STAMPS") == "4":  # diagnostic library only: phase sums of k_se_stage
+            walt_amd.lib().walt_profile_stage_stamps(1, None)
         leg = se_leg(cx, idx, d_bases, d_off, n, args.read_len, args.max_mismatches, args.bucket, args.ag, args.steps,
                      args.warmup)
+        if os.environ.get("WALT_AMD_STAMPS") == "4":
+            buf = (ctypes.c_ulonglong * 16)()
+            walt_amd.lib().walt_profile_stage_stamps(0, buf)
+            tot = float(buf[8]) or 1.0
+            nm = ["take a read", "query + filter + directory", "danger test", "entries + resolve", "masks + small regions",
+                  "dense range + mid regions", "work items", "store / lists / finished"]
+            log("k_se_stage phase shares (s_memtime, drained at boundaries): " +
+                ", ".join("%s %.1f%%" % (x, 100.0 * buf[i] / tot) for i, x in enumerate(nm)))
+            log("k_se_stage events (all steps): fence rounds %d with %d lanes (%d searches of 128), seed steps %d with %d lanes, "
+                "candidate turns %d with %d candidates" % (buf[9], buf[10], buf[15], buf[11], buf[12], buf[13], buf[14]))
         elapsed = wdist.allreduce_max(leg["elapsed"], device=dev if not shared_gpu else "cpu")  # MAX over ranks
         leg["kern_ms_ranks_max"] = wdist.allreduce_max(float(np.median(leg["map_ms"])), device=dev if not shared_gpu else "cpu")
         # mapping statistics of the last step; the ONLY data-path collective is this final sum over ranks

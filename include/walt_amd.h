@@ -220,7 +220,8 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
  *   se_lit_side    1  literal pass on a side stream beside the end of the heavy pass
  *   se_lit_staged  0  reads with a truly dangerous probe go through staged rounds with the reference's search on instead
  *   se_defer_min  -1  long seeds: key-equal ranges of more slots than this go to the verifier unnarrowed (-1: default 4, 0: never)
- *   se_stage_occ   0  wavefronts per SIMD the stage kernel is built for (0: default, 3)
+ *   se_stage_occ   0  wavefronts per SIMD the stage kernel is built for (0: chosen by read length and sequence count;
+ *                     3 / 4 for reads of up to 128 bases, 2 / 3 up to 160)
  *   se_carry       1  pass 1 hands its state to the staged rounds (0: they start over at seed 0)
  *   se_heavy_mono  0  the one-kernel heavy pass instead of the staged rounds
  *   grid           0  blocks of the persistent kernels (0: 8 per compute unit)

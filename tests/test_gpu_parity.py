@@ -136,6 +136,25 @@ def test_gpu_random_genomes_vs_oracle(wa, scratch, seed, n_chrom):
     assert any_bad > 0
 
 
+@pytest.mark.parametrize("blocks", [1, 3])
+def test_gpu_stage_hands_reads_out_over_several_windows(wa, scratch, blocks):
+    """k_se_stage hands a wavefront's part of the heavy list out read by read, from list entries fetched a window of 64
+    ahead (map_se.hip): with the default grid a test's few thousand reads never leave the first window, so the
+    persistent kernels run on `blocks` blocks here (option grid) -- every wavefront walks through several windows."""
+    seqs, db = make_random_case(12, 300, scratch)
+    rng = random.Random(977)
+    reads = sample_reads(rng, seqs, 6000, "CT")
+    want, _ = refio.oracle_se(db, reads, ag=False, max_mm=6, b=5000)
+    bct, oct_ = wa.pack_reads(reads)
+    idx = wa.Index.open(db.path, device=0, strands=wa.STRANDS_ALL, dir_bits=24)
+    idx.set_option("grid", blocks)
+    for pipe in (1, 0):
+        idx.set_option("se_pipe", pipe)
+        got, st = idx.map_se_batch(bct, oct_, ag_wildcard=False, max_mismatches=6, b=5000)
+        assert_best_equal(got, want, "stage blocks=%d pipe=%d" % (blocks, pipe))
+    idx.close()
+
+
 def test_gpu_long_reads_all_word_widths(wa, scratch):
     """Reads of 129..1000 bp take the 10-, 16-, 32- and 64-word kernel instances."""
     rng = random.Random(5)

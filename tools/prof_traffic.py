@@ -54,7 +54,7 @@ def pmc(sub):
             if not is_ours(k):
                 continue
             # index-building kernels run once, before the steps: not part of a step's traffic
-            if not any(x in k for x in ("k_map_se", "k_se_verify", "k_se_tail", "k_pe_", "k_ascii_to_2bit", "k_bin_", "k_reduce_stats")):
+            if not any(x in k for x in ("k_map_se", "k_se_stage", "k_se_verify", "k_se_tail", "k_lit_", "k_pe_", "k_ascii_to_2bit", "k_bin_", "k_reduce_stats")):
                 continue
             tot[k.split("(")[0].replace("void ", "")][r["Counter_Name"]] += float(r["Counter_Value"])
     return tot

@@ -157,6 +157,21 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+// ds_bpermute whose result is PINNED where it is written.  hipcc turns `c ? __shfl(a, l) : __shfl(b, l)` (and a
+// shuffle whose value is only used under a per-lane condition) into a branch with the ds_bpermute inside it, i.e. run
+// with the lanes that fail the condition switched off -- and a ds_bpermute reads nothing from a switched-off lane (seen
+// in the ISA of k_se_stage's read hand-out, where it mapped reads with other reads' offsets).  The empty volatile asm
+// uses the value at this point, so the shuffle stays in the block it is written in.
+__device__ __forceinline__ uint32_t shfl_pin(uint32_t v, uint32_t src_lane) {
+  uint32_t r = (uint32_t)__shfl((int)v, (int)src_lane);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+__device__ __forceinline__ uint32_t shfl_up_pin(uint32_t v, uint32_t d) {
+  uint32_t r = (uint32_t)__shfl_up((int)v, d);
+  asm volatile("" : "+v"(r));
+  return r;
+}
 // exclusive prefix sum over the lanes (and the total, in every lane)
 __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t lane, uint32_t& total) {
   uint32_t x = v;
@@ -362,6 +377,19 @@ __device__ __forceinline__ void block_flush_stats(uint32_t a0, uint32_t a1, uint
     if (t) atomicAdd(&shards[(uint64_t)(blockIdx.x % kStatShards) * kStatShardWords + threadIdx.x], (unsigned long long)t);
   }
 }
+
+#if defined(WALT_DIAG)
+// diagnostic build: event counters of the staged kernels (walt_profile_stage_stamps returns them behind the phase sums)
+static __device__ unsigned long long g_diag_ctr[16];
+#define WALT_DIAG_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((g_diag_twice >> 16) != 0 && (threadIdx.x & 63u) == 0) atomicAdd(&g_diag_ctr[(i)], v_); } while (0)
+// ... and "do it twice" switches (walt_profile_stage_stamps, bits 8 and up of `on`): what a part of the kernel costs is
+// the time the run gains when that part runs a second time with the same inputs (the results stay valid)
+static __device__ uint32_t g_diag_twice;  // (bit 16: the event counters count -- millions of same-address atomics, 30 ms per step)
+#define WALT_DIAG_TWICE(bit) ((g_diag_twice >> (bit)) & 1u)
+#else
+#define WALT_DIAG_COUNT(i, v)
+#define WALT_DIAG_TWICE(bit) 0u
+#endif
 
 // ---- slot probes of the seed-major kernels (map_se.hip se_process_dual, map_pe.hip pe_process_dual) ----
 struct SlotProbe {
@@ -647,7 +675,19 @@ __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const 
     }
   }
   if (svp.fen[0] != nullptr && svm.fen[0] != nullptr) {  // uniform
-    while (kary_busy(ks[0]) || kary_busy(ks[1])) fence_round_dual(svp, svm, ks, T, M, pp.lo, pm.lo);
+#if defined(WALT_DIAG)
+    if (WALT_DIAG_TWICE(0)) {
+      KaryState k2[2] = {ks[0], ks[1]};
+      while (kary_busy(k2[0]) || kary_busy(k2[1])) fence_round_dual(svp, svm, k2, T, M, pp.lo, pm.lo);
+      if (k2[0].x1 == 0xFFFFFFF0u) ks[0] = k2[0];  // (keeps the copy alive)
+    }
+#endif
+    while (kary_busy(ks[0]) || kary_busy(ks[1])) {
+      WALT_DIAG_COUNT(0, 1);                                                        // fence rounds run by a wavefront
+      WALT_DIAG_COUNT(1, __popcll(__ballot(kary_busy(ks[0]) || kary_busy(ks[1]))));  // ... and the lanes that needed them
+      WALT_DIAG_COUNT(6, __popcll(__ballot(kary_busy(ks[0]))) + __popcll(__ballot(kary_busy(ks[1]))));  // searches busy
+      fence_round_dual(svp, svm, ks, T, M, pp.lo, pm.lo);
+    }
   } else {
     while (kary_busy(ks[0]) || kary_busy(ks[1])) {
       kary_round(svp, ks[0], T, M, pp.lo);
@@ -660,7 +700,8 @@ __device__ __forceinline__ void probe_resolve_dual(const StrandView& svp, const 
     if (p.ne > kScan) found[f] = kary_result(ks[f], a[f], u[f]);
   }
   // ---- 2. positions of short regions the search found (one round, both strands; idle lanes read their slot's first entry)
-  {
+#pragma unroll 1
+  for (uint32_t twice = 0; twice <= WALT_DIAG_TWICE(1); ++twice) {
     uint32_t v[2][kLookupPos];
     bool want[2];
 #pragma unroll

@@ -443,6 +443,128 @@ __device__ __forceinline__ void se_mid_regions(const IndexView& iv, const BlockS
   }
 }
 
+// Round 4 (late), pattern 3: the candidates the lanes of a wavefront verify themselves -- regions of up to kMidRegion
+// index slots on either strand -- as ONE list in lane order (lane 0's '+' candidates, its '-' ones, lane 1's ...):
+// candidate q goes to lane q % 64 of turn q / 64, whichever lane owns it.  Before, every lane walked its own regions
+// (four candidates of both strands one after the other, then up to sixteen of a mid region four at a time) while the
+// lanes with shorter or no regions waited: the phase stamps put a third of the stage kernel there.  A turn:
+//   1. the owner of q: the last lane whose exclusive candidate count is <= q (bisection over the lanes, ds_bpermute),
+//   2. the owner's read, masks and region start by ds_bpermute; the slot's position (the line the probe just read),
+//      edge filters of mapping.cpp:280-286, genome window, mismatch count -- verify_nobranch's steps,
+//   3. a segmented inclusive scan of the one-candidate summaries with summary_merge (keys = owner and strand, which
+//      rise along the lanes; the merge is associative and order-aware, core.h), and
+//   4. every owner merges the summary of the LAST lane of its run in this turn into its own, turn after turn in list
+//      order -- the order its own loop had.
+// Every lane runs every turn (ds_bpermute reads nothing from a lane outside EXEC).
+template <int NW>
+__device__ __forceinline__ void coop_lane_regions(const IndexView& iv, const BlockShared& sh, const StrandView& svp,
+                                                  const StrandView& svm, uint32_t n_p, uint32_t n_m, uint32_t l_p,
+                                                  uint32_t l_m, uint32_t pos0_p, uint32_t pos0_m, bool reg_p, bool reg_m,
+                                                  uint32_t sd, const LaneRead<NW>& lr, const uint32_t* mk,
+                                                  bool tail_p, bool tail_m, const uint32_t* care, uint32_t n_chrom,
+                                                  RegionSummary& sum_p, RegionSummary& sum_m, uint32_t& n_verified) {
+  constexpr bool kLong = long_seed_nw<NW>();
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t total;
+  const uint32_t off = wave_excl_scan_u32(n_p + n_m, lane, total);
+  const ChromTab ct = chrom_tab_of(n_chrom);
+  // reg_x: the region's first position is in pos0_x already (a slot-table record that holds its single entry has no
+  // index slot to read it from: map_common.h probe_issue)
+  const uint32_t meta = sd | (lr.repeats << 3) | (lr.len << 9) | (tail_p ? 1u << 20 : 0u) | (tail_m ? 1u << 21 : 0u) |
+                        (reg_p ? 1u << 22 : 0u) | (reg_m ? 1u << 23 : 0u);
+#pragma unroll 1
+  for (uint32_t base = 0; base < total; base += 64) {
+    WALT_DIAG_COUNT(4, 1);                                            // turns of the candidate list
+    WALT_DIAG_COUNT(5, total - base < 64u ? total - base : 64u);      // ... and the candidates in them
+    const uint32_t q = base + lane;
+    const bool have = q < total;
+    uint32_t own = 0;
+#pragma unroll
+    for (uint32_t s = 32; s; s >>= 1) {
+      const uint32_t o = shfl_pin(off, own + s);
+      own = o <= q ? own + s : own;
+    }
+    const uint32_t o_off = shfl_pin(off, own), o_np = shfl_pin(n_p, own);
+    const uint32_t o_lp = shfl_pin(l_p, own), o_lm = shfl_pin(l_m, own);
+    const uint32_t o_meta = shfl_pin(meta, own);
+    const uint32_t k = q - o_off;
+    const bool on_m = have && k >= o_np;
+    const uint32_t kk = on_m ? k - o_np : k;
+    const bool from_reg = have && kk == 0 && ((o_meta >> (on_m ? 23 : 22)) & 1u);
+    const uint32_t slot = (have && !from_reg) ? (on_m ? o_lm : o_lp) + kk : 0u;
+    const Ent* const ent = on_m ? svm.ent : svp.ent;
+    const uint32_t* const g2 = on_m ? svm.g2 : svp.g2;
+    const uint32_t o_p0 = shfl_pin(pos0_p, own), o_m0 = shfl_pin(pos0_m, own);
+    uint32_t pos = ent[slot].pos;  // (a lane without a candidate: entry 0, one broadcast access)
+    pos = from_reg ? (on_m ? o_m0 : o_p0) : pos;
+    uint32_t o_rd[NW], o_mk[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      o_rd[w] = shfl_pin(lr.rd[w], own);
+      o_mk[w] = shfl_pin(mk[w], own);
+    }
+    const uint32_t o_sd = o_meta & 7u, o_len = (o_meta >> 9) & 2047u;
+    uint32_t c_lo, c_hi;
+    chrom_bounds(sh.start_index, iv.start_index, ct, pos, c_lo, c_hi);
+    const uint32_t g = pos - o_sd;
+    bool ok = have && (pos - c_lo >= o_sd) && (g + o_len < c_hi);  // mapping.cpp:280-286
+    const uint32_t gp = ok ? g : 0u;
+    uint32_t mm = 0;
+    if (ok) mm = count_mismatch<NW>(g2, gp, o_rd, o_mk);
+    if constexpr (kLong) {  // a single key-equal candidate of a long seed still owes its care characters >= 44 (probe_resolve)
+      uint32_t o_care[kCareWords];
+#pragma unroll
+      for (uint32_t w = 0; w < kCareWords; ++w) o_care[w] = shfl_pin(care[w], own);
+      const bool tail = (o_meta >> (on_m ? 21 : 20)) & 1u;
+      if (__ballot(ok && tail)) {
+        const StrandView& sv0 = svp;
+        const bool t = on_m ? tail_care_ok(svm, ok ? pos : 0u, o_care, seed_len_of((o_meta >> 3) & 63u))
+                            : tail_care_ok(sv0, ok ? pos : 0u, o_care, seed_len_of((o_meta >> 3) & 63u));
+        ok = ok && (!tail || t);
+      }
+    }
+    n_verified += ok ? 1u : 0u;
+    // ---- the turn's summaries, run by run
+    uint32_t key = have ? 2u * own + (on_m ? 1u : 0u) : 0xFFFFFFFFu;
+    RegionSummary acc = summary_empty();
+    if (ok) acc = summary_one(mm, gp);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      RegionSummary prev;
+      prev.min_mm = shfl_up_pin(acc.min_mm, (uint32_t)d);
+      prev.count = shfl_up_pin(acc.count, (uint32_t)d);
+      prev.first = shfl_up_pin(acc.first, (uint32_t)d);
+      prev.last = shfl_up_pin(acc.last, (uint32_t)d);
+      const uint32_t pkey = shfl_up_pin(key, (uint32_t)d);
+      const RegionSummary both = summary_merge(prev, acc);
+      const bool join = lane >= (uint32_t)d && pkey == key;
+      acc.min_mm = join ? both.min_mm : acc.min_mm;
+      acc.count = join ? both.count : acc.count;
+      acc.first = join ? both.first : acc.first;
+      acc.last = join ? both.last : acc.last;
+    }
+    // ---- back to the owners: the last lane of my '+' run and of my '-' run in this turn
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const uint32_t lo = f ? off + n_p : off, hi = f ? off + n_p + n_m : off + n_p;
+      const uint32_t a = lo > base ? lo : base, e = hi < base + 64 ? hi : base + 64;
+      const bool mine = e > a;
+      const int src = mine ? (int)(e - 1 - base) : 0;
+      RegionSummary run;
+      run.min_mm = shfl_pin(acc.min_mm, (uint32_t)src);
+      run.count = shfl_pin(acc.count, (uint32_t)src);
+      run.first = shfl_pin(acc.first, (uint32_t)src);
+      run.last = shfl_pin(acc.last, (uint32_t)src);
+      RegionSummary& sum = f ? sum_m : sum_p;
+      const RegionSummary both = summary_merge(sum, run);
+      sum.min_mm = mine ? both.min_mm : sum.min_mm;
+      sum.count = mine ? both.count : sum.count;
+      sum.first = mine ? both.first : sum.first;
+      sum.last = mine ? both.last : sum.last;
+    }
+  }
+}
+
 // does the reference probe seed shift seed_i when the best mismatch count so far is mm?  (mapping.cpp:248-263: never
 // again after an exact match; after a one-mismatch match only the first kExitOneMismatch shifts.)  Monotone: a larger
 // mm never needs fewer seeds, a later seed is never needed when an earlier one is not.
@@ -889,6 +1011,20 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
   flush_counters(ctr, shortv, stats);
 }
 
+#if defined(WALT_DIAG)
+// Diagnostic build: phase sums of k_se_stage (WALT_AMD_STAMPS=4; walt_profile_stage_stamps).  Phases: 0 taking a read
+// (record / state loads), 1 seed query + filter + directory loads, 2 exact danger test, 3 entries + resolve, 4 masks +
+// small regions, 5 dense range + mid regions, 6 work items, 7 state store / lists / finished reads, 8 total.
+__device__ unsigned long long g_stage_stamps[16];
+__device__ uint32_t g_stage_stamps_on;
+#define STG_DECL StampsT<true> sst; const bool sst_on = g_stage_stamps_on != 0; stamp_begin(sst, g_stage_stamps)
+#define STG(k) do { if (sst_on) stamp(sst, (k)); } while (0)
+#define STG_END do { if (sst_on) stamp_end(sst); } while (0)
+#else
+#define STG_DECL
+#define STG(k)
+#define STG_END
+#endif
 // ---------------------------------------------------------------------------
 // k_se_stage: one ROUND of the staged heavy pass over one chunk of the heavy list (HeavyStage).  One read per lane;
 // a lane runs its seed shifts until a probe produces a work item, a dangerous probe sends the read to the literal list,
@@ -946,33 +1082,88 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
   const uint64_t c_lo = (uint64_t)blockIdx.x * per_block;
   const uint64_t c_hi = c_lo + per_block < chunks ? c_lo + per_block : chunks;
   const uint64_t o_first = offsets[0];
-  // fetched one chunk ahead: round 0: the heavy-list entry and the read's offsets; later rounds: the list entry
-  uint32_t e_nx = 0;
-  uint64_t o_nx = 0, oe_nx = 0;
-  auto fetch = [&](uint64_t i) {
-    if (hs.round == 0) {
-      e_nx = heavy_list[i];
-      const uint32_t r = e_nx & kDeferMask;
-      o_nx = offsets[r];
-      oe_nx = offsets[(uint64_t)r + 1];
-    } else {
-      e_nx = hs.list_in[i];
+  // The block's slice of the list goes to its wavefronts in equal parts, and a wavefront hands ITS part out read by read:
+  // the lanes that need a read take the next ones in lane order (round 4, late; with a fixed column of reads per lane --
+  // c * 256 + thread -- the lanes whose reads were done early waited for the lane with the most seed shifts: 42 of 64
+  // lanes in a seed shift).  The list entries (round 0: and the reads' offsets) are fetched a window of 64 ahead, lane L
+  // holding entry `win + L` (A) and `win + 64 + L` (B); a taker gets its entry by ds_bpermute.
+  const uint32_t lane_id = threadIdx.x & 63u;
+  const uint64_t b_lo = c_lo * blockDim.x, b_hi = c_hi * blockDim.x < n ? c_hi * blockDim.x : n;
+  const uint64_t per_wave = ((((b_hi > b_lo ? b_hi - b_lo : 0) + (blockDim.x >> 6) - 1) / (blockDim.x >> 6)) + 63) & ~63ull;
+  const uint64_t w_lo = b_lo + (threadIdx.x >> 6) * per_wave < b_hi ? b_lo + (threadIdx.x >> 6) * per_wave : b_hi;
+  const uint64_t w_hi = w_lo + per_wave < b_hi ? w_lo + per_wave : b_hi;
+  uint64_t cursor = w_lo, win = w_lo;  // (wave-uniform) next read to hand out; first entry of window A
+  uint32_t e_a = 0, e_b = 0;
+  uint64_t o_a = 0, oe_a = 0, o_b = 0, oe_b = 0;
+  auto fetch = [&](uint64_t i, uint32_t& e, uint64_t& o, uint64_t& oe) {
+    e = 0; o = 0; oe = 0;
+    if (i < w_hi) {
+      if (hs.round == 0) {
+        e = heavy_list[i];
+        const uint32_t r = e & kDeferMask;
+        o = offsets[r];
+        oe = offsets[(uint64_t)r + 1];
+      } else {
+        e = hs.list_in[i];
+      }
     }
   };
-  if (c_lo < c_hi && c_lo * blockDim.x + threadIdx.x < n) fetch(c_lo * blockDim.x + threadIdx.x);
-  for (uint64_t c = c_lo; c < c_hi; ++c) {
-    const uint64_t i64 = c * blockDim.x + threadIdx.x;
-    const bool valid = i64 < n;
-    const uint32_t e_cur = e_nx;
-    const uint64_t o_cur = o_nx, oe_cur = oe_nx;
-    if (c + 1 < c_hi && i64 + blockDim.x < n) fetch(i64 + blockDim.x);
+  fetch(win + lane_id, e_a, o_a, oe_a);
+  fetch(win + 64 + lane_id, e_b, o_b, oe_b);
+  // Every LANE has a read of its own, takes it one seed shift further per turn of the loop below, and takes its next
+  // read as soon as this one is blocked, deferred or finished (round 4, late): until then the 64 reads of a wavefront
+  // iteration went through the seed shifts together, and a lane whose read was done after the first shift idled while some
+  // other lane ran a second and a third -- 29 of 64 lanes per vector instruction.  Per-lane state of the current read:
+  bool have = false;
+  LaneRead<NW> lr;
+  lr.len = 0; lr.repeats = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) lr.rd[w] = 0;
+  BestMatch best;  // mapping.cpp:486; only '+' folds reach it before the end, so its strand is '+' throughout
+  best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
+  uint32_t minus_lb = 0xFFFFFFFFu;  // smallest mismatch count any kept '-' summary holds
+  uint32_t j = 0, r = 0, seed_i = 0, seed_len = 0, defer_iter = 0;
+  bool active = false, fin = false, deferred = false;
+  STG_DECL;
+  for (;;) {
+    const uint64_t takers = __ballot(!have);
+    const uint64_t i64 = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(takers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)takers, 0u));
+    const bool valid = !have && i64 < w_hi;  // this lane takes its next read now
+    if (__ballot(valid)) {
+    // its list entry: in window A or B (cursor < win + 64 and at most 64 takers: i64 < win + 128)
+    const uint32_t rel = valid ? (uint32_t)(i64 - win) : 0u;
+    const int src = (int)(rel & 63u);
+    const bool in_b = rel >= 64u;
+    const uint32_t ea = shfl_pin(e_a, (uint32_t)src), eb = shfl_pin(e_b, (uint32_t)src);
+    const uint32_t e_cur = in_b ? eb : ea;
+    uint64_t o_cur = 0, oe_cur = 0;
+    if (hs.round == 0) {  // (uniform)
+      const uint32_t ola = shfl_pin((uint32_t)o_a, (uint32_t)src), olb = shfl_pin((uint32_t)o_b, (uint32_t)src);
+      const uint32_t oha = shfl_pin((uint32_t)(o_a >> 32), (uint32_t)src), ohb = shfl_pin((uint32_t)(o_b >> 32), (uint32_t)src);
+      const uint32_t ela = shfl_pin((uint32_t)oe_a, (uint32_t)src), elb = shfl_pin((uint32_t)oe_b, (uint32_t)src);
+      const uint32_t eha = shfl_pin((uint32_t)(oe_a >> 32), (uint32_t)src), ehb = shfl_pin((uint32_t)(oe_b >> 32), (uint32_t)src);
+      o_cur = (uint64_t)(in_b ? olb : ola) | ((uint64_t)(in_b ? ohb : oha) << 32);
+      oe_cur = (uint64_t)(in_b ? elb : ela) | ((uint64_t)(in_b ? ehb : eha) << 32);
+    }
+    cursor += (uint64_t)__popcll(takers);
+    cursor = cursor < w_hi ? cursor : w_hi;
+    if (cursor >= win + 64) {  // (uniform) window A is used up: B becomes A, the next 64 entries are fetched
+      e_a = e_b; o_a = o_b; oe_a = oe_b;
+      win += 64;
+      fetch(win + 64 + lane_id, e_b, o_b, oe_b);
+    }
 
-    // ---- this lane's read and its state
-    LaneRead<NW> lr;
-    BestMatch best;  // mapping.cpp:486; only '+' folds reach it before the end, so its strand is '+' throughout
-    best.genome_pos = 0; best.times = 0; best.strand = '+'; best.mismatch = max_mm;
-    uint32_t minus_lb = 0xFFFFFFFFu;  // smallest mismatch count any kept '-' summary holds
-    uint32_t j = 0, r = 0, seed_i = 0;
+    // ---- the read and its state (into t_*: the lanes that keep their read keep everything)
+    LaneRead<NW> t_lr;
+    BestMatch t_best;
+    t_best.genome_pos = 0; t_best.times = 0; t_best.strand = '+'; t_best.mismatch = max_mm;
+    uint32_t t_minus_lb = 0xFFFFFFFFu;
+    uint32_t t_j = 0, t_r = 0, t_seed_i = 0;
+    {
+    LaneRead<NW>& lr = t_lr;
+    BestMatch& best = t_best;
+    uint32_t& minus_lb = t_minus_lb;
+    uint32_t& j = t_j; uint32_t& r = t_r; uint32_t& seed_i = t_seed_i;
     if (hs.round == 0) {
       j = (uint32_t)i64;
       r = valid ? e_cur & kDeferMask : 0u;
@@ -1028,21 +1219,36 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
         seed_i = s_blocked + 1;
       }
     }
-    const uint32_t seed_len = seed_len_of(lr.repeats);
-    bool active = valid && lr.len >= kMinReadLen && seed_i < kPat;
-    bool fin = valid && !active;  // finished: the '-' folds and the record are left (seed_i = seeds that have been done)
-    bool deferred = false;
-    uint32_t defer_iter = 0;
+    }
+    if (valid) {
+      lr.len = t_lr.len; lr.repeats = t_lr.repeats;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) lr.rd[w] = t_lr.rd[w];
+      best = t_best;
+      minus_lb = t_minus_lb;
+      j = t_j; r = t_r; seed_i = t_seed_i;
+      seed_len = seed_len_of(lr.repeats);
+      have = true;
+      active = lr.len >= kMinReadLen && seed_i < kPat;
+      fin = !active;  // finished: the '-' folds and the record are left (seed_i = seeds that have been done)
+      deferred = false;
+      defer_iter = 0;
+    }
+    }
+    STG(0);
+    if (!__ballot(have)) break;  // the wavefront's part of the list is used up
 
-    // ---- seed shifts, until blocked (a lane's seed_i is its own)
-    while (__ballot(active)) {
+    // ---- one seed shift for the lanes whose read goes on (a lane's seed_i is its own)
+    if (__ballot(active)) {
       // '+': exact (mapping.cpp:250-257 with the state after the '+' folds so far); '-': a superset of the reference's
       // decision (se_process_dual's header comment).  Monotone in the seed: when neither is needed, nothing later is.
       bool need_p = active && seed_needed(best.mismatch, seed_i);
       const uint32_t lb = best.mismatch < minus_lb ? best.mismatch : minus_lb;
       bool need_m = active && seed_needed(lb, seed_i);
       if (active && !need_p && !need_m) { fin = true; active = false; }
-      if (!__ballot(active)) break;
+      if (__ballot(active)) {
+      WALT_DIAG_COUNT(2, 1);                                // seed steps of a wavefront
+      WALT_DIAG_COUNT(3, __popcll(__ballot(active)));       // ... and the lanes in them
       const uint32_t sd = active ? seed_i : 0u;  // (an idle lane computes along on seed 0)
       RegionSummary sum_p = summary_empty(), sum_m = summary_empty();
       bool pend_p = false, pend_m = false;  // the summary comes from k_se_verify
@@ -1061,6 +1267,7 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
       probe_issue(svm, need_m, slot, span, pm, hi_m);
       const bool bad_p = need_p && bw_p && danger_filter_hit(bw_p, care);
       const bool bad_m = need_m && bw_m && danger_filter_hit(bw_m, care);
+      STG(1);
       bool lit_p = false, lit_m = false;  // LIT: this strand's region comes from the reference's search
       if (bad_p || bad_m) {  // a filter hit is a superset of the dangerous probes: the exact test
         const bool dng_p = bad_p && probe_is_dangerous(svp, care, seed_len);
@@ -1076,8 +1283,18 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
           defer_iter = defer_iter < 7u ? defer_iter : 7u;
         }
       }
+      STG(2);
       pp.ne = (need_p && !lit_p && hi_p > pp.lo) ? hi_p - pp.lo : 0u;
       pm.ne = (need_m && !lit_m && hi_m > pm.lo) ? hi_m - pm.lo : 0u;
+#if defined(WALT_DIAG)
+      if (WALT_DIAG_TWICE(3)) {  // (other lines of the same slots: the entries behind the first four)
+        SlotProbe p2 = pp, m2 = pm;
+        p2.lo += p2.ne > 64 ? 48 : 0; m2.lo += m2.ne > 64 ? 48 : 0;
+        probe_entries(svp, p2);
+        probe_entries(svm, m2);
+        if (p2.e[1].pos == 0xFFFFFFF0u && m2.e[1].pos == 0xFFFFFFF1u) pp.lo = 0;  // (keeps the loads alive)
+      }
+#endif
       probe_entries(svp, pp);
       probe_entries(svm, pm);
       Lookup lp, lm;
@@ -1095,6 +1312,7 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
       }
       uint32_t size_p = lp.reg.l <= lp.reg.u ? lp.reg.u - lp.reg.l + 1 : 0;
       uint32_t size_m = lm.reg.l <= lm.reg.u ? lm.reg.u - lm.reg.l + 1 : 0;
+      STG(3);
       ctr.probes += (size_p ? 1u : 0u) + (size_m ? 1u : 0u);
       // patterns 5 / 7: a key-equal range of several slots whose candidates owe their tail characters (probe_resolve_dual)
       MidTail mt;
@@ -1106,8 +1324,26 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
       make_masks<NW>(mk, sh.mask_table, sd, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
       const uint32_t tail_cut = tail_care_cut(sd, seed_len);
 
+      constexpr uint32_t kLaneMax = (MIDS || kMulti) ? kMidRegion : kSmallRegion;  // largest region a lane verifies itself
+      const bool big_p = size_p > kLaneMax || defer_p, big_m = size_m > kLaneMax || defer_m;
+      constexpr bool kCoop = kPat == 3;  // the lanes' own regions as one list over the wavefront (coop_lane_regions)
+      if constexpr (kCoop) {
+        const uint32_t own_p = big_p ? 0u : size_p, own_m = big_m ? 0u : size_m;
+#if defined(WALT_DIAG)
+        if (WALT_DIAG_TWICE(2) && __ballot(own_p | own_m)) {
+          RegionSummary d_p = summary_empty(), d_m = summary_empty();
+          uint32_t d_n = 0;
+          coop_lane_regions<NW>(iv, sh, svp, svm, own_p, own_m, lp.reg.l, lm.reg.l, lp.pos[0], lm.pos[0], lp.npos != 0, lm.npos != 0,
+                                sd, lr, mk, tail_p, tail_m, care, n_chrom, d_p, d_m, d_n);
+          if (d_n == 0xFFFFFFF0u) sum_p = d_p;  // (keeps the copy alive)
+        }
+#endif
+        if (__ballot(own_p | own_m))
+          coop_lane_regions<NW>(iv, sh, svp, svm, own_p, own_m, lp.reg.l, lm.reg.l, lp.pos[0], lm.pos[0], lp.npos != 0, lm.npos != 0,
+                                sd, lr, mk, tail_p, tail_m, care, n_chrom, sum_p, sum_m, ctr.verified);
+      }
       // small regions: candidate k of both strands checked side by side
-      const bool small_p = size_p && size_p <= kSmallRegion, small_m = size_m && size_m <= kSmallRegion;
+      const bool small_p = !kCoop && size_p && size_p <= kSmallRegion, small_m = !kCoop && size_m && size_m <= kSmallRegion;
       if (__ballot(small_p || small_m)) {
         const uint32_t kmax = (small_p ? size_p : 0u) > (small_m ? size_m : 0u) ? size_p : (small_m ? size_m : 0u);
 #pragma unroll 1
@@ -1146,14 +1382,13 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
       // larger regions: the dense range of those that become items (two loads, all lanes together); regions of up to
       // kMidRegion candidates stay with their lane (a deferred range -- long seeds -- is an item whatever its size: only
       // the verifier can narrow it)
-      constexpr uint32_t kLaneMax = (MIDS || kMulti) ? kMidRegion : kSmallRegion;  // largest region a lane verifies itself
-      const bool big_p = size_p > kLaneMax || defer_p, big_m = size_m > kLaneMax || defer_m;
+      STG(4);
       const DenseRange dr_p = dense_range(svp, lp.reg.l, size_p, big_p && win_usable<NW>(svp, lr.len));
       const DenseRange dr_m = dense_range(svm, lm.reg.l, size_m, big_m && win_usable<NW>(svm, lr.len));
       {
-        const uint32_t nmid_p = (size_p > kSmallRegion && !big_p) ? size_p : 0u;
-        const uint32_t nmid_m = (size_m > kSmallRegion && !big_m) ? size_m : 0u;
-        if constexpr (MIDS || kMulti)
+        const uint32_t nmid_p = (!kCoop && size_p > kSmallRegion && !big_p) ? size_p : 0u;
+        const uint32_t nmid_m = (!kCoop && size_m > kSmallRegion && !big_m) ? size_m : 0u;
+        if constexpr ((MIDS || kMulti) && !kCoop)
         if (__ballot(nmid_p | nmid_m))
           se_mid_regions<NW, kMulti>(iv, sh, svp, svm, nmid_p, nmid_m, lp.reg.l, lm.reg.l, sd, lr.len, lr.rd, mk, n_chrom, top_step,
                                      tail_cut, mt, sum_p, sum_m, ctr.verified);
@@ -1182,6 +1417,7 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
           }
         }
       }
+      STG(5);
       if (__ballot(big_p || big_m)) {  // both strands' large regions become work items: one atomic for the two (map_items.h item_append2)
         const bool big2[2] = {big_p, big_m};
         const bool dense2[2] = {big_p && dr_p.hi > dr_p.lo, big_m && dr_m.hi > dr_m.lo};
@@ -1192,6 +1428,7 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
         if (big_p) { ++ctr.big; pend_p = true; }
         if (big_m) { ++ctr.big; pend_m = true; }
       }
+      STG(6);
       // ---- the seed is done, or the read waits for the verifier
       bool blocked = false;
       if (active) {
@@ -1210,8 +1447,12 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
         }
       }
       wavelist_append(wl, blocked, stage_entry(j, seed_i), &hs.ctl[4], hs.list_out);
+      }
     }
-    wave_append(deferred, r | (defer_iter << kDeferShift), defer_count, defer_list);
+    // ---- the lanes whose read is blocked, deferred or finished leave it (and take the next one at the loop's top)
+    const bool leave = have && !active;
+    fin = fin && leave;
+    wave_append(leave && deferred, r | (defer_iter << kDeferShift), defer_count, defer_list);
     // ---- finished reads: the '-' strand's summaries folded in reference order under the exact exit conditions
     if (__ballot(fin)) {
       uint4 ng[kPat];
@@ -1229,7 +1470,10 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
       }
       if (fin) out[r] = best;
     }
+    if (leave) { have = false; fin = false; deferred = false; }
+    STG(7);
   }
+  STG_END;
   if (hs.list_out != nullptr) wavelist_flush(wl, &hs.ctl[4], hs.list_out);
   flush_counters(ctr, 0u, stats);
 }
@@ -1610,7 +1854,12 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
           hipLaunchKernelGGL((k_se_stage<NW, 0, true>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
 
-        else if (NW <= 10 && opt.se_stage_occ == (NW <= 8 ? 3 : 2))  // A/B (option se_stage_occ): one wavefront per SIMD fewer, more registers
+        // One wavefront per SIMD fewer and no spilled registers (reads of up to 128 bases: 3 instead of 4; measured after
+        // the read hand-out and the candidate list went in: 38.6 against 39.6 ms per 50 M reads) -- unless the genome has
+        // more sequences than the LDS table of chromosome starts holds (map_common.h ChromTab): then every look-up
+        // bisects in HBM and the extra wavefront is worth more than the registers (3,000 contigs: 106.7 against 109.8 ms).
+        // Option se_stage_occ chooses explicitly (A/B).
+        else if (NW <= 10 && (opt.se_stage_occ ? opt.se_stage_occ == (NW <= 8 ? 3 : 2) : (NW <= 8 && view.n_chrom <= 1023u)))
           hipLaunchKernelGGL((k_se_stage<NW, (NW <= 8 ? 3 : 2)>), dim3(gh), dim3(kBlock), 0, cs, view, codes2, offsets, err,
                              strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list, count, list, hs, cy);
         else
@@ -1845,6 +2094,26 @@ int walt_profile_stamps(unsigned long long* out16) {
   return fail(WALT_EINVAL, "phase stamps exist in the diagnostic build only (make diag: libwalt_amd_diag.so)");
 #endif
 }
+
+#if defined(WALT_DIAG)
+// diagnostic library only: switch the phase stamps of k_se_stage on / off; read and clear their sums
+extern "C" int walt_profile_stage_stamps(int on, unsigned long long* out16) {
+  WALT_HIP(hipDeviceSynchronize());
+  unsigned long long zero[16] = {0};
+  if (out16) {
+    unsigned long long ctr[16];
+    WALT_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(walt::g_stage_stamps), sizeof(zero)));
+    WALT_HIP(hipMemcpyFromSymbol(ctr, HIP_SYMBOL(walt::g_diag_ctr), sizeof(ctr)));
+    for (int i = 0; i < 7; ++i) out16[9 + i] = ctr[i];
+  }
+  WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_stage_stamps), zero, sizeof(zero)));
+  WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_diag_ctr), zero, sizeof(zero)));
+  const uint32_t v = (on & 1) ? 1u : 0u, tw = (uint32_t)on >> 8;
+  WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_stage_stamps_on), &v, sizeof(v)));
+  WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_diag_twice), &tw, sizeof(tw)));
+  return WALT_OK;
+}
+#endif
 
 int walt_profile_detail(walt_index* idx, float* out4) {
   if (!idx || !out4 || !idx->profile || !idx->ev_valid) return fail(WALT_EINVAL, "no profiled call recorded");
