@@ -217,7 +217,8 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
  *   se_heavy_chunk 0  reads per chunk of the heavy list (0: default; a test hook for several chunks on a small batch)
  *   se_stage_blocks / se_verify_blocks 0  blocks per compute unit of the stage / dense verifier launches (0: fill the device)
  *   se_stagger     0  the second half of the heavy pass starts one look-up stage behind the first
- *   se_lit_side    1  literal pass on a side stream beside the end of the heavy pass
+ *   se_lit_side    1  literal pass on a side stream beside the end of the heavy pass (0: after it; 2: what pass 1
+ *                     deferred beside the whole heavy pass, the staged rounds' deferrals beside its end)
  *   se_lit_staged  0  reads with a truly dangerous probe go through staged rounds with the reference's search on instead
  *   se_defer_min  -1  long seeds: key-equal ranges of more slots than this go to the verifier unnarrowed (-1: default 4, 0: never)
  *   se_stage_occ   0  wavefronts per SIMD the stage kernel is built for (0: chosen by read length and sequence count;

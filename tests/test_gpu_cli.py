@@ -53,7 +53,7 @@ def test_cli_output_files_identical_to_reference(cli_index, scratch, case):
 
 
 @pytest.mark.parametrize("env", [{"se_pipe": "0"}, {"se_pipe": "0", "se_heavy_chunk": "64"},
-                                 {"se_heavy_chunk": "64"}, {"se_lit_side": "0"}, {"se_lit_staged": "1"}, {"se_carry": "0", "se_heavy_chunk": "64"}])
+                                 {"se_heavy_chunk": "64"}, {"se_lit_side": "0"}, {"se_lit_side": "1"}, {"se_lit_side": "2"}, {"se_lit_side": "2", "se_pipe": "0"}, {"se_lit_staged": "1"}, {"se_carry": "0", "se_heavy_chunk": "64"}])
 @pytest.mark.parametrize("case", ["se_sam_au", "se150_ag_sam_au_m10"])
 def test_cli_single_end_schedules_give_the_same_files(cli_index, scratch, case, env):
     """The staged heavy pass has two schedules -- two halves of the heavy list on two streams, each with its own state

@@ -31,7 +31,7 @@ struct walt_options {
   int se_verify_blocks = 0;   // ... of the dense verifier launches (0: its occupancy)
   int se_stagger = 0;         // the second half of the heavy pass starts one look-up stage behind the first
   int se_lit_ablate = 0;      // measurement only (results wrong when set)
-  int se_lit_side = 1;        // the literal pass on a side stream beside the end of the heavy pass
+  int se_lit_side = 1;        // the literal pass on a side stream beside the end of the heavy pass (2: pass 1's share right after pass 1)
   int se_lit_staged = 0;      // the deferred reads through staged rounds with the reference's search on instead of the strand-major kernel
   long long se_defer_min = -1;   // long seeds: key-equal ranges of more slots go to the verifier (-1: default, 0: never)
   int se_stage_occ = 0;       // wavefronts per SIMD the stage kernel is built for (0: default)

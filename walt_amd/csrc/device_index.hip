@@ -1132,7 +1132,7 @@ struct OptionName {
 #define WALT_OPT_I(f, lo, hi) {#f, 0, offsetof(walt_options, f), lo, hi}
 #define WALT_OPT_L(f, lo, hi) {#f, 1, offsetof(walt_options, f), lo, hi}
 const OptionName kOptions[] = {
-    WALT_OPT_I(se_pipe, 0, 1),        WALT_OPT_L(se_heavy_chunk, 0, 1ll << 28), WALT_OPT_I(se_lit_staged, 0, 1), WALT_OPT_I(se_stage_blocks, 0, 16), WALT_OPT_I(se_verify_blocks, 0, 16), WALT_OPT_I(se_stagger, 0, 1), WALT_OPT_I(se_lit_side, 0, 1), WALT_OPT_I(se_lit_ablate, 0, 7),
+    WALT_OPT_I(se_pipe, 0, 1),        WALT_OPT_L(se_heavy_chunk, 0, 1ll << 28), WALT_OPT_I(se_lit_staged, 0, 1), WALT_OPT_I(se_stage_blocks, 0, 16), WALT_OPT_I(se_verify_blocks, 0, 16), WALT_OPT_I(se_stagger, 0, 1), WALT_OPT_I(se_lit_side, 0, 2), WALT_OPT_I(se_lit_ablate, 0, 7),
     WALT_OPT_L(se_defer_min, -1, 1ll << 30), WALT_OPT_I(se_stage_occ, 0, 4),   WALT_OPT_I(se_carry, 0, 1),
     WALT_OPT_I(se_heavy_mono, 0, 1),  WALT_OPT_L(grid, 0, 1ll << 20),           WALT_OPT_I(pe_mode, 0, 1),
     WALT_OPT_L(pe_chunk, 0, 1ll << 28), WALT_OPT_L(pe_rounds, 0, 4),            WALT_OPT_L(pe_stage_cap, 0, 1ll << 28),

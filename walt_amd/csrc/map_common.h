@@ -998,7 +998,7 @@ __device__ __forceinline__ void wavelist_append(WaveList& w, bool take, uint32_t
 constexpr uint32_t kDeferShift = 28;
 constexpr uint32_t kDeferMask = (1u << kDeferShift) - 1;
 void launch_bin_deferred(uint32_t* d_ctl /*32 zeroed words: [0] = count*/, const uint32_t* d_list, uint32_t* d_sorted,
-                         hipStream_t stream);
+                         hipStream_t stream, const uint32_t* d_first = nullptr /*device word: first entry of the share (nullptr: 0)*/);
 
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream);
 

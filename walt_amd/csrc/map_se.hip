@@ -307,6 +307,10 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
 // SlotProbe / probe_issue / probe_entries / probe_resolve / verify_nobranch live in map_common.h (shared with map_pe.hip)
 
 constexpr uint32_t kMidRegion = 16;  // heavy pass: regions up to this size are verified by their own lane, in batches
+#ifndef WALT_COOP_REGION
+#define WALT_COOP_REGION 16
+#endif
+constexpr uint32_t kCoopRegion = WALT_COOP_REGION;  // ... with the wavefront's candidate list (pattern 3: coop_lane_regions): up to this size
 
 // ---- staged heavy pass (round 4: run until blocked) ------------------------------------------------------------
 // The heavy list is mapped chunk by chunk (hcap reads) in ROUNDS.  In a round a lane takes one read and goes through
@@ -873,6 +877,19 @@ static __global__ void k_lit_snapshot(const uint32_t* __restrict__ count, uint32
   if (threadIdx.x == 0) { ctl2[0] = *count; rng[0] = *count; }
   if (threadIdx.x >= 8 && threadIdx.x < 24) ctl2[threadIdx.x] = 0;
 }
+// the second share of the side launches: the entries behind the first share (rng[0]) up to the list's length now --
+// ctl3 = {their number, .., [8..23] = 0 (bins), [24..25] = their range}; rng[0] = the length now (what the last launch starts at)
+static __global__ void k_lit_snapshot_rest(const uint32_t* __restrict__ count, uint32_t* __restrict__ ctl3, uint32_t* __restrict__ rng) {
+  if (threadIdx.x == 0) {
+    const uint32_t first = rng[0], c = *count;
+    ctl3[0] = c > first ? c - first : 0u;
+    ctl3[1] = first;
+    ctl3[24] = first;
+    ctl3[25] = c > first ? c : first;
+    rng[0] = c > first ? c : first;
+  }
+  if (threadIdx.x >= 8 && threadIdx.x < 24) ctl3[threadIdx.x] = 0;
+}
 static __global__ void k_lit_end(const uint32_t* __restrict__ count, uint32_t* __restrict__ rng) { rng[1] = *count; }
 // rng = {first, end}: the entries of the deferred list behind the `done` the literal rounds have mapped
 static __global__ void k_lit_rest(const uint32_t* __restrict__ count, uint32_t* __restrict__ rng, uint32_t done) {
@@ -880,10 +897,12 @@ static __global__ void k_lit_rest(const uint32_t* __restrict__ count, uint32_t* 
   rng[0] = done < c ? done : c;
   rng[1] = c;
 }
-static __global__ void k_bin_count(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list) {
+// (first != nullptr: the ctl[0] entries from *first on, sorted into the same places of `sorted`)
+static __global__ void k_bin_count(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, const uint32_t* __restrict__ first) {
   __shared__ uint32_t bins[8];
   if (threadIdx.x < 8) bins[threadIdx.x] = 0;
   __syncthreads();
+  if (first != nullptr) list += *first;
   uint32_t lo, hi;
   bin_slice(ctl[0], lo, hi);
   const uint32_t lane = threadIdx.x & 63;
@@ -899,10 +918,11 @@ static __global__ void k_bin_count(uint32_t* __restrict__ ctl, const uint32_t* _
   if (threadIdx.x < 8 && bins[threadIdx.x]) atomicAdd(&ctl[8 + threadIdx.x], bins[threadIdx.x]);
 }
 static __global__ void k_bin_scatter(uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list,
-                                     uint32_t* __restrict__ sorted) {
+                                     uint32_t* __restrict__ sorted, const uint32_t* __restrict__ first) {
   __shared__ uint32_t bins[8], cursor[8];
   if (threadIdx.x < 8) bins[threadIdx.x] = 0;
   __syncthreads();
+  if (first != nullptr) { list += *first; sorted += *first; }
   uint32_t lo, hi;
   bin_slice(ctl[0], lo, hi);
   const uint32_t lane = threadIdx.x & 63;
@@ -935,9 +955,9 @@ static __global__ void k_bin_scatter(uint32_t* __restrict__ ctl, const uint32_t*
     }
   }
 }
-void launch_bin_deferred(uint32_t* d_ctl, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream) {
-  hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBlock), 0, stream, d_ctl, d_list);
-  hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBlock), 0, stream, d_ctl, d_list, d_sorted);
+void launch_bin_deferred(uint32_t* d_ctl, const uint32_t* d_list, uint32_t* d_sorted, hipStream_t stream, const uint32_t* d_first) {
+  hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBlock), 0, stream, d_ctl, d_list, d_first);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBlock), 0, stream, d_ctl, d_list, d_sorted, d_first);
 }
 
 void launch_reduce_stats(unsigned long long* d_shards, unsigned long long* d_stats, hipStream_t stream) {
@@ -1324,9 +1344,9 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : (LIT ? (NW <= 8 ? 3 : (NW <= 10
       make_masks<NW>(mk, sh.mask_table, sd, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
       const uint32_t tail_cut = tail_care_cut(sd, seed_len);
 
-      constexpr uint32_t kLaneMax = (MIDS || kMulti) ? kMidRegion : kSmallRegion;  // largest region a lane verifies itself
-      const bool big_p = size_p > kLaneMax || defer_p, big_m = size_m > kLaneMax || defer_m;
       constexpr bool kCoop = kPat == 3;  // the lanes' own regions as one list over the wavefront (coop_lane_regions)
+      constexpr uint32_t kLaneMax = kCoop ? kCoopRegion : ((MIDS || kMulti) ? kMidRegion : kSmallRegion);  // largest region a lane verifies itself
+      const bool big_p = size_p > kLaneMax || defer_p, big_m = size_m > kLaneMax || defer_m;
       if constexpr (kCoop) {
         const uint32_t own_p = big_p ? 0u : size_p, own_m = big_m ? 0u : size_m;
 #if defined(WALT_DIAG)
@@ -1638,7 +1658,7 @@ uint64_t se_stride(uint32_t n) { return align_up(n ? n : 1, 64); }
 // (walt_se_workspace_bytes, which knows no index) is that of the DEFAULT options, and no option may need more: an
 // option value that would is not applied (se_geometry).
 constexpr uint32_t kLitChunks = 2;  // chunks of the deferred list the literal rounds take (launch_map_se)
-constexpr uint32_t kHeavyCtlWords = 64 * kPat + 8 * kPat * kLitChunks + 8;  // 8 words per (chunk, round): up to 8 chunks x kPat rounds, the literal rounds' chunks, the rest launch's range
+constexpr uint32_t kHeavyCtlWords = 64 * kPat + 8 * kPat * kLitChunks + 32 + 8;  // 8 words per (chunk, round): up to 8 chunks x kPat rounds, the literal rounds' chunks, the side launch's second share, the rest launch's range
 struct SeGeometry {
   uint32_t hcap;     // reads per chunk
   uint32_t chunks;   // launched chunks (<= 8; even when piped)
@@ -1832,6 +1852,22 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       WALT_HIP(hipStreamCreateWithFlags(&idx->se_pipe, hipStreamNonBlocking));
       for (hipEvent_t& e : idx->se_pipe_ev) WALT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    // se_lit_side = 2 (default): the side launch starts HERE, on what pass 1 deferred (most of the list: pass 1 sees every
+    // read, the staged rounds the heavy sixth), and runs beside the whole heavy pass -- a chain of dependent look-ups in
+    // few wavefronts that fills a fraction of the device; what the staged rounds defer is mapped at the end.  The
+    // snapshot is taken before any staged kernel of either half can append to the list.
+    const bool lit_early = lit_side && opt.se_lit_side >= 2;
+    if (lit_early) {
+      hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, stream, defer_count, ctl2, rng_side);
+      WALT_HIP(hipEventRecord(idx->se_fork, stream));
+      WALT_HIP(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
+      forked = true;
+      launch_bin_deferred(ctl2, defer_list, defer_list + stride, idx->se_side);
+      const unsigned g_lit = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+      hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g_lit), dim3(kBlock), 0, idx->se_side, view, codes2, offsets, err,
+                         strand_base, max_mm, b, idx->d_mask_table, out, stats, ctl2, defer_list + stride, 0u);
+      WALT_HIP_FORKED(hipEventRecord(idx->se_join, idx->se_side));
+    }
     if (piped) {  // (pass 1 done)
       WALT_HIP(hipEventRecord(idx->se_pipe_ev[0], stream));
       WALT_HIP(hipStreamWaitEvent(idx->se_pipe, idx->se_pipe_ev[0], 0));
@@ -1873,7 +1909,19 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
         }
         if (!lit && round == kPat - 1) {  // (round kPat probes nothing: this chunk has made its last deferrals)
           if (piped && c_side == 0) WALT_HIP_FORKED(hipEventRecord(idx->se_pipe_ev[1], stream));
-          if (lit_side && c_side == (piped ? 1u : 0u)) {
+          if (lit_early && c_side == (piped ? 1u : 0u)) {  // the second share: what the staged rounds deferred
+            if (piped) WALT_HIP_FORKED(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));
+            uint32_t* const ctl3 = ctl0 + 64 * kPat + 8 * kPat * kLitChunks;
+            hipLaunchKernelGGL(k_lit_snapshot_rest, dim3(1), dim3(64), 0, cs, defer_count, ctl3, rng_side);
+            WALT_HIP_FORKED(hipEventRecord(idx->se_fork, cs));
+            WALT_HIP_FORKED(hipStreamWaitEvent(idx->se_side, idx->se_fork, 0));
+            launch_bin_deferred(ctl3, defer_list, defer_list + stride, idx->se_side, ctl3 + 1);
+            const unsigned g_lit = grid_for(n) < kLiteralGrid ? grid_for(n) : kLiteralGrid;
+            hipLaunchKernelGGL(k_map_se_literal<NW>, dim3(g_lit), dim3(kBlock), 0, idx->se_side, view, codes2, offsets, err,
+                               strand_base, max_mm, b, idx->d_mask_table, out, stats, defer_count, defer_list + stride, 0u, ctl3 + 24);
+            WALT_HIP_FORKED(hipEventRecord(idx->se_join, idx->se_side));
+          }
+          if (lit_side && !lit_early && c_side == (piped ? 1u : 0u)) {
             if (piped) WALT_HIP_FORKED(hipStreamWaitEvent(cs, idx->se_pipe_ev[1], 0));
             hipLaunchKernelGGL(k_lit_snapshot, dim3(1), dim3(64), 0, cs, defer_count, ctl2, rng_side);
             WALT_HIP_FORKED(hipEventRecord(idx->se_fork, cs));
@@ -1904,7 +1952,7 @@ static int launch_map_se(walt_index* idx, const IndexView& view, const uint32_t*
       hs.first = c * hcap;
       hs.chunk = c;
       // chunks behind the first pair append to the deferred list: not while the side launch's share is being fixed
-      if (piped && lit_side && c == 2) WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_fork, 0));
+      if (piped && lit_side && !lit_early && c == 2) WALT_HIP_FORKED(hipStreamWaitEvent(stream, idx->se_fork, 0));
       const int rc_chunk = run_chunk(odd ? idx->se_pipe : stream, ctl0 + 8 * kPat * c, lists, false, heavy_count, heavy_list, carry, !odd, c);
       if (rc_chunk) return rc_chunk;
     }
