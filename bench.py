@@ -975,10 +975,19 @@ def worker(args):
         log("reads: %d x %d bp (%.1f s)" % (n, args.read_len, time.perf_counter() - t0))
         if os.environ.get("WALT_AMD_TWICE"):  # diagnostic library only: parts of k_se_stage run twice (bit mask)
             walt_amd.lib().walt_profile_stage_stamps(int(os.environ["WALT_AMD_TWICE"]) << 8, None)
+        if os.environ.get("WALT_AMD_STAMPS") == "5":  # diagnostic library only: phase sums of k_map_se_literal
+            walt_amd.lib().walt_profile_stage_stamps(2, None)
         if os.environ.get("WALT_AMD_STAMPS") == "4":  # diagnostic library only: phase sums of k_se_stage
             walt_amd.lib().walt_profile_stage_stamps(1, None)
         leg = se_leg(cx, idx, d_bases, d_off, n, args.read_len, args.max_mismatches, args.bucket, args.ag, args.steps,
                      args.warmup)
+        if os.environ.get("WALT_AMD_STAMPS") == "5":
+            buf = (ctypes.c_ulonglong * 16)()
+            walt_amd.lib().walt_profile_stage_stamps(0, buf)
+            tot = float(buf[8]) or 1.0
+            nm = ["read record", "care", "filter", "lookup", "masks", "candidate list", "large regions", "store"]
+            log("k_map_se_literal phase shares (s_memtime, drained at boundaries): " +
+                ", ".join("%s %.1f%%" % (x, 100.0 * buf[i] / tot) for i, x in enumerate(nm)))
         if os.environ.get("WALT_AMD_STAMPS") == "4":
             buf = (ctypes.c_ulonglong * 16)()
             walt_amd.lib().walt_profile_stage_stamps(0, buf)

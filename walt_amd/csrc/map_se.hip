@@ -165,6 +165,16 @@ __device__ __forceinline__ void stamp_end(StampsT<false>&) {}
 struct MapCounters {
   uint32_t probes, verified, big;
 };
+template <int NW>
+__device__ __forceinline__ void coop_lane_regions(const IndexView& iv, const BlockShared& sh, const StrandView& svp,
+                                                  const StrandView& svm, uint32_t n_p, uint32_t n_m, uint32_t l_p,
+                                                  uint32_t l_m, uint32_t pos0_p, uint32_t pos0_m, bool reg_p, bool reg_m,
+                                                  uint32_t sd, const LaneRead<NW>& lr, const uint32_t* mk,
+                                                  bool tail_p, bool tail_m, const uint32_t* care, uint32_t n_chrom,
+                                                  RegionSummary& sum_p, RegionSummary& sum_m, uint32_t& n_verified);
+// strand-major kernel: regions of up to this many slots go through the wavefront's candidate list (coop_lane_regions),
+// larger ones take the wavefront one at a time (coop_region: dense records where they exist)
+constexpr uint32_t kListRegion = 64;
 
 template <int NW, bool LITERAL, bool DIAG>
 __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh, const uint32_t* si,
@@ -239,24 +249,24 @@ __device__ __forceinline__ void se_process(const IndexView& iv, BlockShared& sh,
       make_masks<NW>(mk, sh.mask_table, seed_i, lr.repeats >= kMinRepeats ? lr.repeats : kMinRepeats, lr.len);
       stamp(st, 4);
 
-      // small regions: the owning lane walks its own candidates in order
-      if (size && size <= kSmallRegion) {
-        RegionSummary sum = summary_empty();
-#pragma unroll
-        for (uint32_t k = 0; k < kSmallRegion; ++k) {  // static k: lk.pos[] stays in registers
-          if (k < size) {
-            uint32_t pos = k < lk.npos ? lk.pos[k] : sv.ent[reg.l + k].pos, gp, mm;
-            if (verify_candidate<NW>(sv, si, iv.start_index, n_chrom, pos, seed_i, lr.len, lr.rd, mk, gp, mm)) {
-              sum = summary_merge(sum, summary_one(mm, gp));
-              ++ctr.verified;
-            }
-          }
+      // regions of up to kListRegion slots: ONE candidate list over the wavefront (round 4, late).  Before, a lane walked
+      // its region of up to four slots by itself and every larger one took the whole wavefront for itself, one after the
+      // other -- a region of five candidates cost the wavefront a turn like one of sixty-four, and a wavefront of this
+      // kernel has a dozen of them per probe phase.
+      {
+        const uint32_t own = (size && size <= kListRegion) ? size : 0u;
+        if (__ballot(own != 0)) {
+          RegionSummary sum = summary_empty(), none = summary_empty();
+          const uint32_t care0[kCareWords] = {};
+          coop_lane_regions<NW>(iv, sh, sv, sv, own, 0u, reg.l, 0u, lk.pos[0], 0u, lk.npos != 0, false, seed_i, lr, mk, false, false,
+                                care0, n_chrom, sum, none, ctr.verified);
+          fold_region(best, sum, strand_char);
+          if (own > kSmallRegion) ++ctr.big;  // (counted as before: regions the owning lane does not walk alone)
         }
-        fold_region(best, sum, strand_char);
       }
       stamp(st, 5);
       // large regions: the whole wave verifies one owner's region at a time
-      unsigned long long big = __ballot(size > kSmallRegion);
+      unsigned long long big = __ballot(size > kListRegion);
       while (big) {
         const int owner = (int)__ffsll((long long)big) - 1;
         big &= big - 1;
@@ -1037,7 +1047,7 @@ __global__ __launch_bounds__(kBlock, HEAVY ? (NW <= 8 ? 3 : (NW <= 10 ? 2 : 1)) 
 // small regions, 5 dense range + mid regions, 6 work items, 7 state store / lists / finished reads, 8 total.
 __device__ unsigned long long g_stage_stamps[16];
 __device__ uint32_t g_stage_stamps_on;
-#define STG_DECL StampsT<true> sst; const bool sst_on = g_stage_stamps_on != 0; stamp_begin(sst, g_stage_stamps)
+#define STG_DECL StampsT<true> sst; const bool sst_on = (g_stage_stamps_on & 1u) != 0; stamp_begin(sst, g_stage_stamps)
 #define STG(k) do { if (sst_on) stamp(sst, (k)); } while (0)
 #define STG_END do { if (sst_on) stamp_end(sst); } while (0)
 #else
@@ -1634,9 +1644,18 @@ __global__ __launch_bounds__(kBlock, NW <= 8 ? WALT_LIT_OCC : 1) void k_map_se_l
     const bool valid = i < count;
     const uint32_t r = valid ? (all_reads ? i : (defer_list[i] & kDeferMask)) : 0;
     uint32_t len;
+#if defined(WALT_DIAG)
+    // diagnostic library: phase sums of this kernel (se_process's phases, map_se.hip kStampPhases) when bit 1 of the switch is set
+    StampsT<true> st;
+    stamp_begin(st, g_stage_stamps);
+    se_process<NW, LITERAL, true>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, out,
+                                  LITERAL ? nullptr : defer_count, LITERAL ? nullptr : defer_list, ctr, len, 0u, st);
+    if (g_stage_stamps_on & 2u) stamp_end(st);
+#else
     StampsT<false> st;
     se_process<NW, LITERAL, false>(iv, sh, si, codes2, offsets, err, r, valid, strand_base, max_mm, b, out,
                                    LITERAL ? nullptr : defer_count, LITERAL ? nullptr : defer_list, ctr, len, 0u, st);
+#endif
     // too_short is counted once per strand pass (mapping.cpp:230-233); pass 1 counts it when there is one
     if (all_reads) shortv += (valid && len < kMinReadLen) ? 2u : 0u;
   }
@@ -2156,7 +2175,7 @@ extern "C" int walt_profile_stage_stamps(int on, unsigned long long* out16) {
   }
   WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_stage_stamps), zero, sizeof(zero)));
   WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_diag_ctr), zero, sizeof(zero)));
-  const uint32_t v = (on & 1) ? 1u : 0u, tw = (uint32_t)on >> 8;
+  const uint32_t v = (uint32_t)on & 3u, tw = (uint32_t)on >> 8;  // bit 0: k_se_stage's stamps, bit 1: k_map_se_literal's
   WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_stage_stamps_on), &v, sizeof(v)));
   WALT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(walt::g_diag_twice), &tw, sizeof(tw)));
   return WALT_OK;
