@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <random>
 #include <vector>
 
 #include "../walt_amd/csrc/host_common.h"
@@ -605,6 +606,73 @@ long hh_tail_mask_check(uint32_t seed) {
     uint32_t got_t = 0;
     const uint32_t got_mm = count_mismatch_tail<NW>(g2, gpos, rd, mk, seed_i, tail_care_cut(seed_i, seed_len), got_t);
     if (got_mm != want_mm || got_t != want_t) ++bad;
+  }
+  return bad;
+}
+
+// The wavefront's candidate list (map_se.hip coop_lane_regions) on the CPU, step for step: 64 "lanes" with random
+// regions on both strands, every candidate a random (passes the filters?, mismatches, position); per turn of 64
+// candidates the owner of candidate q is found by the kernel's bisection over the lanes' exclusive counts, the
+// one-candidate summaries go through the kernel's segmented inclusive scan (Hillis-Steele, keys = 2 * owner + strand,
+// join when the key d lanes below is the same) with core.h's summary_merge, and every owner merges the summary of the
+// last lane of its run in the turn into its own.  Each lane's two summaries must equal the in-order fold of its own
+// candidates -- the loop the list replaced.  Returns the number of (trial, lane, strand) that differ.
+long hh_candidate_list_check(uint32_t seed, uint32_t trials) {
+  std::mt19937 rng(seed);
+  long bad = 0;
+  for (uint32_t t = 0; t < trials; ++t) {
+    const uint32_t max_size = (t % 3 == 0) ? 4u : ((t % 3 == 1) ? 16u : 64u);
+    const uint32_t busy = 1u + rng() % 100u;  // per cent of the lanes with a region on a strand
+    uint32_t n_p[64], n_m[64], off[64], total = 0;
+    for (int l = 0; l < 64; ++l) {
+      n_p[l] = (rng() % 100u < busy) ? 1u + rng() % max_size : 0u;
+      n_m[l] = (rng() % 100u < busy) ? 1u + rng() % max_size : 0u;
+      off[l] = total;
+      total += n_p[l] + n_m[l];
+    }
+    std::vector<RegionSummary> one(total);
+    for (uint32_t q = 0; q < total; ++q)
+      one[q] = (rng() % 4u) ? summary_one(rng() % 3u, 1000u + rng() % 50u) : summary_empty();  // few values: ties are the point
+    RegionSummary want_p[64], want_m[64], got_p[64], got_m[64];
+    for (int l = 0; l < 64; ++l) {
+      want_p[l] = want_m[l] = got_p[l] = got_m[l] = summary_empty();
+      for (uint32_t k = 0; k < n_p[l]; ++k) want_p[l] = summary_merge(want_p[l], one[off[l] + k]);
+      for (uint32_t k = 0; k < n_m[l]; ++k) want_m[l] = summary_merge(want_m[l], one[off[l] + n_p[l] + k]);
+    }
+    for (uint32_t base = 0; base < total; base += 64) {
+      RegionSummary acc[64];
+      uint32_t key[64];
+      for (uint32_t lane = 0; lane < 64; ++lane) {
+        const uint32_t q = base + lane;
+        const bool have = q < total;
+        uint32_t own = 0;
+        for (uint32_t st = 32; st; st >>= 1) own = off[own + st] <= q ? own + st : own;
+        const uint32_t k = q - off[own];
+        const bool on_m = have && k >= n_p[own];
+        key[lane] = have ? 2u * own + (on_m ? 1u : 0u) : 0xFFFFFFFFu;
+        acc[lane] = have ? one[q] : summary_empty();
+      }
+      for (uint32_t d = 1; d < 64; d <<= 1) {
+        RegionSummary nxt[64];
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+          const bool join = lane >= d && key[lane - d] == key[lane];
+          nxt[lane] = join ? summary_merge(acc[lane - d], acc[lane]) : acc[lane];
+        }
+        for (uint32_t lane = 0; lane < 64; ++lane) acc[lane] = nxt[lane];
+      }
+      for (uint32_t l = 0; l < 64; ++l)
+        for (int f = 0; f < 2; ++f) {
+          const uint32_t lo = f ? off[l] + n_p[l] : off[l], hi = f ? off[l] + n_p[l] + n_m[l] : off[l] + n_p[l];
+          const uint32_t a = lo > base ? lo : base, e = hi < base + 64 ? hi : base + 64;
+          if (e <= a) continue;
+          RegionSummary& sum = f ? got_m[l] : got_p[l];
+          sum = summary_merge(sum, acc[e - 1 - base]);
+        }
+    }
+    auto same = [](const RegionSummary& x, const RegionSummary& y) {
+      return x.count == y.count && (x.count == 0 || (x.min_mm == y.min_mm && x.first == y.first && x.last == y.last));
+    };
+    for (int l = 0; l < 64; ++l) bad += (same(got_p[l], want_p[l]) ? 0 : 1) + (same(got_m[l], want_m[l]) ? 0 : 1);
   }
   return bad;
 }

@@ -163,6 +163,8 @@ def harness():
         L.hh_kary_check.restype = ctypes.c_long
         L.hh_fence_check.argtypes = [u32, u32]
         L.hh_fence_check.restype = ctypes.c_long
+        L.hh_candidate_list_check.argtypes = [u32, u32]
+        L.hh_candidate_list_check.restype = ctypes.c_long
         L.hh_tail_mask_check.argtypes = [u32]
         L.hh_tail_mask_check.restype = ctypes.c_long
         L.hh_pack.argtypes = [vp, vp, u32, ci, u32, u32, vp, ctypes.c_uint64]

@@ -375,3 +375,12 @@ def test_harness_tail_characters_narrowed_by_the_verifier(scratch, seed, monkeyp
             monkeypatch.delenv("WALT_AMD_TEST_DEFER_BREAKERS")
             assert all_ranges == ranges and differ_without_rule > 10, (all_ranges, differ_without_rule)
         h.close()
+
+
+def test_harness_candidate_list_gives_each_lane_its_own_fold():
+    """map_se.hip coop_lane_regions replaced "every lane walks its own regions" by one candidate list over the wavefront:
+    owner by bisection over the lanes' exclusive counts, one-candidate summaries through a segmented scan with
+    summary_merge, the last lane of a run handed back to its owner turn after turn.  The harness runs exactly those steps
+    on 64 simulated lanes (regions of up to 4 / 16 / 64 slots on both strands, lanes without regions, ties in mismatch
+    count and position) and compares every lane's two summaries with the in-order fold of its own candidates."""
+    assert refio.harness().hh_candidate_list_check(20261005, 3000) == 0
