@@ -1292,9 +1292,6 @@ WALT_HD Region lit_region_inferred(const StrandView& sv, const uint32_t* care, u
     have_table = olev_relevant(sv, h, T, lim, levels, dng, q_first, &counts, &beyond);
     if (!have_table) beyond = true;
   }
-#if !defined(__HIP_DEVICE_COMPILE__)
-  if (getenv("WALT_DBG_NOBEYOND")) beyond = false;  // (test of the test: without the flag, differences must show)
-#endif
   if (!have_table) {
     uint32_t hi = sv.n_outl;
     if (sv.outl_dir) {
