@@ -728,7 +728,8 @@ def pe_leg(cx, idx, d1, d2, d_off, n, read_len, max_mm, b, top_k, frag_range, st
     st = d_stats.cpu().numpy() // (warmup + steps)
     ctl = d_ws[:192 * 4].view(torch.int32).cpu().numpy()  # control words of the last pass (map_pe.hip carve_pe)
     return {"elapsed": elapsed, "per_step": per_step, "d_out": d_out, "stats": st,
-            "lists": {"literal": [int(ctl[64]), int(ctl[96])], "overflowed_small_heaps": [int(ctl[89]), int(ctl[121])],
+            "lists": {"literal": [int(ctl[64]), int(ctl[96])], "literal_round_in_one_launch": [int(ctl[67]), int(ctl[99])],
+                      "overflowed_small_heaps": [int(ctl[89]), int(ctl[121])],
                       "staged": [int(ctl[88]), int(ctl[120])], "staged_fallback": [int(ctl[90]), int(ctl[122])],
                       "staged_items": [[int(ctl[92]), int(ctl[93])], [int(ctl[124]), int(ctl[125])]],
                       "heavy_pairs": int(ctl[128])}}

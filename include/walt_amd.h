@@ -231,6 +231,7 @@ int walt_map_pe_batch_device(walt_index* idx, const void* d_bases1, const void* 
  *   pe_stage_cap   0  staged reads per round (0: default)  pe_small_heaps 0  force the 8-slot heaps of long literal lists
  *   pe_serial      0  mates and passes on one stream (profiling)   pe_push_wide 0  4-byte heap entries in the push kernel (A/B)
  *   pe_defer_min  -1  as se_defer_min                      pe_roomy    -1  -1: by the workspace's size, 0 / 1: forced
+ *   pe_lit_fuse    1  the literal round's three seed shifts in one launch when its list is short (0: seed by seed)
  * Set between calls, not during one.  WALT_EINVAL for an unknown name. */
 int walt_index_set_option(walt_index* idx, const char* name, long long value);
 int walt_index_get_option(const walt_index* idx, const char* name, long long* value);

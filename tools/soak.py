@@ -120,6 +120,10 @@ def run_soak(seconds, seed0=1, pattern=3, max_genomes=None):
             g_opt = rng.choice([0, 0, 0, 0, 1, 2])
             if g_opt:
                 idx.set_option("grid", g_opt)
+            # a quarter of the genomes with the paired-end literal round seed by seed (default: one launch when the list
+            # is short, map_pe.hip k_pe_stage); drawn from a generator of its own so that a seed's genome and reads stay
+            if random.Random(seed * 7919 + 13).random() < 0.25:
+                idx.set_option("pe_lit_fuse", 0)
             lengths = [lo + 2, lo + 3, 40, 45, 60, 100, 100, 100, 131, 140, min(150, hi), min(200, hi), hi]
             # the kernels are instantiated per read-length class (up to 112, 128, 160 ... bases: the batch's longest read
             # selects the instance): some genomes get batches that stop at 112 or 128 bases

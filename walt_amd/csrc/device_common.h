@@ -47,6 +47,7 @@ struct walt_options {
   int pe_serial = 0;          // mates and pipeline slots one after the other (profiling)
   int pe_push_wide = 0;       // 4-byte heap entries in the push kernel whatever -m is (A/B; 0: 2-byte entries when -m <= 15)
   long long pe_defer_min = -1;
+  int pe_lit_fuse = 1;        // the literal round's three seed shifts in one launch when its list is short (0: seed by seed; A/B)
   int pe_roomy = -1;          // -1: decided once per index from the device's free memory
 };
 

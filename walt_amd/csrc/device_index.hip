@@ -1137,7 +1137,7 @@ const OptionName kOptions[] = {
     WALT_OPT_I(se_heavy_mono, 0, 1),  WALT_OPT_L(grid, 0, 1ll << 20),           WALT_OPT_I(pe_mode, 0, 1),
     WALT_OPT_L(pe_chunk, 0, 1ll << 28), WALT_OPT_L(pe_rounds, 0, 4),            WALT_OPT_L(pe_stage_cap, 0, 1ll << 28),
     WALT_OPT_I(pe_small_heaps, 0, 1), WALT_OPT_I(pe_serial, 0, 1), WALT_OPT_I(pe_push_wide, 0, 1),              WALT_OPT_L(pe_defer_min, -1, 1ll << 30),
-    WALT_OPT_I(pe_roomy, -1, 1),
+    WALT_OPT_I(pe_roomy, -1, 1),      WALT_OPT_I(pe_lit_fuse, 0, 1),
 };
 #undef WALT_OPT_I
 #undef WALT_OPT_L

@@ -451,6 +451,8 @@ struct PeStage {
   ItemQueue q;       // 2 * ccap items (emptied after every seed); id = j | probe << 24, probe = 3 * strand + seed shift
   uint32_t ccap;     // staged reads per pass and mate
   uint32_t defer_min;  // long seeds: key-equal ranges of more slots than this are narrowed by the verifier (0xFFFFFFFF: never)
+  uint32_t lit_fuse;   // the literal round's three seed shifts in ONE launch when its list is short enough (k_pe_stage)
+  uint32_t* fused_note;  // control word 3 of the mate: set to 1 by a literal round that ran that way (tests, bench)
 };
 
 template <int NW, bool LITERAL>
@@ -459,8 +461,8 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
                                               uint32_t* __restrict__ err, uint32_t r, bool valid, uint32_t j,
                                               uint32_t strand_base, uint32_t max_mm, uint32_t b, const PeStage& ps,
                                               uint32_t* __restrict__ lit_count, uint32_t* __restrict__ lit_list,
-                                              uint32_t stage_seed, uint32_t top_k, uint32_t& n_probe, uint32_t& n_verified,
-                                              uint32_t& n_big) {
+                                              uint32_t stage_seed, uint32_t seed_last, uint32_t top_k, uint32_t& n_probe,
+                                              uint32_t& n_verified, uint32_t& n_big) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t top_step = top_step_of(n_chrom);
   const StrandView& svp = iv.s[strand_base];
@@ -516,8 +518,13 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
     (void)a0; (void)a1;
   }
 
+  // The literal round may take its seed shifts in one launch (k_pe_stage: seed_last = 2): every probe is made -- a
+  // superset of the superset above, k_pe_push applies the exact exits all the same -- and the items of all three seeds
+  // wait in the queue for one run of the verifier.  The ordinary rounds never do (seed_hi is the constant stage_seed).
+  const uint32_t seed_hi = LITERAL ? seed_last : stage_seed;
 #pragma unroll 1
-  for (uint32_t seed_i = stage_seed; seed_i <= stage_seed; ++seed_i) {
+  for (uint32_t seed_i = stage_seed; seed_i <= seed_hi; ++seed_i) {
+    if (LITERAL) z0_p = z1_p = z0_m = z1_m = 0;
     bool need = need_p || need_m;
     uint32_t care[kCareWords] = {0, 0, 0, 0};
     uint32_t slot = 0, span = 0;
@@ -690,6 +697,18 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   count = count > first ? count - first : 0u;
   if (!last_round && count > ps.ccap) count = ps.ccap;
   if (count == 0) return;
+  // The literal round of a pass holds a per cent of its reads, and each of its launches waits for the slowest lane's
+  // literal search: when six items per read fit the queue (two per read and seed is what it is sized for) the launch
+  // of seed 0 takes all three seed shifts and the launches of seeds 1 and 2 return at once; their verifier launches
+  // find the queue empty.  Decided here, from the list's length on the device, the same way by all three launches.
+  uint32_t seed_last = stage_seed;
+  if constexpr (LITERAL) {
+    if (ps.lit_fuse && last_round && first == 0 && (uint64_t)3 * count <= ps.ccap) {
+      if (stage_seed != 0) return;
+      seed_last = 2;
+      if (blockIdx.x == 0 && threadIdx.x == 0) *ps.fused_note = 1u;
+    }
+  }
   list += first;
   __shared__ BlockShared sh;
   __shared__ PreFilter pf;
@@ -703,7 +722,7 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
     const bool staged = in && i < ps.ccap;
     wave_append(in && !staged && stage_seed == 0, r, fb_count, fb_list);  // beyond the staged capacity of the pass: the list kernel's
     pe_stage_dual<NW, LITERAL>(iv, sh, pf, si, codes2, offsets, err, r, staged, (uint32_t)i, strand_base, max_mm, b, ps, lit_count,
-                      lit_list, stage_seed, top_k, n_probe, n_verified, n_big);
+                      lit_list, stage_seed, seed_last, top_k, n_probe, n_verified, n_big);
   }
   pe_flush(0u, n_probe, n_verified, n_big, stats);
 }
@@ -1372,7 +1391,8 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
                           uint32_t max_mm, uint32_t b, uint32_t top_k, uint32_t* heap_n,
                           Candidate* ranked, unsigned long long* stats, uint32_t* ctl, uint32_t* defer_list,
                           const PeWorkspace& w, int mate, hipStream_t stream) {
-  // ctl: [0] literal-list count, [8..23] its bins (launch_bin_deferred), [24] complex-list count
+  // ctl: [0] literal-list count, [3] 1 when the literal round took its seed shifts in one launch, [8..23] its bins
+  // (launch_bin_deferred), [24] complex-list count
   uint32_t* lit_count = ctl;
   uint32_t* cplx_count = ctl + 24;
   uint32_t* lit_list = defer_list;
@@ -1403,6 +1423,8 @@ static int launch_pe_topk(const walt_index* idx, const IndexView& view, const ui
     ps.q.items = w.items[mate]; ps.q.ctl = ctl + 28; ps.q.cap = 2 * w.ccap; ps.q.ovf = nullptr;
     ps.q.bigs = w.bigs[mate]; ps.q.big_n = ctl + 2; ps.q.big_cap = w.ccap / 8 + 64;
     ps.ccap = w.ccap;
+    ps.lit_fuse = idx->opt.pe_lit_fuse != 0 ? 1u : 0u;
+    ps.fused_note = ctl + 3;
     // option pe_defer_min = 0: never (A/B); = n: ranges of more than n slots (n >= the in-lane limit)
     const long long dm = idx->opt.pe_defer_min;
     ps.defer_min = dm < 0 ? (uint32_t)kSmallRegion : dm == 0 ? 0xFFFFFFFFu : (uint32_t)(dm < (long long)kSmallRegion ? (long long)kSmallRegion : dm);
