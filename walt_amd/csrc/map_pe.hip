@@ -461,8 +461,8 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
                                               uint32_t* __restrict__ err, uint32_t r, bool valid, uint32_t j,
                                               uint32_t strand_base, uint32_t max_mm, uint32_t b, const PeStage& ps,
                                               uint32_t* __restrict__ lit_count, uint32_t* __restrict__ lit_list,
-                                              uint32_t stage_seed, uint32_t seed_last, uint32_t top_k, uint32_t& n_probe,
-                                              uint32_t& n_verified, uint32_t& n_big) {
+                                              uint32_t stage_seed, uint32_t strands_in, bool every_probe, uint32_t top_k,
+                                              uint32_t& n_probe, uint32_t& n_verified, uint32_t& n_big) {
   const uint32_t n_chrom = iv.n_chrom;
   const uint32_t top_step = top_step_of(n_chrom);
   const StrandView& svp = iv.s[strand_base];
@@ -492,8 +492,13 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
   // was pushed, so that is: top_k pushed candidates that good.  Counted over the probes of the earlier seeds that
   // were made (a '+' probe of THIS seed or a later one could only add to what the '-' strand sees): never a
   // probe dropped that the reference makes; k_pe_push applies the exact exits.
-  bool need_p = mappable, need_m = mappable;
-  if (stage_seed > 0 && valid) {
+  // strands: which of the seed's two probes are this lane's (bit 0 '+', bit 1 '-').  Both, except in the literal round
+  // taken in one launch (k_pe_stage), where every (read, seed, strand) has a lane of its own and every probe is made
+  // (every_probe: the counts of the earlier seeds' items are not known yet -- a superset of the superset below).
+  const uint32_t strands = LITERAL ? strands_in : 3u;
+  const bool skip_exits = LITERAL && every_probe;
+  bool need_p = mappable && (strands & 1u), need_m = mappable && (strands & 2u);
+  if (stage_seed > 0 && valid && !skip_exits) {
     if (ps.flag[j] & 1u) mappable = need_p = need_m = false;  // went to the literal list at an earlier seed
     auto zeros = [&](uint32_t probe, bool made, uint32_t& a0, uint32_t& a1) {
       const uint32_t v = made ? ps.cz[(uint64_t)probe * ccap + j] : 0u;
@@ -518,13 +523,8 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
     (void)a0; (void)a1;
   }
 
-  // The literal round may take its seed shifts in one launch (k_pe_stage: seed_last = 2): every probe is made -- a
-  // superset of the superset above, k_pe_push applies the exact exits all the same -- and the items of all three seeds
-  // wait in the queue for one run of the verifier.  The ordinary rounds never do (seed_hi is the constant stage_seed).
-  const uint32_t seed_hi = LITERAL ? seed_last : stage_seed;
 #pragma unroll 1
-  for (uint32_t seed_i = stage_seed; seed_i <= seed_hi; ++seed_i) {
-    if (LITERAL) z0_p = z1_p = z0_m = z1_m = 0;
+  for (uint32_t seed_i = stage_seed; seed_i <= stage_seed; ++seed_i) {
     bool need = need_p || need_m;
     uint32_t care[kCareWords] = {0, 0, 0, 0};
     uint32_t slot = 0, span = 0;
@@ -672,17 +672,17 @@ __device__ __forceinline__ void pe_stage_dual(const IndexView& iv, BlockShared& 
       item_append2<NW>(take2, dense2, id2, l2, size2, rec2, lr.len, seed_i, lr.rd, mk, ps.q, tail2);  // one atomic for both strands' items
       n_big += (big_p ? 1u : 0u) + (big_m ? 1u : 0u);
     }
-    if (valid && !big_p) {  // an item's counts come from k_pe_verify
+    if (valid && !big_p && (strands & 1u)) {  // an item's counts come from k_pe_verify
       ps.surv_n[(uint64_t)probe_p * ccap + j] = cnt_p;
       ps.cz[(uint64_t)probe_p * ccap + j] = z0_p | (z1_p << 16);
     }
-    if (valid && !big_m) {
+    if (valid && !big_m && (strands & 2u)) {
       ps.surv_n[(uint64_t)probe_m * ccap + j] = cnt_m;
       ps.cz[(uint64_t)probe_m * ccap + j] = z0_m | (z1_m << 16);
     }
   }
   wave_append(dead, r <= kDeferMask ? (r | (defer_iter << kDeferShift)) : r, lit_count, lit_list);
-  if (valid && (stage_seed == 0 || dead)) ps.flag[j] = dead ? 1u : 0u;
+  if (valid && ((stage_seed == 0 && (strands & 1u)) || dead)) ps.flag[j] = dead ? 1u : 0u;
 }
 
 template <int NW, bool LITERAL>
@@ -698,14 +698,18 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   if (!last_round && count > ps.ccap) count = ps.ccap;
   if (count == 0) return;
   // The literal round of a pass holds a per cent of its reads, and each of its launches waits for the slowest lane's
-  // literal search: when six items per read fit the queue (two per read and seed is what it is sized for) the launch
-  // of seed 0 takes all three seed shifts and the launches of seeds 1 and 2 return at once; their verifier launches
+  // literal searches -- three launches, each a chain of up to two searches deep.  When six items per read fit the queue
+  // (two per read and seed is what it is sized for) the launch of seed 0 takes the whole round, one (read, seed, strand)
+  // per lane, probe-major: the list comes sorted by the iteration of the dangerous probe, so the lanes of a wavefront
+  // either all search literally or none does, and no lane runs more than one search.  Every probe is made (the exits
+  // between the seeds need the verifier's counts: a superset of the superset the ordinary rounds make, k_pe_push
+  // applies the exact exits all the same); the launches of seeds 1 and 2 return at once and their verifier launches
   // find the queue empty.  Decided here, from the list's length on the device, the same way by all three launches.
-  uint32_t seed_last = stage_seed;
+  bool fused = false;
   if constexpr (LITERAL) {
     if (ps.lit_fuse && last_round && first == 0 && (uint64_t)3 * count <= ps.ccap) {
       if (stage_seed != 0) return;
-      seed_last = 2;
+      fused = true;
       if (blockIdx.x == 0 && threadIdx.x == 0) *ps.fused_note = 1u;
     }
   }
@@ -715,14 +719,19 @@ __global__ __launch_bounds__(kBlock, (NW <= 8 ? 4 : (NW <= 10 ? 3 : 1))) void k_
   prefilter_stage(pf, iv, strand_base);
   const uint32_t* si = block_prologue(sh, iv, mask_table, strand_base);
   uint32_t n_probe = 0, n_verified = 0, n_big = 0;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < count; base += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t i = base + threadIdx.x;
-    const bool in = i < count;
+  const uint64_t total = fused ? (uint64_t)6 * count : (uint64_t)count;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < total; base += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v = base + threadIdx.x;
+    const bool in = v < total;
+    uint32_t pr = 0;   // fused: the probe this lane makes (0..2 '+', 3..5 '-')
+    uint64_t i = v;
+    if (fused && in) { pr = (uint32_t)(v / count); i = v - (uint64_t)pr * count; }
     const uint32_t r = in ? (list[i] & kDeferMask) : 0u;
     const bool staged = in && i < ps.ccap;
     wave_append(in && !staged && stage_seed == 0, r, fb_count, fb_list);  // beyond the staged capacity of the pass: the list kernel's
     pe_stage_dual<NW, LITERAL>(iv, sh, pf, si, codes2, offsets, err, r, staged, (uint32_t)i, strand_base, max_mm, b, ps, lit_count,
-                      lit_list, stage_seed, seed_last, top_k, n_probe, n_verified, n_big);
+                      lit_list, fused ? pr % 3u : stage_seed, fused ? (pr >= 3u ? 2u : 1u) : 3u, fused, top_k, n_probe, n_verified,
+                      n_big);
   }
   pe_flush(0u, n_probe, n_verified, n_big, stats);
 }
