@@ -1286,10 +1286,47 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
         bj = (int)bcast((uint32_t)j, last);
       }
     }
-    if (lane == 0) {
-      PairResult pr;
-      pair_finish(r1, (int)na, r2, (int)nb, len1, len2, starts, iv.n_chrom, max_mm, bi, bj, best_times, pr);
-      out[r] = pr;
+    // The tail of the merge (core.h pair_finish, paired.cpp:515-545) from the lists in LDS: lane 0 used to run it over
+    // the lists in device memory -- GetBestMatch4Single's fold is a chain of up to top_k dependent loads per mate, and a
+    // pair of a repeat family (the heavy pairs) is ambiguous more often than not: most of the kernel's duration.  The two
+    // mates' folds now run side by side on lanes 0 and 1 over the LDS copies.
+    {
+      BestMatch mine;
+      mine.genome_pos = 0; mine.times = 0; mine.strand = '+'; mine.mismatch = max_mm;
+      if (best_times != 1 && lane < 2) {  // paired.cpp:296-318, the fold of core.h best4single entry for entry
+        const uint4* const cl = lane ? cb : ca;
+        for (int k = (int)(lane ? nb : na) - 1; k >= 0; --k) {
+          const uint4 e = cl[k];
+          const uint32_t emm = e.y & 0x7FFFFFFFu;
+          const char es = (e.y >> 31) ? '-' : '+';
+          if (emm < mine.mismatch) {
+            mine.genome_pos = e.x; mine.times = 1; mine.strand = es; mine.mismatch = emm;
+          } else if (emm == mine.mismatch) {
+            if (mine.genome_pos == e.x) continue;
+            mine.genome_pos = e.x; mine.strand = es; mine.times++;
+          } else {
+            break;
+          }
+        }
+      }
+      const uint32_t o_pos = shfl_pin(mine.genome_pos, 1u), o_times = shfl_pin(mine.times, 1u);
+      const uint32_t o_strand = shfl_pin((uint32_t)(uint8_t)mine.strand, 1u), o_mm = shfl_pin(mine.mismatch, 1u);
+      if (lane == 0) {
+        PairResult pr;
+        pr.m1 = mine;
+        pr.m2.genome_pos = o_pos; pr.m2.times = o_times; pr.m2.strand = (char)o_strand; pr.m2.mismatch = o_mm;
+        pr.best_times = best_times; pr.frag_len = 0; pr.best_i = -1; pr.best_j = -1; pr.pair_mm = 0;
+        pr.pad_[0] = pr.pad_[1] = pr.pad_[2] = 0;
+        if (best_times == 1) {
+          const uint4 A = ca[bi], B = cb[bj];
+          pr.best_i = bi; pr.best_j = bj;
+          pr.frag_len = (A.y >> 31) ? (int)(A.w + len1 - B.w) : (int)(B.w + len2 - A.w);  // core.h pair_len
+          pr.pair_mm = (A.y & 0x7FFFFFFFu) + (B.y & 0x7FFFFFFFu);
+          pr.m1.genome_pos = A.x; pr.m1.times = 1; pr.m1.strand = (A.y >> 31) ? '-' : '+'; pr.m1.mismatch = A.y & 0x7FFFFFFFu;
+          pr.m2.genome_pos = B.x; pr.m2.times = 1; pr.m2.strand = (B.y >> 31) ? '-' : '+'; pr.m2.mismatch = B.y & 0x7FFFFFFFu;
+        }
+        out[r] = pr;
+      }
     }
   }
 }
