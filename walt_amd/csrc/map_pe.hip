@@ -1245,14 +1245,27 @@ __global__ __launch_bounds__(kBlock) void k_pe_merge_heavy(IndexView iv, const C
     uint32_t min_mm = max_mm, best_times = 0;
     uint32_t best_hi = 0, best_lo = 0;  // best_pos = (pos1 << 32) + pos2
     int bi = -1, bj = -1;
+    // combination c = base + lane is (i, j) = (na - 1 - c / nb, nb - 1 - c % nb): quotient and remainder are carried from
+    // step to step (one division per pair instead of one per step and lane).  Both lists are in pop order -- mismatches
+    // descending with the index -- so the combinations of a step and of every later one hold at least
+    // mismatches(first lane's i) + mismatches(best of list 2): once that exceeds min_mm nothing that follows can change
+    // the fold (the reference's `break`, paired.cpp:486-487, leaves the same combinations out row by row).
+    const uint32_t q_step = 64u / nb, r_step = 64u % nb;
+    uint32_t cq = lane / nb, cr = lane % nb;
+    const uint32_t best_b = cb[nb - 1].y & 0x7FFFFFFFu;
     for (uint32_t base = 0; base < total; base += 64) {
       const uint32_t c = base + lane;
+      const uint32_t q0 = shfl_pin(cq, 0u);  // (uniform) base / nb < na
+      if ((ca[na - 1 - q0].y & 0x7FFFFFFFu) + best_b > min_mm) break;
       bool ok = false;
       uint32_t mm = 0xFFFFFFFFu, p1 = 0, p2 = 0;
       int i = 0, j = 0;
+      const uint32_t my_q = cq, my_r = cr;
+      cq += q_step; cr += r_step;
+      if (cr >= nb) { cr -= nb; ++cq; }
       if (c < total) {
-        i = (int)(na - 1 - c / nb);
-        j = (int)(nb - 1 - c % nb);
+        i = (int)(na - 1 - my_q);
+        j = (int)(nb - 1 - my_r);
         const uint4 A = ca[i], B = cb[j];
         p1 = A.x; p2 = B.x;
         if ((A.y ^ B.y) >> 31) {  // opposite strands
